@@ -1,0 +1,120 @@
+"""Handle management shared by the nn.Module shells.
+
+The shells own ordinary torch parameter containers (so `state_dict()` keys, `.to()`,
+`.float()`, `load_state_dict()` and `.eval()` behave exactly like the reference's
+modules, evfly_ros/run.py:120-171) but never run them: `forward` hands the tensors to
+the C ABI (`evfly_model_*`, include/evfly_hip.h) which repacks them for the HIP
+kernels. The handle is rebuilt lazily whenever the parameters may have changed.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class HipHandle:
+    """RAII wrapper of an `evfly_model*`."""
+
+    def __init__(self, cfg, state_dict):
+        L = _lib.lib()
+        self._L = L
+        self.h = C.c_void_p()
+        _lib.check(L.evfly_model_create(C.byref(cfg), C.byref(self.h)))
+        for k, v in state_dict.items():
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            _lib.check(L.evfly_model_load_tensor(self.h, k.encode(), t.data_ptr(), shape, t.dim()))
+        _lib.check(L.evfly_model_finalize(self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._L.evfly_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tap(self, name, max_elems=1 << 26):
+        """Copy a named intermediate of the last forward to host (parity tests)."""
+        buf = torch.empty(max_elems, dtype=torch.float32)
+        shape = (C.c_int64 * 4)()
+        n = _lib.check(self._L.evfly_model_tap(self.h, name.encode(), buf.data_ptr(), max_elems, shape,
+                                               _lib.cur_stream()))
+        dims = [int(s) for s in shape if s > 0]
+        return buf[:n].reshape(dims).clone()
+
+    def profile(self):
+        L = self._L
+        out = []
+        name = C.create_string_buffer(128)
+        ms, fl, by, ln = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        for i in range(L.evfly_model_profile_count(self.h)):
+            L.evfly_model_profile_get(self.h, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by), C.byref(ln))
+            out.append(dict(name=name.value.decode(), ms=ms.value, flops=fl.value, bytes=by.value,
+                            launches=ln.value))
+        return out
+
+
+class HipModule(nn.Module):
+    """Base of the shells: lazily (re)builds the native handle from the current parameters."""
+
+    compute_dtype = 0  # _lib EVFLY_DTYPE_F32; set to 1 for bf16 MFMA operands
+
+    def __init__(self):
+        super().__init__()
+        self.__dict__["_hip"] = None
+        self.__dict__["_hip_built_at"] = -1
+        self.__dict__["_epoch"] = 0
+
+    # ---- invalidation: anything that can change parameter values bumps this module's epoch; a
+    # handle is stale when the epoch sum over the module and its HipModule descendants moved (so
+    # `model.origunet.load_state_dict(...)`, evfly_ros/run.py:161, also invalidates `model`).
+    def _bump(self):
+        self.__dict__["_epoch"] += 1
+
+    def _epoch_sum(self):
+        return sum(m.__dict__["_epoch"] for m in self.modules() if isinstance(m, HipModule))
+
+    def _apply(self, fn, *a, **kw):
+        self._bump()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._bump()
+        return super().load_state_dict(*a, **kw)
+
+    def refresh_weights(self):
+        """Call after mutating parameters in place."""
+        self._bump()
+
+    def set_compute_dtype(self, name):
+        self.compute_dtype = {"f32": 0, "fp32": 0, "bf16": 1}[name]
+        self._bump()
+        return self
+
+    # ---- subclasses provide the config + key prefixing
+    def _hip_config(self):
+        raise NotImplementedError
+
+    def _hip_state_dict(self):
+        return self.state_dict()
+
+    def hip(self):
+        h = self.__dict__["_hip"]
+        e = self._epoch_sum()
+        if h is None or self.__dict__["_hip_built_at"] != e:
+            h = HipHandle(self._hip_config(), self._hip_state_dict())
+            self.__dict__["_hip"] = h
+            self.__dict__["_hip_built_at"] = e
+        return h
+
+
+def to_gpu(t, dtype=torch.float32):
+    """Input staging (evfly_ros/run.py:247 `.to(self.device).float()`): returns a contiguous CUDA
+    tensor; host tensors are copied to the current device."""
+    _lib.lib()
+    if not t.is_cuda:
+        t = t.to("cuda")
+    return t.to(dtype).contiguous()

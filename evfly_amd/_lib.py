@@ -1,0 +1,107 @@
+"""ctypes binding of libevfly_hip.so (the C ABI declared in include/evfly_hip.h).
+
+There is no CPU fallback: every compute entry point of evfly_amd goes through this
+library, and `lib()` raises if it is missing or a GPU is not present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevfly_hip.so")
+_LIB = None
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_i64 = C.c_int64
+c_f = C.c_float
+c_d = C.c_double
+
+
+class ModelConfig(C.Structure):
+    """Mirror of `evfly_model_config` (include/evfly_hip.h)."""
+    _fields_ = [
+        ("has_unet", c_i), ("num_in_channels", c_i), ("num_out_channels", c_i), ("form_bev", c_i),
+        ("skip_type", c_i), ("num_recurrent_unet", c_i), ("input_h", c_i), ("input_w", c_i),
+        ("evs_min_cutoff", c_f), ("head", c_i),
+        ("vit_in_channels", c_i),
+        ("vit_width", c_i * 2), ("vit_heads", c_i * 2), ("vit_layers", c_i * 2),
+        ("vit_reduction", c_i * 2), ("vit_patch", c_i * 2), ("vit_stride", c_i * 2),
+        ("vit_pad", c_i * 2), ("vit_expansion", c_i),
+        ("compute_dtype", c_i),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/evfly_hip.h declares
+SIGNATURES = {
+    "evfly_abi_version": (c_i, []),
+    "evfly_last_error": (C.c_char_p, []),
+    "evfly_voxelize_windows": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_d, c_d,
+                                     c_p, c_p, c_p, c_p]),
+    "evfly_eventframe_rows_f64": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_d, c_d, c_i64, c_d, c_d,
+                                        c_p, c_p, c_p, c_p]),
+    "evfly_accumulate_u8": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
+    "evfly_accumulate_reset": (c_i, [c_p, c_i64, c_p]),
+    "evfly_condition_frames": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "evfly_model_create": (c_i, [C.POINTER(ModelConfig), C.POINTER(c_p)]),
+    "evfly_model_load_tensor": (c_i, [c_p, C.c_char_p, c_p, C.POINTER(c_i64), c_i]),
+    "evfly_model_finalize": (c_i, [c_p]),
+    "evfly_model_destroy": (None, [c_p]),
+    "evfly_unet_forward": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "evfly_vit_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "evfly_vit_stage_forward": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "evfly_e2v_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "evfly_model_tap": (c_i64, [c_p, C.c_char_p, c_p, c_i64, C.POINTER(c_i64), c_p]),
+    "evfly_model_set_profiling": (c_i, [c_p, c_i]),
+    "evfly_model_profile_count": (c_i, [c_p]),
+    "evfly_model_profile_get": (c_i, [c_p, c_i, C.c_char_p, c_i, C.POINTER(c_d), C.POINTER(c_d),
+                                      C.POINTER(c_d), C.POINTER(c_i)]),
+    "evfly_model_profile_reset": (c_i, [c_p]),
+    "evfly_op_conv2d_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
+                                   c_p, c_p, c_i, c_p]),
+}
+
+
+def load_library():
+    """dlopen the library and attach signatures (no GPU needed: used by the symbol test)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"evfly_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def lib():
+    """The library, for compute: additionally requires a visible GPU."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("evfly_amd: no MI355X/ROCm device visible; the HIP path is the only path "
+                           "(there is no CPU fallback).")
+    return load_library()
+
+
+def check(rc):
+    if rc < 0:
+        msg = load_library().evfly_last_error().decode(errors="replace")
+        raise RuntimeError(f"evfly_hip error {rc}: {msg}")
+    return rc
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "evfly_amd: tensor handed to the C ABI must be contiguous"
+    return t.data_ptr()
+
+
+def cur_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,127 @@
+"""Synthetic inputs and deterministic weight fill (bench, tests, golden generation).
+
+Nothing here is compute: it only produces reproducible event streams (SURVEY.md
+§8d distribution) and a by-name weight fill that can be re-created on the GPU
+box without the reference being present.
+
+Event wire format mirrors the reference's ROS message
+(`dv_ros_msgs/msg/Event.msg:1-5`: u16 x, u16 y, time ts, bool polarity) as a
+structure-of-arrays: x u16, y u16, t i64 (ns), p i8 -- 13 B / event.
+"""
+import zlib
+
+import numpy as np
+
+WINDOW_NS = 33_333_333  # 1/30 s windows (evfly_ros/src/node.cpp:70 PUBLISH_RATE)
+
+
+def make_stream(stream_id, T, H=260, W=346, events_per_window=60_000, polarity="pm1",
+                clustered=False, seed_base=1234):
+    """One synthetic event stream covering T windows of 1/30 s.
+
+    Returns dict(x u16, y u16, t i64 sorted, p i8) and the (T+1,) window edges.
+    polarity: "pm1" -> {-1,+1} (esim / to_events.py convention),
+              "01"  -> {0,1}   (rosbag / all_events convention).
+    """
+    rs = np.random.RandomState(seed_base + stream_id)
+    N = T * events_per_window
+    x = rs.randint(0, W, N).astype(np.uint16)
+    y = rs.randint(0, H, N).astype(np.uint16)
+    t = np.sort(rs.randint(0, T * WINDOW_NS, N)).astype(np.int64)
+    p = rs.randint(0, 2, N).astype(np.int8)
+    if clustered:
+        # half of the events come from 64 Gaussian blobs (sigma = 3 px): edge-like
+        # structure that stresses atomic contention.
+        nb = N // 2
+        cx = rs.randint(0, W, 64)
+        cy = rs.randint(0, H, 64)
+        which = rs.randint(0, 64, nb)
+        bx = np.clip(np.rint(cx[which] + 3.0 * rs.standard_normal(nb)), 0, W - 1)
+        by = np.clip(np.rint(cy[which] + 3.0 * rs.standard_normal(nb)), 0, H - 1)
+        x[:nb] = bx.astype(np.uint16)
+        y[:nb] = by.astype(np.uint16)
+    if polarity == "pm1":
+        p = (2 * p - 1).astype(np.int8)
+    edges = (np.arange(T + 1, dtype=np.int64) * WINDOW_NS)
+    return dict(x=x, y=y, t=t, p=p), edges
+
+
+def make_batch(B, T, H=260, W=346, events_per_window=60_000, polarity="pm1",
+               clustered=False, seed_base=1234, first_stream=0):
+    """B concatenated streams in SoA form + CSR-style offsets + (B, T+1) window edges."""
+    xs, ys, ts, ps, offs, edges = [], [], [], [], [0], []
+    for b in range(B):
+        ev, e = make_stream(first_stream + b, T, H, W, events_per_window, polarity,
+                            clustered, seed_base)
+        xs.append(ev["x"]); ys.append(ev["y"]); ts.append(ev["t"]); ps.append(ev["p"])
+        offs.append(offs[-1] + len(ev["x"]))
+        edges.append(e)
+    return dict(x=np.concatenate(xs), y=np.concatenate(ys), t=np.concatenate(ts),
+                p=np.concatenate(ps), offsets=np.asarray(offs, dtype=np.int64),
+                edges=np.stack(edges).astype(np.int64))
+
+
+def fill_tensor(name, shape):
+    """Deterministic, well-scaled fp32 fill for the state-dict entry `name`.
+
+    SURVEY.md §8c "Weight fill for goldens": default init gives degenerate
+    activations (depth std 1e-3), so a wrong kernel would be invisible. Seeds are
+    crc32(name) into numpy's frozen RandomState stream, so the GPU box can re-create
+    bit-identical weights without the reference.
+    """
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0xFFFFFFFF)
+    shape = tuple(int(s) for s in shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf in ("weight_u", "weight_v"):
+        v = rs.standard_normal(shape)
+        return (v / np.linalg.norm(v)).astype(np.float32)
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        if "upconv" in name:  # ConvTranspose2d weight is (Cin, Cout, kh, kw)
+            fan_in = shape[0]
+        gain = np.sqrt(2.0 / fan_in)
+        if leaf.startswith("weight_hh") or leaf.startswith("weight_ih") or "lstm.cell_list" in name:
+            gain = np.sqrt(1.0 / fan_in)
+        if name.endswith("unet_out.weight"):
+            gain *= 0.1  # keep depth*2 mostly inside the (0,1) clip of learner_models.py:634
+        return (rs.standard_normal(shape) * gain).astype(np.float32)
+    # 1-D: LayerNorm weight ~ 1, everything else (biases) ~ 0.1 N(0,1)
+    if leaf == "weight":
+        return (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)
+    return (0.1 * rs.standard_normal(shape)).astype(np.float32)
+
+
+def fill_state_dict(module_or_sd, prefix=""):
+    """Return {key: torch.Tensor} filled by name for every entry of a state dict."""
+    import torch
+    sd = module_or_sd.state_dict() if hasattr(module_or_sd, "state_dict") else module_or_sd
+    out = {}
+    for k, v in sd.items():
+        out[k] = fill_tensor(prefix + k, tuple(v.shape))
+    # Spectral-norm layers (A12): eval-time weight is weight_orig / (u^T W v). With
+    # independent random u, v that scalar is ~N(0, 2/fan_in) (tiny, any sign) and
+    # activations explode. Add the rank-1 bump u v^T so sigma = u^T W0 v + 1 ~ 1;
+    # elementwise, so bit-reproducible on any host.
+    for k in list(out):
+        if k.endswith(".weight_orig"):
+            stem = k[: -len("weight_orig")]
+            u, v = out[stem + "weight_u"], out[stem + "weight_v"]
+            out[k] = (out[k] + np.outer(u, v).astype(np.float32)).astype(np.float32)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
+
+
+def make_frames(seed, n, H=260, W=346, rate=0.35):
+    """n synthetic signed event-count frames (n,1,H,W) float32 = 0.2 * (Poisson - Poisson):
+    the value set the voxelizer produces (integer multiples of 0.2; ev_utils.py:139)."""
+    rs = np.random.RandomState(seed)
+    k = rs.poisson(rate, (n, 1, H, W)).astype(np.int32) - rs.poisson(rate, (n, 1, H, W)).astype(np.int32)
+    f = k.astype(np.float32)
+    f *= np.float32(0.2)
+    return f
+
+
+def make_u8_frames(seed, n, H=480, W=640, rate=0.35):
+    """n accumulator images (n,H,W) uint8 around 128 as evfly_ros/src/node.cpp publishes them."""
+    rs = np.random.RandomState(seed)
+    k = rs.poisson(rate, (n, H, W)).astype(np.int32) - rs.poisson(rate, (n, H, W)).astype(np.int32)
+    return ((128 + k) & 0xFF).astype(np.uint8)

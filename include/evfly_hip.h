@@ -1,0 +1,220 @@
+/* evfly_hip.h -- C ABI of libevfly_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the event -> frame -> depth -> velocity hot path of
+ * anish-bhattacharya/evfly. The reference has no FFI of its own (its boundary is a
+ * Python import surface); each entry point below names the reference
+ * lines it replaces (paths relative to the reference repository root). The Python
+ * host mirror in evfly_amd/ binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued on it and no entry point synchronises unless it says so;
+ *   - return value 0 = ok, negative = error; evfly_last_error() gives the text;
+ *   - tensors with one channel are plain (n, H, W) row-major; multi-channel device
+ *     tensors exposed through this ABI are NHWC (channels innermost);
+ *   - a handle is not thread-safe: one handle per host thread / stream / GPU.
+ */
+#ifndef EVFLY_HIP_H
+#define EVFLY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVFLY_ABI_VERSION 1
+
+int evfly_abi_version(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *evfly_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Event -> frame ("voxelizer")
+ * ---------------------------------------------------------------------------------------- */
+
+/* polarity conventions */
+#define EVFLY_POL_PM1 0 /* pos: p > 0, neg: p < 0   utils/ev_utils.py:137-138, utils/to_events.py:405-406 */
+#define EVFLY_POL_01 1  /* pos: p > 0, neg: p == 0  utils/ev_utils.py:155-156 */
+
+/* Replaces the per-trajectory window-slicing loop utils/to_events.py:394-411 (and, window by
+ * window, the timed mode of form_eventframe utils/ev_utils.py:125-140) for a batch of streams.
+ *
+ * Events are a structure of arrays (13 B / event; dv_ros_msgs/msg/Event.msg:1-5): stream b owns
+ * events [stream_offsets[b], stream_offsets[b+1]). Window w of stream b keeps the events with
+ * window_edges[b*(n_windows+1)+w] <= t < window_edges[b*(n_windows+1)+w+1]  (to_events.py:402-406),
+ * counts them per pixel and polarity (np.histogram2d semantics for integer coordinates: events
+ * with x >= width or y >= height are dropped) and forms
+ *     frame = pos_thresh * P - neg_thresh * N         (to_events.py:409, float64 arithmetic).
+ * Streams may be unsorted in time (the reference masks, it does not assume order); time-sorted
+ * streams take the fast path, which is decided on the device.
+ *
+ * Outputs (any may be NULL): frames_f32 / frames_f64 (n_streams, n_windows, height, width);
+ * counts_i32 (n_streams, n_windows, 2, height, width) with plane 0 = P, plane 1 = N. */
+int evfly_voxelize_windows(const uint16_t *x, const uint16_t *y, const int64_t *t, const int8_t *p,
+                           const int64_t *stream_offsets, int n_streams,
+                           const int64_t *window_edges, int n_windows,
+                           int height, int width, int polarity_mode,
+                           double pos_thresh, double neg_thresh,
+                           float *frames_f32, double *frames_f64, int32_t *counts_i32,
+                           void *stream);
+
+/* Replaces form_eventframe utils/ev_utils.py:113-161 on its native input: `rows` is the (n, 4)
+ * row-major float64 array [t_ns, x, y, p] (non-integer and out-of-range coordinates allowed;
+ * np.histogram2d semantics incl. the inclusive right edge x == width).
+ *   mode 0 (timed):  keep t0_ns <= t < t1_ns                       (:128),   polarity PM1
+ *   mode 1 (N):      first n_keep events with t >= t0_ns, in order (:132),   polarity PM1;
+ *                    *last_t_out (device double) = t of the last kept event (for :133)
+ *   mode 2 (all):    every event                                   (:155-158), polarity 01
+ * frame_f64 (height, width) float64 = pos_thresh*P - neg_thresh*N; counts_i32 (2,height,width) optional. */
+int evfly_eventframe_rows_f64(const double *rows, int64_t n, int height, int width, int mode,
+                              double t0_ns, double t1_ns, int64_t n_keep,
+                              double pos_thresh, double neg_thresh,
+                              double *frame_f64, int32_t *counts_i32, double *last_t_out,
+                              void *stream);
+
+/* Replaces ImagePublisher::eventArrayCallback of the two ROS accumulator nodes:
+ *   mode EVFLY_ACC_WRAP      evfly_ros/src/node.cpp:29-39     (uint8 ++/--, wraps mod 256)
+ *   mode EVFLY_ACC_SATURATE  evfly_dv_ros/src/node.cpp:29-43  (no ++ at 255, no -- at 0)
+ * Updates img (height*width uint8) in place with n events applied IN ORDER (the saturating walk
+ * is order dependent); events with x >= width or y >= height are ignored (node.cpp:31).
+ * polarity: nonzero = ON. The caller resets img to 128 between publishes (node.cpp:57-58), e.g.
+ * with evfly_accumulate_reset. */
+#define EVFLY_ACC_WRAP 0
+#define EVFLY_ACC_SATURATE 1
+int evfly_accumulate_u8(const uint16_t *x, const uint16_t *y, const uint8_t *polarity, int64_t n,
+                        int width, int height, int mode, uint8_t *img, void *stream);
+int evfly_accumulate_reset(uint8_t *img, int64_t n_pixels, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Frame conditioning (between voxelizer and model)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces evfly_ros/run.py:334-336,345-350,247-253 (twins: envtest/ros/run_competition.py:485-495,
+ * learner/dataloading.py:512-523) for n frames at once:
+ *   src_u8 != NULL : v = (float)(u8 - 128) * 0.2f           (run.py:334-336)   [src_f32 must be NULL]
+ *   src_f32 != NULL: v = src_f32
+ *   centre crop (in_h, in_w) -> (out_h, out_w) when they differ (run.py:345-350);
+ *   q = torch.quantile(|v|, quantile) per frame, exact fp32 rank/lerp arithmetic (run.py:250);
+ *   dst = clip(v / q, -1, 1)                                 (run.py:253)
+ * dst (n, out_h, out_w) f32; q_out (n) f32 optional. quantile <= 0 skips the scaling (dst = v). */
+int evfly_condition_frames(const uint8_t *src_u8, const float *src_f32, int n, int in_h, int in_w,
+                           int out_h, int out_w, float quantile, float *dst, float *q_out,
+                           void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Models
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct evfly_model evfly_model;
+
+#define EVFLY_SKIP_CROP 0
+#define EVFLY_SKIP_INTERP 1
+#define EVFLY_SKIP_NONE 2
+
+#define EVFLY_HEAD_NONE 0       /* OrigUNet only                      learner/learner_models.py:339 */
+#define EVFLY_HEAD_LSTMNETVIT 1 /* ... + LSTMNetVIT                   learner/vitfly_models.py:111  */
+#define EVFLY_HEAD_VIT 2        /* ... + ViT (FC head)                learner/vitfly_models.py:152  */
+
+#define EVFLY_DTYPE_F32 0  /* f32-input MFMA, exact fp32 */
+#define EVFLY_DTYPE_BF16 1 /* bf16 MFMA operands, fp32 accumulate / statistics */
+
+typedef struct evfly_model_config {
+    /* OrigUNet.__init__ arguments, learner/learner_models.py:340 */
+    int has_unet;          /* 0: ViT-only handle (depth images in), 1: U-Net present */
+    int num_in_channels;   /* as configured (2 in every shipped config); BEV 1/2 force 1 (:363-364) */
+    int num_out_channels;  /* 1 */
+    int form_bev;          /* 0, 1, 2 (:476-494) */
+    int skip_type;         /* EVFLY_SKIP_* (:510-519) */
+    int num_recurrent_unet;/* ConvLSTM layers in the bottleneck, 0 or 1 (:421-424) */
+    int input_h, input_w;  /* 260, 346 */
+    float evs_min_cutoff;  /* (:477) */
+    /* velocity model */
+    int head;              /* EVFLY_HEAD_* */
+    /* Mix-Transformer trunk widths: reference = {32,64} heads {1,2} layers {2,2} reduction {8,4}
+     * (learner/vitfly_models.py:118-121); "ViT-base" of BASELINE configs = {128,256}/{4,8}/{4,4}. */
+    int vit_in_channels;   /* 1 (depth image) */
+    int vit_width[2], vit_heads[2], vit_layers[2], vit_reduction[2];
+    int vit_patch[2], vit_stride[2], vit_pad[2]; /* {7,3} {4,2} {3,1} */
+    int vit_expansion;     /* 8 */
+    int compute_dtype;     /* EVFLY_DTYPE_* */
+} evfly_model_config;
+
+/* Replaces the module constructors + load_state_dict + .eval() (evfly_ros/run.py:106-171).
+ * Tensors are handed over by their reference state-dict key (SURVEY.md §8b "State-dict keys"),
+ * fp32, PyTorch layout, HOST memory; the library repacks (OIHW -> [O][kh][kw][I], ConvTranspose
+ * to 4 GEMM panels, spectral-norm fold W/(u.Wv), LSTM bias sum, flatten-order permute) in
+ * evfly_model_finalize and uploads. Keys of the composite carry the prefixes "origunet." /
+ * "vitfly_vitlstm." (learner/learner_models.py:622-624); a bare OrigUNet / LSTMNetVIT / ViT handle
+ * accepts un-prefixed keys too. */
+int evfly_model_create(const evfly_model_config *cfg, evfly_model **out);
+int evfly_model_load_tensor(evfly_model *m, const char *key, const float *data_host,
+                            const int64_t *shape, int ndim);
+int evfly_model_finalize(evfly_model *m);
+void evfly_model_destroy(evfly_model *m);
+
+/* Replaces OrigUNet.forward learner/learner_models.py:521-616 (velpred = 0, decoder always run).
+ * frames: (n_streams * T, input_h, input_w) conditioned event frames laid out [stream][t]; the T
+ * frames of a stream are consecutive time steps (the reference's batch-as-time ConvLSTM,
+ * learner_models.py:544-546), streams are independent. The reference call is n_streams = 1.
+ * h_state / c_state: (n_streams, 8, 13, 512) NHWC ConvLSTM state, read and updated in place; NULL =
+ * start from zeros and discard. depth_out (n_streams*T, input_h, input_w) = y_interp,
+ * upconv_out (n_streams*T, 68, 148) = y_upconv; either may be NULL. Does not modify `frames`
+ * (the reference mutates its input in place, learner_models.py:477). */
+int evfly_unet_forward(evfly_model *m, const float *frames, int n_streams, int T,
+                       float *h_state, float *c_state, float *depth_out, float *upconv_out,
+                       void *stream);
+
+/* Replaces LSTMNetVIT.forward learner/vitfly_models.py:132-150 / ViT.forward :170-186, including
+ * refine_inputs :18-31. img: (n_streams*T, img_h, img_w) depth images (bilinearly resized to 60x90
+ * when different, :28-29); clip2x != 0 first applies clip(2*img, 0, 1) (learner_models.py:634).
+ * desvel (n_streams*T); quat (n_streams*T, 4) or NULL = [1,0,0,0]. lstm_h / lstm_c:
+ * (n_streams, 3, 128) nn.LSTM state read and updated in place, NULL = zeros (ignored by HEAD_VIT).
+ * vel_out (n_streams*T, 3). */
+int evfly_vit_forward(evfly_model *m, const float *img, int img_h, int img_w, int clip2x,
+                      const float *desvel, const float *quat, int n_streams, int T,
+                      float *lstm_h, float *lstm_c, float *vel_out, void *stream);
+
+/* Replaces MixTransformerEncoderLayer.forward learner/ViTsubmodules.py:132-148 for trunk stage
+ * `stage` (0 or 1) of the handle: x (n, h, w, Cin) NHWC -> y (n, h', w', C) NHWC. */
+int evfly_vit_stage_forward(evfly_model *m, int stage, const float *x, int n, int h, int w,
+                            float *y, void *stream);
+
+/* Replaces OrigUNet_w_VITFLY_ViTLSTM.forward learner/learner_models.py:629-636: U-Net, then
+ * clip(2*depth, 0, 1), then the velocity head, without materialising the depth hand-off on the
+ * host. Arguments as above. */
+int evfly_e2v_forward(evfly_model *m, const float *frames, const float *desvel, int n_streams, int T,
+                      float *h_state, float *c_state, float *lstm_h, float *lstm_c,
+                      float *depth_out, float *upconv_out, float *vel_out, void *stream);
+
+/* Debug / parity taps: copy a named intermediate of the LAST forward into dst_host (synchronises
+ * `stream`). Writes up to 4 dims into shape_out and returns the element count (negative on error).
+ * Names: "e1".."e5", "e5_lstm", "d1".."d4", "vit_in", "s1", "s2", "flat", "x517". NHWC. */
+int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_host, int64_t max_elems,
+                        int64_t *shape_out, void *stream);
+
+/* Names + average device time (ms, HIP events on `stream`) of the kernels of the last profiled
+ * forward; enabled by evfly_model_set_profiling(m, 1). Used by bench.py for the roofline object. */
+int evfly_model_set_profiling(evfly_model *m, int enable);
+int evfly_model_profile_count(evfly_model *m);
+int evfly_model_profile_get(evfly_model *m, int i, char *name_out, int name_cap, double *ms_out,
+                            double *flops_out, double *bytes_out, int *launches_out);
+int evfly_model_profile_reset(evfly_model *m);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-operator entry points (kernel-level parity tests; same kernels the models launch)
+ * ---------------------------------------------------------------------------------------- */
+
+/* y[N,OH,OW,Cout] = act(conv2d(x[N,H,W,Cin], w) + bias (+ res)); w_packed is [Cout][KH][KW][Cin].
+ * act: 0 none, 1 relu, 2 leaky_relu(0.01). dtype EVFLY_DTYPE_*. */
+int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin, const float *w_packed,
+                         const float *bias, int cout, int kh, int kw, int stride, int pad, int act,
+                         const float *res, float *y, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVFLY_HIP_H */

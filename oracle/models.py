@@ -1,0 +1,278 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- model forward oracle.
+
+Functional torch-CPU fp32 restatement of the reference forward passes, written
+against a flat state dict {reference key -> tensor}. This is the "plain PyTorch fp32
+reference" for the floating-point HIP kernels. Every function cites the reference
+lines it follows; op semantics (conv, linear, layer_norm, softmax, gelu-erf,
+bilinear interpolate, pixel_shuffle) come from torch itself on both sides.
+
+Batch-as-time: both recurrent modules treat the rows of a batch as
+consecutive time steps of ONE stream.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------- helpers
+
+
+def _p(sd, key):
+    return sd[key].float()
+
+
+def spectral_weight(sd, stem):
+    """Old-style torch.nn.utils.spectral_norm in eval mode: W = weight_orig / (u . (W v)),
+    no power iteration (used at learner/vitfly_models.py:123,126,164,165)."""
+    w, u, v = _p(sd, stem + "weight_orig"), _p(sd, stem + "weight_u"), _p(sd, stem + "weight_v")
+    sigma = torch.dot(u, torch.mv(w, v))
+    return w / sigma
+
+
+def _conv(sd, stem, x, **kw):
+    return F.conv2d(x, _p(sd, stem + "weight"), sd.get(stem + "bias"), **kw)
+
+
+def _linear(sd, stem, x):
+    return F.linear(x, _p(sd, stem + "weight"), _p(sd, stem + "bias"))
+
+
+def _ln(sd, stem, x):
+    return F.layer_norm(x, (x.shape[-1],), _p(sd, stem + "weight"), _p(sd, stem + "bias"), 1e-5)
+
+
+# ----------------------------------------------------------------------------- ConvLSTM
+
+
+def convlstm_forward(sd, stem, x_seq, state=None):
+    """learner/ConvLSTM_pytorch/convlstm.py:38-53,120-176 for the configuration used at
+    learner/learner_models.py:421-424: one layer, 1x1 kernel, no bias, batch 1.
+    x_seq: (T, C, h, w) = the time steps. state: [[h, c]] each (1, C, h, w) or None.
+    Returns (outputs (T, C, h, w), [[h, c]])."""
+    w = _p(sd, stem + "cell_list.0.conv.weight")
+    hid = w.shape[0] // 4
+    T = x_seq.shape[0]
+    if state is None:
+        h = torch.zeros(1, hid, *x_seq.shape[-2:])
+        c = torch.zeros_like(h)
+    else:
+        h, c = state[0]
+    outs = []
+    for t in range(T):
+        comb = torch.cat([x_seq[t:t + 1], h], dim=1)             # :41
+        cc = F.conv2d(comb, w)                                   # :43
+        cc_i, cc_f, cc_o, cc_g = torch.split(cc, hid, dim=1)     # :44  (order i, f, o, g)
+        i, f, o, g = torch.sigmoid(cc_i), torch.sigmoid(cc_f), torch.sigmoid(cc_o), torch.tanh(cc_g)
+        c = f * c + i * g                                        # :50
+        h = o * torch.tanh(c)                                    # :51
+        outs.append(h)
+    return torch.cat(outs, dim=0), [[h, c]]
+
+
+# ----------------------------------------------------------------------------- OrigUNet
+
+_SKIPS = (((25, 35), (16, 26)), ((58, 79), (24, 44)), ((124, 167), (40, 80)), ((256, 342), (72, 152)))
+
+
+def _skip(y, big, small, skip_type):
+    """learner/learner_models.py:510-519"""
+    if skip_type == "crop":
+        return y[:, :, big[0] // 2 - small[0] // 2: big[0] // 2 + small[0] // 2,
+                 big[1] // 2 - small[1] // 2: big[1] // 2 + small[1] // 2]
+    if skip_type == "interp":
+        return F.interpolate(y, size=small, mode="bilinear", align_corners=False)
+    if skip_type == "none":
+        return None
+    raise ValueError(skip_type)
+
+
+def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff=0.15,
+                     skip_type="interp", num_recurrent=(1, 0), input_hw=(260, 346), num_in_channels=2,
+                     return_taps=False):
+    """learner/learner_models.py:521-616 with velpred=0, is_deployment=False.
+    x: (T,1,260,346) float32 conditioned frames = consecutive steps of one stream.
+    Returns y_vel, (y_interp, y_upconv, (h_unet, None))."""
+    from .conditioning import form_input
+    P = prefix
+    relu = F.relu
+    im = form_input(x, evs_min_cutoff, form_BEV) if (num_in_channels == 2 or form_BEV > 0) else x  # :523-524
+    taps = {}
+    y_e1 = relu(_conv(sd, P + "unet_e12.", relu(_conv(sd, P + "unet_e11.", im))))   # :533
+    e = F.max_pool2d(y_e1, 2, 2)
+    y_e2 = relu(_conv(sd, P + "unet_e22.", relu(_conv(sd, P + "unet_e21.", e))))    # :535
+    e = F.max_pool2d(y_e2, 2, 2)
+    y_e3 = relu(_conv(sd, P + "unet_e32.", relu(_conv(sd, P + "unet_e31.", e))))    # :537
+    e = F.max_pool2d(y_e3, 2, 2)
+    y_e4 = relu(_conv(sd, P + "unet_e42.", relu(_conv(sd, P + "unet_e41.", e))))    # :539
+    e = F.max_pool2d(y_e4, 2, 2)
+    y_e5 = relu(_conv(sd, P + "unet_e52.", relu(_conv(sd, P + "unet_e51.", e))))    # :541
+    taps["y_e5_pre"] = y_e5
+    h_unet = None
+    if num_recurrent[0] > 0:                                                        # :544-546
+        y_e5, h_unet = convlstm_forward(sd, P + "lstm.", y_e5, state)
+    taps["y_e5"] = y_e5
+    y = y_e5
+    for lvl, (enc, (big, small)) in enumerate(zip((y_e4, y_e3, y_e2, y_e1), _SKIPS), start=1):
+        up = F.conv_transpose2d(y, _p(sd, P + f"unet_upconv{lvl}.weight"),
+                                _p(sd, P + f"unet_upconv{lvl}.bias"), stride=2)
+        sk = _skip(enc, big, small, skip_type)
+        cat = torch.cat((sk, up), 1) if sk is not None else up                       # :559 (skip first)
+        y = relu(_conv(sd, P + f"unet_d{lvl}2.", relu(_conv(sd, P + f"unet_d{lvl}1.", cat))))
+        taps[f"y_d{lvl}"] = y
+    y_upconv = _conv(sd, P + "unet_out.", y)                                        # :583
+    y_interp = F.interpolate(y_upconv, size=input_hw, mode="bilinear", align_corners=False)  # :497
+    y_vel = torch.tensor([1., 0., 0.]).repeat(x.shape[0], 1)                        # :590-591
+    out = (y_vel, (y_interp, y_upconv, (h_unet, None)))
+    return (out, taps) if return_taps else out
+
+
+# ----------------------------------------------------------------------------- Mix-Transformer
+
+
+def esa_forward(sd, stem, x, H, W, reduction_ratio, heads):
+    """learner/ViTsubmodules.py:54-83 EfficientSelfAttention."""
+    B, N, C = x.shape
+    x1 = x.permute(0, 2, 1).reshape(B, C, H, W)
+    x1 = _conv(sd, stem + "cn1.", x1, stride=reduction_ratio)                       # :69 (no padding)
+    x1 = x1.reshape(B, C, -1).permute(0, 2, 1)
+    x1 = _ln(sd, stem + "ln1.", x1)                                                 # :71
+    kv = _linear(sd, stem + "keyValueExtractor.", x1)                               # :73
+    kv = kv.reshape(B, -1, 2, heads, C // heads).permute(2, 0, 3, 1, 4)             # :74
+    k, v = kv[0], kv[1]
+    q = _linear(sd, stem + "query.", x).reshape(B, N, heads, C // heads).permute(0, 2, 1, 3)
+    att = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(C / heads), dim=-1)     # :78-79
+    att = (att @ v).transpose(1, 2).reshape(B, N, C)                                # :80
+    return _linear(sd, stem + "finalLayer.", att)                                   # :82
+
+
+def mixffn_forward(sd, stem, x, H, W, channels):
+    """learner/ViTsubmodules.py:98-120 MixFFN (grouped 3x3 'same', groups=channels; erf GELU)."""
+    x = _linear(sd, stem + "mlp1.", x)
+    B, N, C = x.shape
+    x = x.transpose(1, 2).reshape(B, C, H, W)
+    x = _conv(sd, stem + "depthwise.", x, padding=1, groups=channels)
+    x = F.gelu(x.flatten(2).transpose(1, 2))
+    return _linear(sd, stem + "mlp2.", x)
+
+
+def mix_stage_forward(sd, stem, x, *, patch, stride, padding, n_layers, reduction, heads):
+    """learner/ViTsubmodules.py:132-148 MixTransformerEncoderLayer. x (B,Cin,H,W) -> (B,C,H',W')."""
+    B = x.shape[0]
+    y = _conv(sd, stem + "patchMerge.cn1.", x, stride=stride, padding=padding)      # :30
+    C, H, W = y.shape[1:]
+    y = _ln(sd, stem + "patchMerge.layerNorm.", y.flatten(2).transpose(1, 2))       # :32-33
+    for i in range(n_layers):
+        y = y + esa_forward(sd, stem + f"_attn.{i}.", y, H, W, reduction, heads)    # :144
+        y = y + mixffn_forward(sd, stem + f"_ffn.{i}.", y, H, W, C)                 # :145
+        y = _ln(sd, stem + f"_lNorm.{i}.", y)                                       # :146
+    return y.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+VIT_STAGES = (dict(patch=7, stride=4, padding=3, n_layers=2, reduction=8, heads=1),
+              dict(patch=3, stride=2, padding=1, n_layers=2, reduction=4, heads=2))
+
+
+# ----------------------------------------------------------------------------- nn.LSTM
+
+
+def lstm_forward(sd, stem, x, state=None, num_layers=3):
+    """torch.nn.LSTM restated for an UNBATCHED (T, in) sequence (how learner/vitfly_models.py:144-148
+    calls it with a 2-D tensor): gate order i, f, g, o, biases b_ih + b_hh, eval mode (no dropout).
+    state: (h, c) each (num_layers, hid) or None. Returns (out (T, hid), (h, c))."""
+    T = x.shape[0]
+    hid = sd[stem + "weight_hh_l0"].shape[1]
+    if state is None:
+        h0 = torch.zeros(num_layers, hid); c0 = torch.zeros(num_layers, hid)
+    else:
+        h0, c0 = state
+    hs, cs = [], []
+    inp = x
+    for l in range(num_layers):
+        w_ih, w_hh = _p(sd, stem + f"weight_ih_l{l}"), _p(sd, stem + f"weight_hh_l{l}")
+        b = _p(sd, stem + f"bias_ih_l{l}") + _p(sd, stem + f"bias_hh_l{l}") \
+            if (stem + f"bias_ih_l{l}") in sd else 0.0
+        h, c = h0[l], c0[l]
+        outs = []
+        for t in range(T):
+            g = F.linear(inp[t], w_ih) + F.linear(h, w_hh) + b
+            i, f, gg, o = g.chunk(4)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        inp = torch.stack(outs)
+        hs.append(h); cs.append(c)
+    return inp, (torch.stack(hs), torch.stack(cs))
+
+
+# ----------------------------------------------------------------------------- ViT heads
+
+
+def refine_inputs(X):
+    """learner/vitfly_models.py:18-31"""
+    X = list(X)
+    if X[2] is None:
+        X[2] = torch.zeros((X[0].shape[0], 4)); X[2][:, 0] = 1
+    if X[0].shape[-2] != 60 or X[0].shape[-1] != 90:
+        X[0] = F.interpolate(X[0], size=(60, 90), mode="bilinear")
+    return X
+
+
+def vit_trunk(sd, prefix, img, return_taps=False):
+    """Shared trunk of LSTMNetVIT / ViT: learner/vitfly_models.py:136-143 (== :174-181)."""
+    s1 = mix_stage_forward(sd, prefix + "encoder_blocks.0.", img, **VIT_STAGES[0])
+    s2 = mix_stage_forward(sd, prefix + "encoder_blocks.1.", s1, **VIT_STAGES[1])
+    up = F.interpolate(s1, size=(16, 24), mode="bilinear", align_corners=True)      # :128
+    out = torch.cat([F.pixel_shuffle(s2, 2), up], dim=1)                            # :141
+    out = _conv(sd, prefix + "down_sample.", out, padding=1)                        # :142
+    flat = out.flatten(1)
+    return (flat, dict(s1=s1, s2=s2)) if return_taps else flat
+
+
+def lstmnetvit_forward(sd, X, prefix="", return_taps=False):
+    """learner/vitfly_models.py:132-150. X = [img (T,1,h,w), desvel (T,1), quat (T,4)|None, (h,c)|absent]."""
+    X = refine_inputs(X)
+    flat, taps = vit_trunk(sd, prefix, X[0].float(), return_taps=True)
+    out = F.linear(flat, spectral_weight(sd, prefix + "decoder."), _p(sd, prefix + "decoder.bias"))
+    taps["dec512"] = out
+    out = torch.cat([out, X[1] / 10, X[2]], dim=1).float()                          # :144
+    taps["x517"] = out
+    out, h = lstm_forward(sd, prefix + "lstm.", out, X[3] if len(X) > 3 else None)  # :145-148
+    out = F.linear(out, spectral_weight(sd, prefix + "nn_fc2."), _p(sd, prefix + "nn_fc2.bias"))
+    return (out, h, taps) if return_taps else (out, h)
+
+
+def vit_forward(sd, X, prefix="", return_taps=False):
+    """learner/vitfly_models.py:170-186 (FC head, rows independent)."""
+    X = refine_inputs(X)
+    flat, taps = vit_trunk(sd, prefix, X[0].float(), return_taps=True)
+    out = _linear(sd, prefix + "decoder.", flat)                                    # plain Linear here (:163)
+    out = torch.cat([out, X[1] / 10, X[2]], dim=1).float()
+    taps["x517"] = out
+    out = F.leaky_relu(F.linear(out, spectral_weight(sd, prefix + "nn_fc1."), _p(sd, prefix + "nn_fc1.bias")))
+    out = F.linear(out, spectral_weight(sd, prefix + "nn_fc2."), _p(sd, prefix + "nn_fc2.bias"))
+    return (out, None, taps) if return_taps else (out, None)
+
+
+# ----------------------------------------------------------------------------- composite
+
+
+def composite_forward(sd, X, **unet_kw):
+    """learner/learner_models.py:629-636 OrigUNet_w_VITFLY_ViTLSTM.
+    X = [frames (T,1,260,346), desvel (T,1), [h_unet|None, None], (h,c)|None]."""
+    st = X[2][0] if X[2] is not None else None
+    _, (x_depth, y_upconv, (h_unet, h_velpred)) = origunet_forward(sd, X[0], st, prefix="origunet.", **unet_kw)
+    x_depth_input = torch.clip(x_depth * 2, 0.0, 1.0)                               # :634
+    vit_in = [x_depth_input, X[1], None] + ([X[3]] if X[3] is not None else [])
+    x_vel, h_vitlstm = lstmnetvit_forward(sd, vit_in, prefix="vitfly_vitlstm.")
+    return x_vel, (x_depth, y_upconv, ((h_unet, h_velpred), h_vitlstm))
+
+
+def composite_streams(sd, frames, desvel, n_streams, T, **unet_kw):
+    """Multi-stream convenience: frames (n_streams*T,1,H,W) laid out [stream][t]; every stream is
+    an independent zero-state sequence run through `composite_forward`."""
+    vels, depths = [], []
+    for s in range(n_streams):
+        sl = slice(s * T, (s + 1) * T)
+        v, (d, _, _) = composite_forward(sd, [frames[sl], desvel[sl], [None, None], None], **unet_kw)
+        vels.append(v); depths.append(d)
+    return torch.cat(vels), torch.cat(depths)

@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference, read-only):
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py
+
+The reference modules are imported from where they lie; nothing of them is copied.
+Inputs are regenerated from seeds by `evfly_amd.synthetic` on the test side, so only
+OUTPUTS (and a few intermediates) are stored. Weights are the deterministic by-name
+fill `evfly_amd.synthetic.fill_state_dict`, loaded into the reference modules with
+`load_state_dict` (so the reference runs with exactly the tensors the tests use).
+
+Fixture ids follow SURVEY.md §8c (G1..G8).
+"""
+import os
+import sys
+import zlib
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+REF = os.environ.get("EVFLY_REFERENCE", "/root/reference")
+sys.path += [os.path.join(REF, "learner"), os.path.join(REF, "utils")]
+
+import numpy as np
+import torch
+
+from evfly_amd import synthetic as syn
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+import ev_utils as ref_ev            # noqa: E402  (reference)
+import learner_models as ref_lm      # noqa: E402
+import vitfly_models as ref_vm       # noqa: E402
+import ViTsubmodules as ref_vs       # noqa: E402
+from ConvLSTM_pytorch.convlstm import ConvLSTM as RefConvLSTM  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def sparse(a):
+    a = np.asarray(a)
+    idx = np.flatnonzero(a)
+    return idx.astype(np.int32), a.reshape(-1)[idx]
+
+
+def rows_f64(ev):
+    """SoA -> the (n,4) float64 [t,x,y,p] rows the reference consumes (depth_and_events_script.py:160-168)."""
+    return np.stack([ev["t"].astype(np.float64), ev["x"].astype(np.float64),
+                     ev["y"].astype(np.float64), ev["p"].astype(np.float64)], axis=1)
+
+
+# ------------------------------------------------------------------ G1: voxelizer
+def g1():
+    H, W, T, EPW = 260, 346, 5, 12_000
+    out = {}
+    for s in range(3):
+        ev, edges = syn.make_stream(100 + s, T, H, W, EPW, polarity="pm1", seed_base=1000, clustered=(s == 2))
+        rows = rows_f64(ev)
+        # (c) T windows, exactly the per-window expression of to_events.py:405-409, via histogram2d
+        frames = np.zeros((T, H, W))
+        for i in range(T):
+            m = (ev["t"] >= edges[i]) & (ev["t"] < edges[i + 1])
+            pos, neg = m & (ev["p"] > 0), m & (ev["p"] < 0)
+            fr = 0.2 * np.histogram2d(ev["x"][pos], ev["y"][pos], bins=(W, H), range=[[0, W], [0, H]])[0] \
+                - 0.2 * np.histogram2d(ev["x"][neg], ev["y"][neg], bins=(W, H), range=[[0, W], [0, H]])[0]
+            frames[i] = fr.T
+            # (b) the same window through form_eventframe's timed mode must agree
+            fr2, _ = ref_ev.form_eventframe(rows, H, W, times0=edges[i] / 1e9, times1=[edges[i + 1] / 1e9])
+            # times0*1e9 is a float64 round trip of an int64 edge: only compare when it is exact
+            if float(edges[i] / 1e9) * 1e9 == float(edges[i]) and float(edges[i + 1] / 1e9) * 1e9 == float(edges[i + 1]):
+                assert np.array_equal(fr2, frames[i])
+        out[f"s{s}_win_idx"], out[f"s{s}_win_val"] = sparse(frames)
+        # (a) all_events mode on the {0,1} polarity convention (whole stream in one frame)
+        ev01, _ = syn.make_stream(100 + s, T, H, W, EPW, polarity="01", seed_base=1000, clustered=(s == 2))
+        fa = ref_ev.form_eventframe(rows_f64(ev01), H, W, all_events=True)
+        out[f"s{s}_all_idx"], out[f"s{s}_all_val"] = sparse(fa)
+        # (b') timed mode with non-trivial float bounds and different thresholds
+        t0, t1 = 0.0123, 0.0789
+        ft, t1o = ref_ev.form_eventframe(rows, H, W, times0=t0, times1=[t1], pos_thresh=0.3, neg_thresh=0.1)
+        out[f"s{s}_timed_idx"], out[f"s{s}_timed_val"] = sparse(ft)
+        # N mode
+        fn, t1n = ref_ev.form_eventframe(rows, H, W, times0=t0, N=5000)
+        out[f"s{s}_nmode_idx"], out[f"s{s}_nmode_val"] = sparse(fn)
+        out[f"s{s}_nmode_t1"] = np.float64(t1n)
+    # edge cases on a tiny grid: x==W, y==H (right edge inclusive), negatives, beyond, fractional
+    H, W = 8, 10
+    rows = np.array([[0, 10.0, 3, 1], [1, 9.999, 3, 1], [2, -0.5, 3, 1], [3, 10.5, 3, 1], [4, 2, 8.0, 0],
+                     [5, 2, 8.1, 0], [6, 0.0, 0.0, 1], [7, 2.7, 5.2, 0], [8, 2.7, 5.2, 1], [9, 2, -1e-9, 1],
+                     [10, 9, 7, 0], [11, 9, 7, 0], [12, 9, 7, 1]], dtype=np.float64)
+    out["edge_rows"] = rows
+    out["edge_all"] = ref_ev.form_eventframe(rows, H, W, all_events=True)
+    rows_pm = rows.copy(); rows_pm[:, 3] = 2 * rows_pm[:, 3] - 1
+    out["edge_timed"], _ = ref_ev.form_eventframe(rows_pm, H, W, times0=2e-9, times1=[11e-9])
+    out["empty_all"] = ref_ev.form_eventframe(np.zeros((0, 4)), H, W, all_events=True)
+    out["empty_timed"] = ref_ev.form_eventframe(np.zeros((0, 4)), H, W, times0=0.0, times1=[1.0])[0]
+    save("g1_voxel", **out)
+
+
+# ------------------------------------------------------------------ G3: conditioning
+def g3():
+    u8 = syn.make_u8_frames(7, 3)                                   # (3,480,640)
+    out = {}
+    net = ref_lm.OrigUNet(num_in_channels=2, num_out_channels=1, num_recurrent=[0, 0], input_shape=[1, 1, 260, 346],
+                          velpred=0, form_BEV=2, evs_min_cutoff=0.15, skip_type="interp", logger=lambda *a: None)
+    qs, sums, crcs, masks = [], [], [], []
+    for i in range(3):
+        ev = u8[i].copy().astype(np.float32); ev -= 128; ev *= 0.2                       # run.py:334-336
+        ev = ev[480 // 2 - 260 // 2: 480 // 2 + 260 // 2, 640 // 2 - 346 // 2: 640 // 2 + 346 // 2]  # run.py:349-350
+        x = torch.from_numpy(np.ascontiguousarray(ev)).view(1, 1, 260, 346).float()       # run.py:247
+        q = torch.quantile(x.abs(), .97)                                                  # run.py:250
+        x = torch.clip(x / q, -1.0, 1.0)                                                  # run.py:253
+        qs.append(q.numpy().copy()); sums.append(x.double().sum().item())
+        crcs.append(zlib.crc32(x.numpy().tobytes()))
+        m = net.form_input(x.clone())                                                     # learner_models.py:476-494
+        masks.append(np.packbits(m.numpy().astype(np.uint8).reshape(-1)))
+    # a frame where the quantile falls between two levels (exercise the lerp)
+    f = syn.make_frames(11, 1, rate=0.02)
+    x = torch.from_numpy(f)
+    q = torch.quantile(x.abs(), .97)
+    out.update(q97=np.asarray(qs, np.float32), sums=np.asarray(sums), crcs=np.asarray(crcs, np.uint32),
+               masks=np.stack(masks), q97_sparse=q.numpy())
+    # bev 0 / 1 variants of form_input on frame 0 (checksums)
+    for bev in (0, 1):
+        netb = ref_lm.OrigUNet(num_in_channels=2, num_out_channels=1, num_recurrent=[0, 0], input_shape=[1, 1, 260, 346],
+                               velpred=0, form_BEV=bev, evs_min_cutoff=0.15, skip_type="interp", logger=lambda *a: None)
+        fr = torch.from_numpy(syn.make_frames(12, 1))
+        qq = torch.quantile(fr.abs(), .97)
+        r = netb.form_input(torch.clip(fr / qq, -1, 1))
+        out[f"bev{bev}_crc"] = np.uint32(zlib.crc32(r.contiguous().numpy().tobytes()))
+        out[f"bev{bev}_shape"] = np.asarray(r.shape)
+    save("g3_conditioning", **out)
+
+
+# ------------------------------------------------------------------ G4: Mix-Transformer stages
+def g4():
+    rs = np.random.RandomState(40)
+    x1 = torch.from_numpy(rs.rand(2, 1, 60, 90).astype(np.float32))
+    st1 = ref_vs.MixTransformerEncoderLayer(1, 32, patch_size=7, stride=4, padding=3, n_layers=2, reduction_ratio=8,
+                                            num_heads=1, expansion_factor=8).eval()
+    st1.load_state_dict(syn.fill_state_dict(st1, "vitfly_vitlstm.encoder_blocks.0."))
+    st2 = ref_vs.MixTransformerEncoderLayer(32, 64, patch_size=3, stride=2, padding=1, n_layers=2, reduction_ratio=4,
+                                            num_heads=2, expansion_factor=8).eval()
+    st2.load_state_dict(syn.fill_state_dict(st2, "vitfly_vitlstm.encoder_blocks.1."))
+    with torch.no_grad():
+        y1 = st1(x1)
+        x2 = torch.from_numpy(rs.standard_normal((2, 32, 15, 23)).astype(np.float32))
+        y2 = st2(x2)
+    save("g4_mixstage", y1=y1.numpy(), y2=y2.numpy())
+
+
+# ------------------------------------------------------------------ G5: LSTMNetVIT / ViT
+def g5():
+    rs = np.random.RandomState(50)
+    img = torch.from_numpy(rs.rand(4, 1, 60, 90).astype(np.float32))
+    desvel = torch.from_numpy(np.array([[4.0], [3.0], [5.0], [4.0]], np.float32))
+    out = {}
+    net = ref_vm.LSTMNetVIT().eval()
+    net.load_state_dict(syn.fill_state_dict(net, "vitfly_vitlstm."))
+    with torch.no_grad():
+        v_seq, (h, c) = net([img.clone(), desvel.clone(), None])                  # 4 rows = 4 time steps
+        out.update(lstm_seq_vel=v_seq.numpy(), lstm_seq_h=h.numpy(), lstm_seq_c=c.numpy())
+        v_ind = torch.cat([net([img[i:i + 1].clone(), desvel[i:i + 1].clone(), None])[0] for i in range(4)])
+        out["lstm_ind_vel"] = v_ind.numpy()
+        # stateful continuation: rows 0-1 then rows 2-3 with the carried state, non-default quaternion
+        quat = torch.from_numpy(rs.standard_normal((4, 4)).astype(np.float32))
+        va, st = net([img[:2].clone(), desvel[:2].clone(), quat[:2].clone()])
+        vb, st2 = net([img[2:].clone(), desvel[2:].clone(), quat[2:].clone(), st])
+        out.update(lstm_state_vel=torch.cat([va, vb]).numpy(), lstm_state_h=st2[0].numpy())
+        # non-60x90 input exercises refine_inputs' bilinear resize
+        big = torch.from_numpy(rs.rand(2, 1, 260, 346).astype(np.float32))
+        out["lstm_resize_vel"] = net([big.clone(), desvel[:2].clone(), None])[0].numpy()
+    vit = ref_vm.ViT().eval()
+    vit.load_state_dict(syn.fill_state_dict(vit, "vit."))
+    with torch.no_grad():
+        out["vit_vel"] = vit([img.clone(), desvel.clone(), None])[0].numpy()
+    save("g5_vit", **out)
+
+
+# ------------------------------------------------------------------ G6: ConvLSTM
+def g6():
+    rs = np.random.RandomState(60)
+    T = 16
+    x = torch.from_numpy(np.maximum(rs.standard_normal((1, T, 512, 8, 13)), 0).astype(np.float32))
+    net = RefConvLSTM(input_dim=512, hidden_dim=[512], num_layers=1, kernel_size=(1, 1), bias=False,
+                      batch_first=True, return_all_layers=False).eval()
+    net.load_state_dict(syn.fill_state_dict(net, "origunet.lstm."))
+    with torch.no_grad():
+        outs, st = net(x, None)
+        o = outs[0][0]                                                # (T,512,8,13)
+        # stateful split 10 + 6 must continue identically
+        o_a, st_a = net(x[:, :10], None)
+        o_b, st_b = net(x[:, 10:], st_a)
+        assert torch.equal(o_b[0][0][-1], o[-1])
+    save("g6_convlstm", out_t0=o[0].numpy(), out_t1=o[1].numpy(), out_t15=o[15].numpy(),
+         h=st[0][0].numpy(), c=st[0][1].numpy())
+
+
+def cond_frames(seed, n):
+    f = torch.from_numpy(syn.make_frames(seed, n))
+    out = torch.empty_like(f)
+    for i in range(n):
+        q = torch.quantile(f[i:i + 1].abs(), .97)
+        out[i:i + 1] = torch.clip(f[i:i + 1] / q, -1.0, 1.0)
+    return out
+
+
+# ------------------------------------------------------------------ G7: OrigUNet
+def g7():
+    out = {}
+    x = cond_frames(70, 2)
+    for tag, kw in (("interp_bev2", dict(skip_type="interp", form_BEV=2)),
+                    ("crop_bev2", dict(skip_type="crop", form_BEV=2)),
+                    ("interp_bev0", dict(skip_type="interp", form_BEV=0)),
+                    ("interp_bev1", dict(skip_type="interp", form_BEV=1))):
+        net = ref_lm.OrigUNet(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
+                              input_shape=[1, 1, 260, 346], velpred=0, evs_min_cutoff=0.15,
+                              logger=lambda *a: None, **kw).eval()
+        net.load_state_dict(syn.fill_state_dict(net, "origunet."))
+        with torch.no_grad():
+            y_vel, (y_interp, y_upconv, (h_unet, _)) = net([x.clone(), None, None])
+        out[f"{tag}_upconv"] = y_upconv.numpy()
+        if tag == "interp_bev2":
+            out[f"{tag}_depth"] = y_interp.numpy()
+            out[f"{tag}_h"] = h_unet[0][0].numpy()
+            out[f"{tag}_c"] = h_unet[0][1].numpy()
+            out[f"{tag}_vel"] = y_vel.numpy()
+        else:
+            out[f"{tag}_depth_sum"] = np.float64(y_interp.double().sum().item())
+    # no recurrence: rows independent
+    net = ref_lm.OrigUNet(num_in_channels=2, num_out_channels=1, num_recurrent=[0, 0], input_shape=[1, 1, 260, 346],
+                          velpred=0, evs_min_cutoff=0.15, skip_type="interp", form_BEV=2, logger=lambda *a: None).eval()
+    net.load_state_dict(syn.fill_state_dict(net, "origunet."))
+    with torch.no_grad():
+        out["norec_upconv"] = net([x.clone(), None, None])[1][1].numpy()
+    save("g7_origunet", **out)
+
+
+# ------------------------------------------------------------------ G8: composite, run.py pattern
+def g8():
+    net = ref_lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
+                                           input_shape=[1, 1, 260, 346], velpred=0, enc_params={}, dec_params={},
+                                           fc_params={}, form_BEV=2, evs_min_cutoff=0.15, skip_type="interp",
+                                           is_deployment=False, logger=lambda *a: None).eval()
+    net.load_state_dict(syn.fill_state_dict(net))
+    x = cond_frames(80, 3)
+    desvel = torch.tensor([[4.0]])
+    vels, ups, dsum = [], [], []
+    h_unet, h_vit = None, None
+    with torch.no_grad():
+        for i in range(3):                                            # run.py:259-262 stateful loop, B=1
+            v, (d, up, ((h_unet, _), h_vit)) = net([x[i:i + 1].clone(), desvel, [h_unet, None], h_vit])
+            vels.append(v.numpy()); ups.append(up.numpy()); dsum.append(d.double().sum().item())
+        # the same 3 frames as ONE batch-as-time call must give the same result
+        v3, (d3, up3, _) = net([x.clone(), desvel.repeat(3, 1), [None, None], None])
+    save("g8_composite", vel=np.concatenate(vels), upconv=np.concatenate(ups), depth_sum=np.asarray(dsum),
+         vel_batch=v3.numpy(), depth_last=d.numpy(), lstm_h=h_vit[0].numpy(), lstm_c=h_vit[1].numpy())
+
+
+# ------------------------------------------------------------------ G0: state-dict key inventory
+def g0():
+    import json
+    mk = dict(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346], velpred=0,
+              form_BEV=2, evs_min_cutoff=0.15, skip_type="interp", logger=lambda *a: None)
+    models = {
+        "composite": ref_lm.OrigUNet_w_VITFLY_ViTLSTM(enc_params={}, dec_params={}, fc_params={}, **mk),
+        "origunet": ref_lm.OrigUNet(**mk),
+        "origunet_bev0_noskip": ref_lm.OrigUNet(**{**mk, "form_BEV": 0, "skip_type": "none", "num_recurrent": [0, 0]}),
+        "lstmnetvit": ref_vm.LSTMNetVIT(),
+        "vit": ref_vm.ViT(),
+    }
+    inv = {name: {k: list(v.shape) for k, v in m.state_dict().items()} for name, m in models.items()}
+    with open(os.path.join(HERE, "g0_keys.json"), "w") as f:
+        json.dump(inv, f, indent=0, sort_keys=True)
+    print("g0_keys.json", {k: len(v) for k, v in inv.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8"]
+    with torch.no_grad():
+        for g in which:
+            globals()[g]()
