@@ -35,7 +35,7 @@ class ModelConfig(C.Structure):
 SIGNATURES = {
     "evfly_abi_version": (c_i, []),
     "evfly_last_error": (C.c_char_p, []),
-    "evfly_voxelize_windows": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_d, c_d,
+    "evfly_voxelize_windows": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_d, c_d,
                                      c_p, c_p, c_p, c_p]),
     "evfly_eventframe_rows_f64": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_d, c_d, c_i64, c_d, c_d,
                                         c_p, c_p, c_p, c_p]),

@@ -1,0 +1,46 @@
+// Shared host-side plumbing of libevfly_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/evfly_hip.h"
+
+namespace evfly {
+
+// ---- error reporting behind evfly_last_error()
+std::string &last_error_ref();
+int fail(int code, const char *fmt, ...);
+
+#define EVFLY_HIP(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::evfly::fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                                 __FILE__, __LINE__);                                          \
+    } while (0)
+
+#define EVFLY_REQUIRE(cond, ...)                                  \
+    do {                                                          \
+        if (!(cond)) return ::evfly::fail(-1, __VA_ARGS__);       \
+    } while (0)
+
+#define EVFLY_LAUNCH_CHECK() EVFLY_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- per-device growable scratch for the stateless entry points (voxelizer, accumulators,
+// conditioning). Growth frees + reallocates (hipFree synchronises, so no kernel still uses the
+// old block). Model handles own their own arenas.
+int scratch_get(size_t bytes, void **out);
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+constexpr int kNumXCD = 8;   // MI355X: 8 XCDs, block b is observed on XCD b % 8 (speed only)
+constexpr int kNumCU = 256;
+constexpr int kMaxLds = 160 * 1024;
+
+}  // namespace evfly

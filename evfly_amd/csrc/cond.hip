@@ -1,0 +1,110 @@
+// Frame conditioning (gfx950): uint8 decode, centre crop, exact per-frame quantile of |v| by
+// LDS radix select (no sort), scale + clip. One 1024-thread block per frame; the frame is
+// re-read from L2 for each of the four 8-bit select passes (360 KB at 260x346).
+//
+// Replaces evfly_ros/run.py:334-336,345-350,247-253 (twins envtest/ros/run_competition.py:485-495,
+// learner/dataloading.py:512-523).
+#include "common.h"
+
+namespace evfly {
+namespace {
+
+constexpr int kCondThreads = 1024;
+
+struct CondArgs {
+    const uint8_t *u8;
+    const float *f32;
+    int n, in_h, in_w, out_h, out_w, top, left;
+    float quantile;
+    float *dst, *q_out;
+};
+
+__device__ __forceinline__ float cond_load(const CondArgs &a, int frame, int i) {
+    const int r = i / a.out_w, c = i - r * a.out_w;
+    const int64_t src = ((int64_t)frame * a.in_h + (r + a.top)) * a.in_w + (c + a.left);
+    if (a.u8) return (float)((int)a.u8[src] - 128) * 0.2f;   // run.py:334-336 (numpy float32 ops)
+    return a.f32[src];
+}
+
+__global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
+    __shared__ unsigned hist[2][256];
+    __shared__ unsigned prefix[2], kth[2];
+    const int frame = blockIdx.x;
+    const int n_px = a.out_h * a.out_w;
+    float q = 1.0f;
+    if (a.quantile > 0.0f) {
+        // torch.quantile (linear): rank = q * (n-1) in fp32, below = floor, above = ceil,
+        // weight = rank - below, result = lerp(v[below], v[above], weight)
+        const float rank = a.quantile * (float)(n_px - 1);
+        const float below = floorf(rank);
+        if (threadIdx.x == 0) {
+            prefix[0] = prefix[1] = 0u;
+            kth[0] = (unsigned)below;
+            kth[1] = (unsigned)ceilf(rank);
+        }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = threadIdx.x; i < 512; i += kCondThreads) (&hist[0][0])[i] = 0u;
+            __syncthreads();
+            const unsigned p0 = prefix[0], p1 = prefix[1];
+            for (int i = threadIdx.x; i < n_px; i += kCondThreads) {
+                const unsigned key = __float_as_uint(fabsf(cond_load(a, frame, i)));
+                const unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
+                const unsigned byte = (key >> shift) & 0xffu;
+                if (hi == p0) atomicAdd(&hist[0][byte], 1u);
+                if (hi == p1) atomicAdd(&hist[1][byte], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x < 2) {   // two lanes: one per target rank
+                const int j = threadIdx.x;
+                unsigned k = kth[j], acc = 0;
+                int bin = 0;
+                for (; bin < 256; ++bin) {
+                    const unsigned c = hist[j][bin];
+                    if (acc + c > k) break;
+                    acc += c;
+                }
+                kth[j] = k - acc;
+                prefix[j] = (prefix[j] << 8) | (unsigned)bin;
+            }
+            __syncthreads();
+        }
+        const float v_lo = __uint_as_float(prefix[0]), v_hi = __uint_as_float(prefix[1]);
+        const float w = rank - below;
+        const float d = v_hi - v_lo;
+        // ATen lerp (fused form, as the CPU kernel evaluates it): small weights from the low end
+        q = (fabsf(w) < 0.5f) ? fmaf(w, d, v_lo) : fmaf(-d, 1.0f - w, v_hi);
+        if (threadIdx.x == 0 && a.q_out) a.q_out[frame] = q;
+    }
+    float *dst = a.dst + (int64_t)frame * n_px;
+    for (int i = threadIdx.x; i < n_px; i += kCondThreads) {
+        float v = cond_load(a, frame, i);
+        if (a.quantile > 0.0f) {
+            v = v / q;                                   // run.py:253; IEEE division (0/0 = NaN survives)
+            v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);  // torch.clip keeps NaN
+        }
+        dst[i] = v;
+    }
+}
+
+}  // namespace
+}  // namespace evfly
+
+using namespace evfly;
+
+extern "C" int evfly_condition_frames(const uint8_t *src_u8, const float *src_f32, int n, int in_h, int in_w, int out_h,
+                                      int out_w, float quantile, float *dst, float *q_out, void *stream) {
+    EVFLY_REQUIRE((src_u8 != nullptr) != (src_f32 != nullptr), "condition: exactly one of src_u8 / src_f32");
+    EVFLY_REQUIRE(n > 0 && dst, "condition: empty batch");
+    EVFLY_REQUIRE(out_h <= in_h && out_w <= in_w && out_h > 0 && out_w > 0, "condition: crop larger than the frame");
+    EVFLY_REQUIRE(quantile <= 1.0f, "condition: quantile must be <= 1");
+    CondArgs a{};
+    a.u8 = src_u8; a.f32 = src_f32; a.n = n; a.in_h = in_h; a.in_w = in_w; a.out_h = out_h; a.out_w = out_w;
+    // run.py:349-350: rows [H/2 - h/2, H/2 + h/2), cols [W/2 - w/2, W/2 + w/2)
+    a.top = (in_h == out_h) ? 0 : in_h / 2 - out_h / 2;
+    a.left = (in_w == out_w) ? 0 : in_w / 2 - out_w / 2;
+    a.quantile = quantile; a.dst = dst; a.q_out = q_out;
+    hipLaunchKernelGGL(k_condition, dim3(n), dim3(kCondThreads), 0, as_stream(stream), a);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}

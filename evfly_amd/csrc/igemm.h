@@ -1,0 +1,50 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
+//   y[m, n] = act( sum_k A(m, k) * W[n, k] + bias[n] (+ res[m, n]) )
+// m runs over (image, oy, ox) output pixels of an NHWC tensor, k over (ky, kx, c_in), n over output
+// channels. W is stored [n][k] (k contiguous, row stride ldw, zero padded to a multiple of 32).
+#pragma once
+#include "common.h"
+
+namespace evfly {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+enum OutMode { OUT_ROWS = 0, OUT_UPCONV2X2 = 1 };
+
+struct ConvDesc {
+    const float *x = nullptr;   // input pixels, row (pixel) stride ldx floats, channels [0, C)
+    int64_t ldx = 0;
+    int NI = 1, H = 1, W = 1, C = 0;
+    const float *w = nullptr;   // [Nc][ldw], k = (ky*KW + kx)*C + c
+    int ldw = 0;
+    const float *bias = nullptr;
+    int KH = 1, KW = 1, stride = 1, pad = 0;
+    int OH = 1, OW = 1;
+    int64_t M = 0;
+    int Nc = 0, K = 0;
+    const float *res = nullptr; // optional addend, row stride ldres (OUT_ROWS only)
+    int64_t ldres = 0;
+    int act = ACT_NONE;
+    float *y = nullptr;
+    int64_t ldy = 0;
+    int out_mode = OUT_ROWS;
+    int up_cout = 0;            // OUT_UPCONV2X2: n = (dy*2+dx)*up_cout + co, bias indexed by co
+    int dtype = EVFLY_DTYPE_F32;
+};
+
+// Fills OH/OW/M/K from the geometry (conv arithmetic of torch.nn.Conv2d).
+inline void conv_finish(ConvDesc &d) {
+    d.OH = (d.H + 2 * d.pad - d.KH) / d.stride + 1;
+    d.OW = (d.W + 2 * d.pad - d.KW) / d.stride + 1;
+    d.M = (int64_t)d.NI * d.OH * d.OW;
+    d.K = d.KH * d.KW * d.C;
+}
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Enqueue the GEMM on `st`. Returns 0 / negative (evfly_last_error).
+int igemm_launch(const ConvDesc &d, hipStream_t st);
+
+// algorithmic work of one launch (for the profile / roofline accounting)
+inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }
+
+}  // namespace evfly

@@ -1,0 +1,521 @@
+// Event -> frame kernels (gfx950): windowed voxelizer, form_eventframe on f64 rows, the two
+// uint8 accumulators. HBM-bound integer work: coalesced SoA reads, LDS per-band accumulation,
+// XCD-aware block -> (frame, band) mapping so the bands of a frame share one L2.
+//
+// Replaces utils/to_events.py:394-411, utils/ev_utils.py:113-161, evfly_ros/src/node.cpp:24-40,
+// evfly_dv_ros/src/node.cpp:24-46 (see include/evfly_hip.h for the per-entry citations).
+#include "common.h"
+
+#include <algorithm>
+
+namespace evfly {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// pass 1a: per-stream sortedness flag (reads every timestamp once: 8 B / event)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int stream_of(const int64_t *__restrict__ offs, int n_streams, int64_t i) {
+    int lo = 0, hi = n_streams;  // find b with offs[b] <= i < offs[b+1]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_check_sorted(const int64_t *__restrict__ t, int64_t n,
+                                                      const int64_t *__restrict__ offs, int n_streams,
+                                                      int *__restrict__ unsorted) {
+    // each thread owns 4 consecutive events (two 16-B loads) + the first of the next quad
+    const int64_t nq = (n + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = q << 2;
+        int64_t v[5];
+        if (i0 + 4 < n) {
+            const longlong2 a = *reinterpret_cast<const longlong2 *>(t + i0);
+            const longlong2 b = *reinterpret_cast<const longlong2 *>(t + i0 + 2);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = t[i0 + 4];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = (i0 + k < n) ? t[i0 + k] : INT64_MAX;
+        }
+        bool inv = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) inv |= (i0 + k + 1 < n) && (v[k] > v[k + 1]);
+        if (inv) {
+            // an inversion only counts inside one stream: locate it exactly (rare path)
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k + 1 < n && v[k] > v[k + 1]) {
+                    const int b = stream_of(offs, n_streams, i0 + k);
+                    if (i0 + k + 1 < offs[b + 1]) unsorted[b] = 1;
+                }
+            }
+        }
+    }
+}
+
+// pass 1b: window -> event range by binary search on the (sorted) timestamps of each stream.
+// starts[b*(T+1)+e] = first event index of stream b with t >= edge e.
+__global__ void k_window_ranges(const int64_t *__restrict__ t, const int64_t *__restrict__ offs,
+                                const int64_t *__restrict__ edges, int n_streams, int T,
+                                int64_t *__restrict__ starts) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_streams * (T + 1)) return;
+    const int b = idx / (T + 1);
+    const int64_t edge = edges[idx];
+    int64_t lo = offs[b], hi = offs[b + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (t[mid] < edge) lo = mid + 1; else hi = mid;
+    }
+    starts[idx] = lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2: banded LDS accumulation. One block = one (frame, row band).
+//   GENERAL = false: time-sorted stream and <= 65535 events in the window: the window is the
+//     contiguous range [starts[w], starts[w+1]); only x, y, p are read (5 B / event); P and N
+//     are 16-bit halves of one LDS word.
+//   GENERAL = true: any order / any count: the whole stream is scanned with the int64 time test
+//     of to_events.py:405-406; P and N are separate 32-bit LDS words.
+// ------------------------------------------------------------------------------------------
+struct VoxArgs {
+    const uint16_t *x, *y;
+    const int64_t *t;
+    const int8_t *p;
+    const int64_t *offs, *edges, *starts;
+    const int *unsorted;
+    int64_t n_total;
+    int n_streams, T, H, W, pol_mode, rows_per_band, n_bands, n_frames;
+    double pos_thresh, neg_thresh;
+    float *f32;
+    double *f64;
+    int32_t *counts;
+};
+
+constexpr int kVoxThreads = 1024;
+constexpr int kFastMax = 65535;
+
+template <bool GENERAL>
+__global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    // XCD-aware mapping: ids {g*8*nb + band*8 + xcd} -> frame g*8 + xcd, so every band of a frame
+    // lands on the same XCD (block id % 8) and the re-read of the window's events hits that L2.
+    const int per_group = kNumXCD * a.n_bands;
+    const int g = blockIdx.x / per_group, r = blockIdx.x % per_group;
+    const int frame = g * kNumXCD + (r % kNumXCD);
+    const int band = r / kNumXCD;
+    if (frame >= a.n_frames) return;
+    const int b = frame / a.T, w = frame % a.T;
+
+    int64_t lo, hi;
+    const bool sorted = a.unsorted[b] == 0;
+    const int64_t s0 = a.starts[b * (a.T + 1) + w], s1 = a.starts[b * (a.T + 1) + w + 1];
+    const bool fast_ok = sorted && (s1 - s0) <= kFastMax;
+    if (GENERAL == fast_ok) return;  // the other instantiation owns this frame
+    int64_t e0 = 0, e1 = 0;
+    if (GENERAL) {
+        lo = a.offs[b]; hi = a.offs[b + 1];
+        e0 = a.edges[b * (a.T + 1) + w]; e1 = a.edges[b * (a.T + 1) + w + 1];
+    } else {
+        lo = s0; hi = s1;
+    }
+
+    const int r0 = band * a.rows_per_band;
+    const int r1 = min(a.H, r0 + a.rows_per_band);
+    const int cells = (r1 - r0) * a.W;
+    const int words = GENERAL ? 2 * cells : cells;
+    for (int i = threadIdx.x; i < words; i += kVoxThreads) lds[i] = 0u;
+    __syncthreads();
+
+    // 8 events per thread per step: x, y as one 16-B load each, p as one 8-B load
+    const int64_t first = lo & ~int64_t(7);
+    for (int64_t i0 = first + (int64_t)threadIdx.x * 8; i0 < hi; i0 += (int64_t)kVoxThreads * 8) {
+        uint4 xv, yv;
+        uint2 pv;
+        if (i0 + 8 <= a.n_total) {
+            xv = *reinterpret_cast<const uint4 *>(a.x + i0);
+            yv = *reinterpret_cast<const uint4 *>(a.y + i0);
+            pv = *reinterpret_cast<const uint2 *>(a.p + i0);
+        } else {  // last partial vector of the arrays: never read past n_total
+            unsigned xt[4] = {0, 0, 0, 0}, yt[4] = {0, 0, 0, 0}, pt[2] = {0, 0};
+            for (int k = 0; k < 8 && i0 + k < a.n_total; ++k) {
+                xt[k >> 1] |= (unsigned)a.x[i0 + k] << ((k & 1) * 16);
+                yt[k >> 1] |= (unsigned)a.y[i0 + k] << ((k & 1) * 16);
+                pt[k >> 2] |= (unsigned)(uint8_t)a.p[i0 + k] << ((k & 3) * 8);
+            }
+            xv = make_uint4(xt[0], xt[1], xt[2], xt[3]);
+            yv = make_uint4(yt[0], yt[1], yt[2], yt[3]);
+            pv = make_uint2(pt[0], pt[1]);
+        }
+        const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = i0 + k;
+            const unsigned ex = (xs[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            const unsigned ey = (ys[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            const int ep = (int)(int8_t)(((k < 4 ? pv.x : pv.y) >> ((k & 3) * 8)) & 0xffu);
+            // np.histogram2d: the right-most edge is inclusive (x == W counts in column W-1)
+            const int cx = min((int)ex, a.W - 1), cy = min((int)ey, a.H - 1);
+            bool ok = (i >= lo) && (i < hi) && (int)ex <= a.W && (int)ey <= a.H && cy >= r0 && cy < r1;
+            if (GENERAL && ok) {
+                const int64_t tt = a.t[i];
+                ok = (tt >= e0) && (tt < e1);
+            }
+            const bool pos = ep > 0;
+            const bool neg = a.pol_mode == EVFLY_POL_PM1 ? (ep < 0) : (ep == 0);
+            if (ok && (pos || neg)) {
+                const int cell = (cy - r0) * a.W + cx;
+                if (GENERAL) atomicAdd(&lds[pos ? cell : cells + cell], 1u);
+                else atomicAdd(&lds[cell], pos ? 1u : 0x10000u);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int64_t fbase = (int64_t)frame * a.H * a.W + (int64_t)r0 * a.W;
+    for (int i = threadIdx.x; i < cells; i += kVoxThreads) {
+        unsigned P, N;
+        if (GENERAL) { P = lds[i]; N = lds[cells + i]; }
+        else { const unsigned v = lds[i]; P = v & 0xffffu; N = v >> 16; }
+        // to_events.py:409 / ev_utils.py:139: float64 arithmetic, two roundings then the subtract
+        const double f = a.pos_thresh * (double)P - a.neg_thresh * (double)N;
+        if (a.f32) a.f32[fbase + i] = (float)f;
+        if (a.f64) a.f64[fbase + i] = f;
+        if (a.counts) {
+            const int64_t cb = (int64_t)frame * 2 * a.H * a.W + (int64_t)r0 * a.W + i;
+            a.counts[cb] = (int32_t)P;
+            a.counts[cb + (int64_t)a.H * a.W] = (int32_t)N;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// form_eventframe on float64 [t,x,y,p] rows
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hist_bin(double v, int n) {
+    // np.histogram2d with unit bins on [0, n]: floor(v) for 0 <= v < n; v == n -> last bin;
+    // outside (or NaN) -> dropped
+    if (!(v >= 0.0) || !(v <= (double)n)) return -1;
+    const int b = (int)floor(v);
+    return b >= n ? n - 1 : b;
+}
+
+constexpr int kRowsThreads = 256;
+
+// N mode, phase a: count events with t >= t0 per block
+__global__ __launch_bounds__(kRowsThreads) void k_rows_count(const double *__restrict__ rows, int64_t n, double t0,
+                                                              unsigned *__restrict__ block_counts) {
+    __shared__ unsigned s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kRowsThreads + threadIdx.x;
+    const bool keep = i < n && rows[i * 4] >= t0;
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s, (unsigned)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s;
+}
+
+// phase b: exclusive scan of the block counts by one block (sequential over chunks)
+__global__ __launch_bounds__(1024) void k_scan_blocks(unsigned *__restrict__ block_counts, int n_blocks,
+                                                      unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned long long v = i < n_blocks ? block_counts[i] : 0;
+        unsigned long long incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(incl, d);
+            if ((threadIdx.x & 63) >= d) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long woff = 0;
+        for (int k = 0; k < (threadIdx.x >> 6); ++k) woff += wsum[k];
+        const unsigned long long excl = carry + woff + incl - v;
+        if (i < n_blocks) block_counts[i] = (unsigned)excl;  // ranks < 2^32 events
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+struct RowsArgs {
+    const double *rows;
+    int64_t n;
+    int H, W, mode;
+    double t0, t1;
+    int64_t n_keep;
+    const unsigned *block_offsets;  // N mode
+    int32_t *counts;                // (2,H,W) zeroed
+    double *last_t;
+};
+
+__global__ __launch_bounds__(kRowsThreads) void k_rows_scatter(RowsArgs a) {
+    __shared__ unsigned wcount[kRowsThreads / 64];
+    const int64_t i = (int64_t)blockIdx.x * kRowsThreads + threadIdx.x;
+    double t = 0, x = 0, y = 0, p = 0;
+    bool keep = false;
+    if (i < a.n) {
+        const double4 r = *reinterpret_cast<const double4 *>(a.rows + i * 4);
+        t = r.x; x = r.y; y = r.z; p = r.w;
+        if (a.mode == 0) keep = (t >= a.t0) && (t < a.t1);       // ev_utils.py:128
+        else if (a.mode == 1) keep = (t >= a.t0);                 // ev_utils.py:132 (then [:N])
+        else keep = true;                                         // all_events
+    }
+    if (a.mode == 1) {
+        // rank of this event among the kept ones, in array order
+        const unsigned long long m = __ballot(keep);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) wcount[wv] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned long long rank = a.block_offsets[blockIdx.x];
+        for (int k = 0; k < wv; ++k) rank += wcount[k];
+        rank += __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && (int64_t)rank == a.n_keep - 1 && a.last_t) *a.last_t = t;   // last kept (when >= N kept)
+        keep = keep && (int64_t)rank < a.n_keep;
+    }
+    if (!keep) return;
+    const bool pos = p > 0.0;
+    const bool neg = a.mode == 2 ? (p == 0.0) : (p < 0.0);       // ev_utils.py:155-156 vs :137-138
+    if (!pos && !neg) return;
+    const int bx = hist_bin(x, a.W), by = hist_bin(y, a.H);
+    if (bx < 0 || by < 0) return;
+    atomicAdd(&a.counts[(pos ? 0 : a.H * a.W) + by * a.W + bx], 1);
+}
+
+// N mode with fewer than n_keep kept events: the last kept one is the last with t >= t0
+__global__ void k_rows_last(const double *__restrict__ rows, int64_t n, double t0, int64_t n_keep,
+                            const unsigned long long *__restrict__ total, double *__restrict__ last_t) {
+    if (blockIdx.x || threadIdx.x) return;
+    if ((int64_t)*total >= n_keep || *total == 0) return;
+    for (int64_t i = n - 1; i >= 0; --i)
+        if (rows[i * 4] >= t0) { *last_t = rows[i * 4]; return; }
+}
+
+__global__ void k_counts_to_frame(const int32_t *__restrict__ counts, int hw, double pos_thresh, double neg_thresh,
+                                  double *__restrict__ f64) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hw) f64[i] = pos_thresh * (double)counts[i] - neg_thresh * (double)counts[hw + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// uint8 accumulators
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_acc_count(const uint16_t *__restrict__ x, const uint16_t *__restrict__ y,
+                                                   const uint8_t *__restrict__ pol, int64_t n, int W, int H,
+                                                   unsigned *__restrict__ on, unsigned *__restrict__ off) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ex = x[i], ey = y[i];
+        if (ex < W && ey < H) atomicAdd((pol[i] ? on : off) + (int64_t)ey * W + ex, 1u);   // node.cpp:31-37
+    }
+}
+
+__global__ __launch_bounds__(256) void k_acc_apply(uint8_t *__restrict__ img, int n_pix, int mode,
+                                                   const unsigned *__restrict__ on, const unsigned *__restrict__ off,
+                                                   int *__restrict__ hot_list, int *__restrict__ hot_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    const unsigned a = on[i], b = off[i];
+    if (a == 0 && b == 0) return;
+    const int s = img[i];
+    if (mode == EVFLY_ACC_WRAP) {
+        img[i] = (uint8_t)((unsigned)s + a - b);   // ++/-- on uint8 wrap mod 256 (node.cpp:33-37): order free
+    } else if ((int64_t)s + a <= 255 && (int64_t)s - b >= 0) {
+        img[i] = (uint8_t)(s + (int)a - (int)b);   // the walk can never touch 0 / 255: clamps never fire
+    } else {
+        hot_list[atomicAdd(hot_count, 1)] = i;     // needs the exact in-order walk
+    }
+}
+
+// exact saturating walk for the (rare) pixels that can reach a bound: one block per hot pixel
+// scans the event list in order (evfly_dv_ros/src/node.cpp:33-41).
+__global__ __launch_bounds__(256) void k_acc_walk(const uint16_t *__restrict__ x, const uint16_t *__restrict__ y,
+                                                  const uint8_t *__restrict__ pol, int64_t n, int W,
+                                                  const int *__restrict__ hot_list, const int *__restrict__ hot_count,
+                                                  uint8_t *__restrict__ img) {
+    __shared__ unsigned long long match[4], onm[4];
+    __shared__ int s;
+    for (int h = blockIdx.x; h < *hot_count; h += gridDim.x) {
+        const int pix = hot_list[h];
+        const int px = pix % W, py = pix / W;
+        if (threadIdx.x == 0) s = img[pix];
+        __syncthreads();
+        for (int64_t base = 0; base < n; base += 256) {
+            const int64_t i = base + threadIdx.x;
+            const bool m = i < n && x[i] == px && y[i] == py;
+            const unsigned long long mm = __ballot(m);
+            const unsigned long long om = __ballot(m && pol[i] != 0);
+            if ((threadIdx.x & 63) == 0) { match[threadIdx.x >> 6] = mm; onm[threadIdx.x >> 6] = om; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int v = s;
+                for (int wv = 0; wv < 4; ++wv) {
+                    unsigned long long mk = match[wv];
+                    while (mk) {
+                        const int bit = __ffsll((long long)mk) - 1;
+                        mk &= mk - 1;
+                        if ((onm[wv] >> bit) & 1ull) { if (v < 255) ++v; } else { if (v > 0) --v; }
+                    }
+                }
+                s = v;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) img[pix] = (uint8_t)s;
+        __syncthreads();
+    }
+}
+
+template <typename K>
+int set_max_lds(K kernel, int bytes) {
+    EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  bytes));
+    return 0;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+}  // namespace evfly
+
+using namespace evfly;
+
+extern "C" int evfly_voxelize_windows(const uint16_t *x, const uint16_t *y, const int64_t *t, const int8_t *p,
+                                      int64_t n_events, const int64_t *stream_offsets, int n_streams,
+                                      const int64_t *window_edges, int n_windows, int height, int width,
+                                      int polarity_mode, double pos_thresh, double neg_thresh, float *frames_f32,
+                                      double *frames_f64, int32_t *counts_i32, void *stream) {
+    EVFLY_REQUIRE(n_streams > 0 && n_windows > 0 && height > 0 && width > 0, "voxelize: empty geometry");
+    EVFLY_REQUIRE(n_events >= 0, "voxelize: negative event count");
+    EVFLY_REQUIRE(polarity_mode == EVFLY_POL_PM1 || polarity_mode == EVFLY_POL_01, "voxelize: bad polarity_mode %d",
+                  polarity_mode);
+    EVFLY_REQUIRE(((uintptr_t)x | (uintptr_t)y | (uintptr_t)t | (uintptr_t)p) % 16 == 0,
+                  "voxelize: x, y, t, p must be 16-byte aligned");
+    EVFLY_REQUIRE(stream_offsets && window_edges, "voxelize: null offsets / edges");
+    EVFLY_REQUIRE((int64_t)width * 4 <= kMaxLds / 2, "voxelize: width %d too large for one LDS row band", width);
+    hipStream_t st = as_stream(stream);
+    const int n_frames = n_streams * n_windows;
+
+    // scratch: starts[n_streams*(T+1)] i64 | unsorted[n_streams] i32
+    void *scr = nullptr;
+    const size_t starts_bytes = align_up((size_t)n_streams * (n_windows + 1) * 8, 256);
+    if (int rc = scratch_get(starts_bytes + align_up((size_t)n_streams * 4, 256), &scr)) return rc;
+    int64_t *starts = (int64_t *)scr;
+    int *unsorted = (int *)((char *)scr + starts_bytes);
+    EVFLY_HIP(hipMemsetAsync(unsorted, 0, (size_t)n_streams * 4, st));
+
+    if (n_events > 0) {
+        const int blocks = (int)std::min<int64_t>(8 * kNumCU, cdiv(cdiv(n_events, 4), 256));
+        hipLaunchKernelGGL(k_check_sorted, dim3(blocks), dim3(256), 0, st, t, n_events, stream_offsets, n_streams,
+                           unsorted);
+        EVFLY_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_window_ranges, dim3(cdiv(n_streams * (n_windows + 1), 128)), dim3(128), 0, st, t,
+                       stream_offsets, window_edges, n_streams, n_windows, starts);
+    EVFLY_LAUNCH_CHECK();
+
+    VoxArgs a{};
+    a.x = x; a.y = y; a.t = t; a.p = p; a.offs = stream_offsets; a.edges = window_edges; a.starts = starts;
+    a.unsorted = unsorted; a.n_total = n_events; a.n_streams = n_streams; a.T = n_windows; a.H = height; a.W = width;
+    a.pol_mode = polarity_mode; a.n_frames = n_frames; a.pos_thresh = pos_thresh; a.neg_thresh = neg_thresh;
+    a.f32 = frames_f32; a.f64 = frames_f64; a.counts = counts_i32;
+    const int groups = cdiv(n_frames, kNumXCD);
+    for (int general = 0; general < 2; ++general) {
+        const int bytes_per_row = width * (general ? 8 : 4);
+        const int rows_max = kMaxLds / bytes_per_row;
+        a.n_bands = cdiv(height, rows_max);
+        a.rows_per_band = cdiv(height, a.n_bands);
+        const int lds_bytes = (int)align_up((size_t)a.rows_per_band * bytes_per_row, 16);
+        const dim3 grid(groups * kNumXCD * a.n_bands);
+        if (general) {
+            if (int rc = set_max_lds(k_vox_band<true>, kMaxLds)) return rc;
+            hipLaunchKernelGGL(k_vox_band<true>, grid, dim3(kVoxThreads), lds_bytes, st, a);
+        } else {
+            if (int rc = set_max_lds(k_vox_band<false>, kMaxLds)) return rc;
+            hipLaunchKernelGGL(k_vox_band<false>, grid, dim3(kVoxThreads), lds_bytes, st, a);
+        }
+        EVFLY_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int evfly_eventframe_rows_f64(const double *rows, int64_t n, int height, int width, int mode, double t0_ns,
+                                         double t1_ns, int64_t n_keep, double pos_thresh, double neg_thresh,
+                                         double *frame_f64, int32_t *counts_i32, double *last_t_out, void *stream) {
+    EVFLY_REQUIRE(height > 0 && width > 0 && n >= 0, "eventframe: bad geometry");
+    EVFLY_REQUIRE(mode >= 0 && mode <= 2, "eventframe: bad mode %d", mode);
+    EVFLY_REQUIRE(mode != 1 || n_keep > 0, "eventframe: N mode needs n_keep > 0");
+    EVFLY_REQUIRE(((uintptr_t)rows) % 32 == 0, "eventframe: rows must be 32-byte aligned");
+    EVFLY_REQUIRE(n < (int64_t)1 << 32, "eventframe: more than 2^32 events");
+    hipStream_t st = as_stream(stream);
+    const int hw = height * width;
+    const int n_blocks = std::max(1, cdiv(n, kRowsThreads));
+    void *scr = nullptr;
+    const size_t counts_bytes = align_up((size_t)2 * hw * 4, 256);
+    const size_t blk_bytes = align_up((size_t)n_blocks * 4, 256);
+    if (int rc = scratch_get(counts_bytes + blk_bytes + 256, &scr)) return rc;
+    int32_t *counts = counts_i32 ? counts_i32 : (int32_t *)scr;
+    unsigned *blk = (unsigned *)((char *)scr + counts_bytes);
+    unsigned long long *total = (unsigned long long *)((char *)scr + counts_bytes + blk_bytes);
+    EVFLY_HIP(hipMemsetAsync(counts, 0, (size_t)2 * hw * 4, st));
+    if (n > 0) {
+        if (mode == 1) {
+            hipLaunchKernelGGL(k_rows_count, dim3(n_blocks), dim3(kRowsThreads), 0, st, rows, n, t0_ns, blk);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_blocks, total);
+            EVFLY_LAUNCH_CHECK();
+        }
+        RowsArgs a{rows, n, height, width, mode, t0_ns, t1_ns, n_keep, blk, counts, last_t_out};
+        hipLaunchKernelGGL(k_rows_scatter, dim3(n_blocks), dim3(kRowsThreads), 0, st, a);
+        EVFLY_LAUNCH_CHECK();
+        if (mode == 1 && last_t_out) {
+            hipLaunchKernelGGL(k_rows_last, dim3(1), dim3(1), 0, st, rows, n, t0_ns, n_keep, total, last_t_out);
+            EVFLY_LAUNCH_CHECK();
+        }
+    }
+    if (frame_f64) {
+        hipLaunchKernelGGL(k_counts_to_frame, dim3(cdiv(hw, 256)), dim3(256), 0, st, counts, hw, pos_thresh, neg_thresh,
+                           frame_f64);
+        EVFLY_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int evfly_accumulate_reset(uint8_t *img, int64_t n_pixels, void *stream) {
+    EVFLY_REQUIRE(img && n_pixels > 0, "accumulate_reset: empty image");
+    EVFLY_HIP(hipMemsetAsync(img, 128, (size_t)n_pixels, as_stream(stream)));   // node.cpp:10,58
+    return 0;
+}
+
+extern "C" int evfly_accumulate_u8(const uint16_t *x, const uint16_t *y, const uint8_t *polarity, int64_t n, int width,
+                                   int height, int mode, uint8_t *img, void *stream) {
+    EVFLY_REQUIRE(img && width > 0 && height > 0 && n >= 0, "accumulate: bad arguments");
+    EVFLY_REQUIRE(mode == EVFLY_ACC_WRAP || mode == EVFLY_ACC_SATURATE, "accumulate: bad mode %d", mode);
+    if (n == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    const int n_pix = width * height;
+    void *scr = nullptr;
+    const size_t plane = align_up((size_t)n_pix * 4, 256);
+    if (int rc = scratch_get(3 * plane + 256, &scr)) return rc;
+    unsigned *on = (unsigned *)scr, *off = (unsigned *)((char *)scr + plane);
+    int *hot_list = (int *)((char *)scr + 2 * plane);
+    int *hot_count = (int *)((char *)scr + 3 * plane);
+    EVFLY_HIP(hipMemsetAsync(scr, 0, 2 * plane, st));
+    EVFLY_HIP(hipMemsetAsync(hot_count, 0, 4, st));
+    const int blocks = (int)std::min<int64_t>(4 * kNumCU, cdiv(n, 256));
+    hipLaunchKernelGGL(k_acc_count, dim3(blocks), dim3(256), 0, st, x, y, polarity, n, width, height, on, off);
+    hipLaunchKernelGGL(k_acc_apply, dim3(cdiv(n_pix, 256)), dim3(256), 0, st, img, n_pix, mode, on, off, hot_list,
+                       hot_count);
+    EVFLY_LAUNCH_CHECK();
+    if (mode == EVFLY_ACC_SATURATE) {
+        hipLaunchKernelGGL(k_acc_walk, dim3(kNumCU), dim3(256), 0, st, x, y, polarity, n, width, hot_list, hot_count,
+                           img);
+        EVFLY_LAUNCH_CHECK();
+    }
+    return 0;
+}

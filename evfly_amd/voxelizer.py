@@ -1,0 +1,103 @@
+"""Host mirror of the event -> frame stage (batched, device-resident).
+
+`voxelize_windows` is the GPU replacement of the per-trajectory window loop of
+utils/to_events.py:384-415 for a whole batch of streams; `EventAccumulator` mirrors the
+two ROS accumulator nodes (evfly_ros/src/node.cpp, evfly_dv_ros/src/node.cpp);
+`condition_frames` mirrors evfly_ros/run.py:334-350,247-253. All of them are thin
+ctypes calls into libevfly_hip.so -- no numpy arithmetic happens here.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+POL = {"pm1": 0, "timed": 0, "01": 1, "all": 1}
+
+
+def _dev(a, dtype):
+    if isinstance(a, torch.Tensor):
+        return a.to("cuda", dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def upload_events(batch):
+    """SoA numpy batch (evfly_amd.synthetic.make_batch layout) -> dict of device tensors."""
+    _lib.lib()
+    return dict(x=_dev(batch["x"].view(np.int16) if isinstance(batch["x"], np.ndarray) else batch["x"], torch.int16),
+                y=_dev(batch["y"].view(np.int16) if isinstance(batch["y"], np.ndarray) else batch["y"], torch.int16),
+                t=_dev(batch["t"], torch.int64), p=_dev(batch["p"], torch.int8),
+                offsets=_dev(batch["offsets"], torch.int64), edges=_dev(batch["edges"], torch.int64))
+
+
+def voxelize_windows(ev, H, W, polarity="pm1", pos_thresh=0.2, neg_thresh=0.2, out="f32", frames=None):
+    """ev: dict of device tensors x,y (u16 bits in int16), t i64, p i8, offsets (B+1), edges (B,T+1).
+    out: "f32" | "f64" | "counts" or a tuple of them. Returns the requested device tensors
+    (B,T,H,W) / (B,T,2,H,W) in that order. `frames` may pre-supply the f32 output buffer."""
+    L = _lib.lib()
+    outs = (out,) if isinstance(out, str) else tuple(out)
+    B = ev["offsets"].numel() - 1
+    T = ev["edges"].shape[-1] - 1
+    dev = ev["x"].device
+    bufs = {"f32": None, "f64": None, "counts": None}
+    for o in outs:
+        if o == "f32":
+            bufs[o] = frames if frames is not None else torch.empty(B, T, H, W, device=dev, dtype=torch.float32)
+        elif o == "f64":
+            bufs[o] = torch.empty(B, T, H, W, device=dev, dtype=torch.float64)
+        elif o == "counts":
+            bufs[o] = torch.empty(B, T, 2, H, W, device=dev, dtype=torch.int32)
+        else:
+            raise ValueError(o)
+    _lib.check(L.evfly_voxelize_windows(_lib.ptr(ev["x"]), _lib.ptr(ev["y"]), _lib.ptr(ev["t"]), _lib.ptr(ev["p"]),
+                                        ev["x"].numel(), _lib.ptr(ev["offsets"]), B, _lib.ptr(ev["edges"]), T, H, W,
+                                        POL[polarity], float(pos_thresh), float(neg_thresh), _lib.ptr(bufs["f32"]),
+                                        _lib.ptr(bufs["f64"]), _lib.ptr(bufs["counts"]), _lib.cur_stream()))
+    res = tuple(bufs[o] for o in outs)
+    return res[0] if isinstance(out, str) else res
+
+
+def condition_frames(src, out_hw=(260, 346), quantile=0.97, return_q=False):
+    """src: (n, H, W) uint8 accumulator images or float32 frames (device or host).
+    -> (n, 1, h, w) float32 conditioned frames on the device (decode, centre crop, q-scale, clip)."""
+    L = _lib.lib()
+    if not isinstance(src, torch.Tensor):
+        src = torch.from_numpy(np.ascontiguousarray(src))
+    src = src.to("cuda")
+    if src.dtype != torch.uint8:
+        src = src.float()
+    src = src.reshape(-1, src.shape[-2], src.shape[-1]).contiguous()
+    n, ih, iw = src.shape
+    dst = torch.empty(n, 1, out_hw[0], out_hw[1], device=src.device, dtype=torch.float32)
+    q = torch.empty(n, device=src.device, dtype=torch.float32)
+    u8 = _lib.ptr(src) if src.dtype == torch.uint8 else None
+    f32 = _lib.ptr(src) if src.dtype != torch.uint8 else None
+    _lib.check(L.evfly_condition_frames(u8, f32, n, ih, iw, out_hw[0], out_hw[1],
+                                        float(quantile) if quantile else 0.0, _lib.ptr(dst), _lib.ptr(q),
+                                        _lib.cur_stream()))
+    return (dst, q) if return_q else dst
+
+
+class EventAccumulator:
+    """Online accumulator: `add(x, y, polarity)` = eventArrayCallback, `publish()` = timerCallback
+    (evfly_ros/src/node.cpp:24-59; mode 'saturate' = evfly_dv_ros/src/node.cpp:24-63)."""
+
+    def __init__(self, width=640, height=480, mode="wrap"):
+        _lib.lib()
+        self.width, self.height = width, height
+        self.mode = {"wrap": 0, "saturate": 1}[mode]
+        self.img = torch.full((height, width), 128, dtype=torch.uint8, device="cuda")   # node.cpp:10
+
+    def add(self, x, y, polarity):
+        L = _lib.lib()
+        x = _dev(np.asarray(x, np.uint16).view(np.int16) if not isinstance(x, torch.Tensor) else x, torch.int16)
+        y = _dev(np.asarray(y, np.uint16).view(np.int16) if not isinstance(y, torch.Tensor) else y, torch.int16)
+        pol = _dev(np.asarray(polarity, np.uint8) if not isinstance(polarity, torch.Tensor) else polarity, torch.uint8)
+        _lib.check(L.evfly_accumulate_u8(_lib.ptr(x), _lib.ptr(y), _lib.ptr(pol), x.numel(), self.width, self.height,
+                                         self.mode, _lib.ptr(self.img), _lib.cur_stream()))
+
+    def publish(self):
+        """Returns the accumulated image (a copy) and refills with 128 (node.cpp:52-58)."""
+        L = _lib.lib()
+        out = self.img.clone()
+        _lib.check(L.evfly_accumulate_reset(_lib.ptr(self.img), self.img.numel(), _lib.cur_stream()))
+        return out

@@ -43,11 +43,12 @@ const char *evfly_last_error(void);
 /* Replaces the per-trajectory window-slicing loop utils/to_events.py:394-411 (and, window by
  * window, the timed mode of form_eventframe utils/ev_utils.py:125-140) for a batch of streams.
  *
- * Events are a structure of arrays (13 B / event; dv_ros_msgs/msg/Event.msg:1-5): stream b owns
- * events [stream_offsets[b], stream_offsets[b+1]). Window w of stream b keeps the events with
+ * Events are a structure of arrays (13 B / event; dv_ros_msgs/msg/Event.msg:1-5) of n_events
+ * entries in total (x, y, t, p 16-byte aligned): stream b owns events
+ * [stream_offsets[b], stream_offsets[b+1]), stream_offsets[n_streams] == n_events. Window w of stream b keeps the events with
  * window_edges[b*(n_windows+1)+w] <= t < window_edges[b*(n_windows+1)+w+1]  (to_events.py:402-406),
- * counts them per pixel and polarity (np.histogram2d semantics for integer coordinates: events
- * with x >= width or y >= height are dropped) and forms
+ * counts them per pixel and polarity with np.histogram2d semantics (bins=(W,H), range [0,W]x[0,H]:
+ * x == width / y == height fall in the LAST column / row, larger coordinates are dropped) and forms
  *     frame = pos_thresh * P - neg_thresh * N         (to_events.py:409, float64 arithmetic).
  * Streams may be unsorted in time (the reference masks, it does not assume order); time-sorted
  * streams take the fast path, which is decided on the device.
@@ -55,7 +56,7 @@ const char *evfly_last_error(void);
  * Outputs (any may be NULL): frames_f32 / frames_f64 (n_streams, n_windows, height, width);
  * counts_i32 (n_streams, n_windows, 2, height, width) with plane 0 = P, plane 1 = N. */
 int evfly_voxelize_windows(const uint16_t *x, const uint16_t *y, const int64_t *t, const int8_t *p,
-                           const int64_t *stream_offsets, int n_streams,
+                           int64_t n_events, const int64_t *stream_offsets, int n_streams,
                            const int64_t *window_edges, int n_windows,
                            int height, int width, int polarity_mode,
                            double pos_thresh, double neg_thresh,

@@ -42,8 +42,9 @@ void oracle_window_counts(const uint16_t *x, const uint16_t *y, const int64_t *t
         int32_t *neg = pos + (int64_t)height * width;
         for (int64_t i = 0; i < n_events; ++i) {          /* to_events.py:405-406: full mask pass per window */
             if (t[i] < edges[w] || t[i] >= edges[w + 1]) continue;
-            if (x[i] >= width || y[i] >= height) continue; /* u16 coords: only the upper bound can fail */
-            int64_t c = (int64_t)y[i] * width + x[i];
+            if (x[i] > width || y[i] > height) continue;   /* histogram2d: right-most edge inclusive */
+            int cx = x[i] == width ? width - 1 : x[i], cy = y[i] == height ? height - 1 : y[i];
+            int64_t c = (int64_t)cy * width + cx;
             if (p[i] > 0) pos[c]++;
             else if (polarity_mode == 0 ? (p[i] < 0) : (p[i] == 0)) neg[c]++;
         }

@@ -1,0 +1,184 @@
+"""GPU parity: event -> frame kernels vs the oracle and the golden fixtures (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from evfly_amd import synthetic as syn
+from oracle import accum as oaccum
+from oracle import conditioning as ocond
+from oracle import voxel as ovox
+
+from _util import desparse, golden, rows_f64
+
+pytestmark = pytest.mark.gpu
+H, W = 260, 346
+
+
+def _vox(batch, Hh, Ww, polarity="pm1", **kw):
+    from evfly_amd import voxelizer
+    ev = voxelizer.upload_events(batch)
+    f32, f64, counts = voxelizer.voxelize_windows(ev, Hh, Ww, polarity=polarity, out=("f32", "f64", "counts"), **kw)
+    torch.cuda.synchronize()
+    return f32.cpu().numpy(), f64.cpu().numpy(), counts.cpu().numpy()
+
+
+@pytest.mark.parametrize("s", [0, 1, 2])
+def test_windows_vs_golden(gpu_device, s):
+    """G1(c): T=5 windows of the golden streams, float64 frames bit-exact with the reference's."""
+    g = golden("g1_voxel")
+    T, EPW = 5, 12_000
+    ev, edges = syn.make_stream(100 + s, T, H, W, EPW, polarity="pm1", seed_base=1000, clustered=(s == 2))
+    batch = dict(ev, offsets=np.array([0, len(ev["x"])], np.int64), edges=edges[None])
+    f32, f64, counts = _vox(batch, H, W)
+    want = desparse(g[f"s{s}_win_idx"], g[f"s{s}_win_val"], (T, H, W))
+    assert np.array_equal(f64[0], want)
+    assert np.array_equal(f32[0], want.astype(np.float32))
+    assert np.array_equal(counts[0], ovox.window_counts(ev["x"], ev["y"], ev["t"], ev["p"], edges, H, W))
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_batch_vs_oracle(gpu_device, clustered):
+    """C2-shaped slice: several streams, 60k events / window, incl. the contention distribution."""
+    B, T = 6, 5
+    batch = syn.make_batch(B, T, H, W, events_per_window=60_000, clustered=clustered)
+    f32, f64, counts = _vox(batch, H, W)
+    want = ovox.batch_window_counts(batch, H, W)
+    assert np.array_equal(counts, want)
+    wf = ovox.signed_frame(want[:, :, 0], want[:, :, 1])
+    assert np.array_equal(f64, wf) and np.array_equal(f32, wf.astype(np.float32))
+    assert counts.sum() == len(batch["x"])          # every event lands in exactly one window
+
+
+def test_sensor_size_thresholds_and_01(gpu_device):
+    """C3-shaped: 480x640, T=10, {0,1} polarity convention, unequal thresholds."""
+    B, T, Hh, Ww = 2, 10, 480, 640
+    batch = syn.make_batch(B, T, Hh, Ww, events_per_window=50_000, polarity="01", seed_base=77)
+    f32, f64, counts = _vox(batch, Hh, Ww, polarity="01", pos_thresh=0.3, neg_thresh=0.1)
+    want = ovox.batch_window_counts(batch, Hh, Ww, mode="all")
+    assert np.array_equal(counts, want)
+    assert np.array_equal(f64, ovox.signed_frame(want[:, :, 0], want[:, :, 1], 0.3, 0.1))
+
+
+def test_unsorted_ragged_hot_and_empty(gpu_device):
+    """General path: an unsorted stream, a window with > 65535 events, an empty stream, ragged
+    lengths, events outside every window and outside the sensor."""
+    T = 3
+    rs = np.random.RandomState(3)
+    streams = []
+    # 0: unsorted
+    ev, e = syn.make_stream(0, T, H, W, 9_000, seed_base=500)
+    perm = rs.permutation(len(ev["x"]))
+    streams.append(({k: v[perm] for k, v in ev.items()}, e))
+    # 1: sorted with one window of 70k events (> 16-bit fast path) on few pixels
+    ev, e = syn.make_stream(1, T, H, W, 1_000, seed_base=500)
+    hot = 70_000
+    evh = dict(x=np.r_[ev["x"], rs.randint(0, 4, hot).astype(np.uint16)],
+               y=np.r_[ev["y"], rs.randint(0, 4, hot).astype(np.uint16)],
+               t=np.r_[ev["t"], rs.randint(e[1], e[2], hot).astype(np.int64)],
+               p=np.r_[ev["p"], (2 * rs.randint(0, 2, hot) - 1).astype(np.int8)])
+    o = np.argsort(evh["t"], kind="stable")
+    streams.append(({k: v[o] for k, v in evh.items()}, e))
+    # 2: empty stream
+    streams.append((dict(x=np.zeros(0, np.uint16), y=np.zeros(0, np.uint16), t=np.zeros(0, np.int64),
+                         p=np.zeros(0, np.int8)), e))
+    # 3: sorted, events before / after all windows, coordinates outside the sensor, p == 0
+    ev, e = syn.make_stream(3, T, H, W, 777, seed_base=500)
+    ev["t"] = np.sort(ev["t"] * 2 - e[-1] // 2)
+    ev["x"][::7] = W; ev["y"][::11] = H + 3; ev["p"][::5] = 0
+    streams.append((ev, e))
+    offs = np.cumsum([0] + [len(s[0]["x"]) for s in streams]).astype(np.int64)
+    batch = dict(x=np.concatenate([s[0]["x"] for s in streams]), y=np.concatenate([s[0]["y"] for s in streams]),
+                 t=np.concatenate([s[0]["t"] for s in streams]), p=np.concatenate([s[0]["p"] for s in streams]),
+                 offsets=offs, edges=np.stack([s[1] for s in streams]))
+    _, f64, counts = _vox(batch, H, W)
+    want = ovox.batch_window_counts(batch, H, W)
+    assert np.array_equal(counts, want)
+    assert counts[1, 1].max() > 2000 and counts[2].sum() == 0
+    assert np.array_equal(f64, ovox.signed_frame(want[:, :, 0], want[:, :, 1]))
+
+
+@pytest.mark.parametrize("s", [0, 2])
+def test_form_eventframe_vs_golden(gpu_device, s):
+    """G1(a),(b),N-mode through the reference-signature shell evfly_amd.ev_utils.form_eventframe."""
+    from evfly_amd import ev_utils
+    g = golden("g1_voxel")
+    T, EPW = 5, 12_000
+    ev, _ = syn.make_stream(100 + s, T, H, W, EPW, polarity="pm1", seed_base=1000, clustered=(s == 2))
+    ev01, _ = syn.make_stream(100 + s, T, H, W, EPW, polarity="01", seed_base=1000, clustered=(s == 2))
+    fa = ev_utils.form_eventframe(rows_f64(ev01), H, W, all_events=True)
+    assert fa.dtype == np.float64 and np.array_equal(fa, desparse(g[f"s{s}_all_idx"], g[f"s{s}_all_val"], (H, W)))
+    ft, t1 = ev_utils.form_eventframe(rows_f64(ev), H, W, times0=0.0123, times1=[0.0789], pos_thresh=0.3, neg_thresh=0.1)
+    assert np.array_equal(ft, desparse(g[f"s{s}_timed_idx"], g[f"s{s}_timed_val"], (H, W))) and t1 == [0.0789]
+    fn, t1n = ev_utils.form_eventframe(rows_f64(ev), H, W, times0=0.0123, N=5000)
+    assert np.array_equal(fn, desparse(g[f"s{s}_nmode_idx"], g[f"s{s}_nmode_val"], (H, W)))
+    assert t1n == float(g[f"s{s}_nmode_t1"])
+
+
+def test_form_eventframe_edges(gpu_device):
+    from evfly_amd import ev_utils
+    g = golden("g1_voxel")
+    rows = g["edge_rows"]
+    assert np.array_equal(ev_utils.form_eventframe(rows, 8, 10, all_events=True), g["edge_all"])
+    rows_pm = rows.copy(); rows_pm[:, 3] = 2 * rows_pm[:, 3] - 1
+    assert np.array_equal(ev_utils.form_eventframe(rows_pm, 8, 10, times0=2e-9, times1=[11e-9])[0], g["edge_timed"])
+    assert np.array_equal(ev_utils.form_eventframe(np.zeros((0, 4)), 8, 10, all_events=True), g["empty_all"])
+    z, t0 = ev_utils.form_eventframe(np.zeros((0, 4)), 8, 10, times0=0.0, times1=[1.0])
+    assert np.array_equal(z, g["empty_timed"]) and t0 == 0.0
+    # N larger than the number of kept events: keeps all, times1 from the last one
+    f, t1 = ev_utils.form_eventframe(rows_pm, 8, 10, times0=3e-9, N=1000)
+    fo, t1o = ovox.form_eventframe(rows_pm, 8, 10, times0=3e-9, N=1000)
+    assert np.array_equal(f, fo) and t1 == t1o
+    with pytest.raises(ValueError):
+        ev_utils.form_eventframe(rows_pm, 8, 10, times0=0.0)
+    with pytest.raises(IndexError):
+        ev_utils.form_eventframe(rows_pm, 8, 10, times0=1.0, N=5)     # nothing after times0
+
+
+@pytest.mark.parametrize("mode", ["wrap", "saturate"])
+def test_accumulators(gpu_device, mode):
+    """A3/A4: several callbacks onto one image, incl. > 127 same-pixel events and order dependence."""
+    from evfly_amd.voxelizer import EventAccumulator
+    rs = np.random.RandomState(9)
+    acc = EventAccumulator(640, 480, mode)
+    ref = np.full((480, 640), 128, np.uint8)
+    for call in range(3):
+        n = 200_000
+        x = rs.randint(0, 645, n).astype(np.uint16)            # a few out of bounds (node.cpp:31)
+        y = rs.randint(0, 483, n).astype(np.uint16)
+        pol = rs.randint(0, 2, n).astype(np.uint8)
+        # hot pixels: long ON runs then OFF runs (saturation + order dependence), one wrapping pixel
+        x[:400] = 7; y[:400] = 9; pol[:300] = 1; pol[300:400] = 0
+        x[400:700] = 600; y[400:700] = 400; pol[400:700] = 0
+        x[700:1000] = 33; y[700:1000] = 44; pol[700:1000] = (np.arange(300) % 3 != 0)
+        acc.add(x, y, pol)
+        ref = oaccum.accumulate_u8(x, y, pol, 640, 480, mode, ref)
+    out = acc.publish().cpu().numpy()
+    assert np.array_equal(out, ref)
+    assert (acc.img.cpu().numpy() == 128).all()               # node.cpp:57-58 reset
+    if mode == "saturate":
+        assert out[400, 600] <= 2 and out[9, 7] > 140         # floor at 0; 128 -> 255 (sat) -> ~155
+
+
+def test_conditioning_vs_golden_and_oracle(gpu_device):
+    """G3: uint8 decode + crop + q97 + clip: quantile bits and normalised frames identical."""
+    from evfly_amd import voxelizer
+    g = golden("g3_conditioning")
+    u8 = syn.make_u8_frames(7, 3)
+    x, q = voxelizer.condition_frames(u8, return_q=True)
+    assert np.array_equal(q.cpu().numpy(), g["q97"])
+    fr = np.stack([ocond.center_crop(ocond.decode_u8(u8[i])) for i in range(3)])[:, None]
+    want, _ = ocond.q97_normalize(fr)
+    assert torch.equal(x.cpu(), want)
+    # quantile between two levels (lerp), float input, no crop
+    f = syn.make_frames(11, 1, rate=0.02)
+    x2, q2 = voxelizer.condition_frames(f[:, 0], return_q=True)
+    assert np.array_equal(q2.cpu().numpy()[0], g["q97_sparse"])
+    # generic float data: exact order statistics + torch's lerp
+    rs = np.random.RandomState(21)
+    fr = (rs.standard_normal((4, 260, 346)) ** 3).astype(np.float32)
+    x3, q3 = voxelizer.condition_frames(fr, return_q=True)
+    want3, wq3 = ocond.q97_normalize(fr[:, None])
+    assert torch.equal(q3.cpu(), wq3) and torch.equal(x3.cpu(), want3)
+    # all-zero frame: q = 0 -> 0/0 = NaN exactly like the reference expression
+    z = voxelizer.condition_frames(np.zeros((1, 260, 346), np.float32))
+    assert torch.isnan(z).all()
