@@ -23,6 +23,10 @@ struct ConvDesc {
     int Nc = 0, K = 0;
     const float *res = nullptr; // optional addend, row stride ldres (OUT_ROWS only)
     int64_t ldres = 0;
+    // res row of output row m: plain m, or (m / res_rpi) * res_img_rows + m % res_rpi when res_rpi > 0
+    // (the addend lives in a tensor with more rows per image group, e.g. zx[stream][t] for one t)
+    int res_rpi = 0;
+    int64_t res_img_rows = 0;
     int act = ACT_NONE;
     float *y = nullptr;
     int64_t ldy = 0;

@@ -243,7 +243,11 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                     d.y[o * d.ldy + co] = v;
                 } else {
                     if (d.bias) v += d.bias[n];
-                    if (d.res) v += d.res[m * d.ldres + n];
+                    if (d.res) {
+                        int64_t rr = m;
+                        if (d.res_rpi > 0) { const int64_t g = m / d.res_rpi; rr = g * d.res_img_rows + (m - g * d.res_rpi); }
+                        v += d.res[rr * d.ldres + n];
+                    }
                     if (d.act == ACT_RELU) v = v > 0.f ? v : 0.f;
                     else if (d.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                     d.y[m * d.ldy + n] = v;

@@ -1,0 +1,797 @@
+// Model handles: weight repacking and the forward passes of OrigUNet (+ConvLSTM), the Mix-Transformer
+// velocity models (LSTMNetVIT / ViT) and their composite, as HIP launch sequences on the caller's stream.
+//
+// Replaces learner/learner_models.py:339-636, learner/ConvLSTM_pytorch/convlstm.py:38-176,
+// learner/vitfly_models.py:18-31,111-186, learner/ViTsubmodules.py:15-148 (per-entry citations in
+// include/evfly_hip.h). Activations are fp32 NHWC in one device arena owned by the handle; streams are
+// processed in chunks so the arena stays bounded.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "igemm.h"
+#include "ops.h"
+
+using namespace evfly;
+
+namespace {
+
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Tap {
+    float *ptr;
+    int64_t shape[4];
+};
+
+struct ProfRec {
+    std::string name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+struct ProfAgg {
+    std::string name;
+    double ms = 0, flops = 0, bytes = 0;
+    int launches = 0;
+};
+
+}  // namespace
+
+struct evfly_model {
+    evfly_model_config cfg{};
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    int device = 0;
+    // packed weights: one device allocation, name -> offset
+    float *wdev = nullptr;
+    std::map<std::string, size_t> woff;
+    std::map<std::string, int> wld;       // padded k stride of GEMM weights
+    std::vector<float> wstage;
+    // activation arena
+    char *arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    bool planning = false;
+    size_t plan_peak = 0;
+    std::map<std::string, Tap> taps;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<ProfAgg> agg;
+    hipStream_t st = nullptr;
+
+    ~evfly_model() {
+        if (wdev) (void)hipFree(wdev);
+        if (arena) (void)hipFree(arena);
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+    }
+
+    // ------------------------------------------------------------------ host tensors
+    const HostTensor *find(const std::string &key, const char *prefix) const {
+        auto it = host.find(std::string(prefix) + key);
+        if (it != host.end()) return &it->second;
+        it = host.find(key);
+        return it == host.end() ? nullptr : &it->second;
+    }
+
+    // ------------------------------------------------------------------ packed weights
+    float *stage(const std::string &name, size_t n) {
+        size_t off = (wstage.size() + 63) / 64 * 64;   // 256-B aligned
+        wstage.resize(off + n, 0.f);
+        woff[name] = off;
+        return wstage.data() + off;
+    }
+    const float *W(const std::string &name) const {
+        auto it = woff.find(name);
+        return it == woff.end() ? nullptr : wdev + it->second;
+    }
+    bool has(const std::string &name) const { return woff.count(name) != 0; }
+
+    // ------------------------------------------------------------------ arena
+    float *alloc(int64_t n_floats) {
+        size_t bytes = ((size_t)n_floats * 4 + 255) / 256 * 256;
+        size_t off = arena_off;
+        arena_off += bytes;
+        if (planning) { plan_peak = std::max(plan_peak, arena_off); return reinterpret_cast<float *>(16); }
+        return reinterpret_cast<float *>(arena + off);
+    }
+    void tap(const char *name, float *p, int64_t a, int64_t b, int64_t c, int64_t d) {
+        if (!planning) taps[name] = Tap{p, {a, b, c, d}};
+    }
+
+    // ------------------------------------------------------------------ profiling
+    int prof_begin(const char *name, double flops, double bytes) {
+        if (!profiling || planning) return 0;
+        while (ev_pool.size() < ev_used + 2) {
+            hipEvent_t e;
+            EVFLY_HIP(hipEventCreate(&e));
+            ev_pool.push_back(e);
+        }
+        ProfRec r{name, flops, bytes, ev_pool[ev_used], ev_pool[ev_used + 1]};
+        ev_used += 2;
+        EVFLY_HIP(hipEventRecord(r.e0, st));
+        prof.push_back(r);
+        return 0;
+    }
+    int prof_end() {
+        if (!profiling || planning) return 0;
+        EVFLY_HIP(hipEventRecord(prof.back().e1, st));
+        return 0;
+    }
+    int prof_collect() {
+        if (prof.empty()) return 0;
+        EVFLY_HIP(hipEventSynchronize(prof.back().e1));
+        for (auto &r : prof) {
+            float ms = 0;
+            EVFLY_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+            ProfAgg *a = nullptr;
+            for (auto &x : agg) if (x.name == r.name) a = &x;
+            if (!a) { agg.push_back(ProfAgg{r.name}); a = &agg.back(); }
+            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->launches += 1;
+        }
+        prof.clear();
+        ev_used = 0;
+        return 0;
+    }
+};
+
+namespace {
+
+#define RUN(m, name, flops, bytes, call)                         \
+    do {                                                         \
+        if (!(m)->planning) {                                    \
+            if (int _rc = (m)->prof_begin(name, flops, bytes)) return _rc; \
+            if (int _rc = (call)) return _rc;                    \
+            if (int _rc = (m)->prof_end()) return _rc;           \
+        }                                                        \
+    } while (0)
+
+// ============================================================================ packing (host)
+// Conv2d weight (O, I, kh, kw) -> [O][kh][kw][I], k padded with zeros to a multiple of 32
+int pack_conv(evfly_model *m, const char *prefix, const std::string &key, const std::string &name, bool need = true) {
+    const HostTensor *t = m->find(key + ".weight", prefix);
+    if (!t) { if (need) return fail(-4, "missing tensor %s%s.weight", prefix, key.c_str()); return 1; }
+    EVFLY_REQUIRE(t->shape.size() == 4, "%s.weight: expected 4 dims", key.c_str());
+    const int O = (int)t->shape[0], I = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
+    const int K = kh * kw * I, ld = round_up(K, 32);
+    float *dst = m->stage(name + ".w", (size_t)O * ld);
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+            for (int y = 0; y < kh; ++y)
+                for (int x = 0; x < kw; ++x)
+                    dst[(size_t)o * ld + (y * kw + x) * I + i] = t->v[(((size_t)o * I + i) * kh + y) * kw + x];
+    m->wld[name] = ld;
+    const HostTensor *b = m->find(key + ".bias", prefix);
+    if (b) std::memcpy(m->stage(name + ".b", b->v.size()), b->v.data(), b->v.size() * 4);
+    return 0;
+}
+
+// Linear weight (O, I) (optionally spectral-normalised, optionally with permuted input columns)
+int pack_linear(evfly_model *m, const char *prefix, const std::string &key, const std::string &name, bool need = true,
+                const std::vector<int> *col_perm = nullptr) {
+    const HostTensor *t = m->find(key + ".weight", prefix);
+    std::vector<float> folded;
+    if (!t) {   // old-style torch.nn.utils.spectral_norm: W = weight_orig / (u . (W v)), no power iteration in eval
+        const HostTensor *wo = m->find(key + ".weight_orig", prefix), *u = m->find(key + ".weight_u", prefix),
+                         *v = m->find(key + ".weight_v", prefix);
+        if (!wo || !u || !v) { if (need) return fail(-4, "missing tensor %s%s.weight[_orig/_u/_v]", prefix, key.c_str()); return 1; }
+        const int O = (int)wo->shape[0], I = (int)wo->shape[1];
+        float sigma = 0.f;   // fp32 like torch.dot(u, torch.mv(W, v))
+        for (int o = 0; o < O; ++o) {
+            float acc = 0.f;
+            for (int i = 0; i < I; ++i) acc += wo->v[(size_t)o * I + i] * v->v[i];
+            sigma += u->v[o] * acc;
+        }
+        folded.resize(wo->v.size());
+        for (size_t i = 0; i < folded.size(); ++i) folded[i] = wo->v[i] / sigma;
+        t = wo;
+    }
+    const std::vector<float> &src = folded.empty() ? t->v : folded;
+    const int O = (int)t->shape[0], I = (int)t->shape[1], ld = round_up(I, 32);
+    float *dst = m->stage(name + ".w", (size_t)O * ld);
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i) dst[(size_t)o * ld + (col_perm ? (*col_perm)[i] : i)] = src[(size_t)o * I + i];
+    m->wld[name] = ld;
+    const HostTensor *b = m->find(key + ".bias", prefix);
+    if (b) std::memcpy(m->stage(name + ".b", b->v.size()), b->v.data(), b->v.size() * 4);
+    return 0;
+}
+
+int pack_vec(evfly_model *m, const char *prefix, const std::string &key, const std::string &name) {
+    const HostTensor *t = m->find(key, prefix);
+    if (!t) return fail(-4, "missing tensor %s%s", prefix, key.c_str());
+    std::memcpy(m->stage(name, t->v.size()), t->v.data(), t->v.size() * 4);
+    return 0;
+}
+
+const char *kUnetP = "origunet.";
+const char *kVitP = "vitfly_vitlstm.";
+
+int pack_unet(evfly_model *m) {
+    const auto &c = m->cfg;
+    {   // e11: (32, cin, 3, 3) -> [tap*cin + ci][32]
+        const HostTensor *t = m->find("unet_e11.weight", kUnetP);
+        if (!t) return fail(-4, "missing tensor unet_e11.weight");
+        const int cin = (int)t->shape[1];
+        const int want = (c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels;
+        EVFLY_REQUIRE(cin == want && t->shape[0] == 32, "unet_e11.weight: expected (32,%d,3,3)", want);
+        float *dst = m->stage("e11.w", (size_t)9 * cin * 32);
+        for (int o = 0; o < 32; ++o)
+            for (int i = 0; i < cin; ++i)
+                for (int k = 0; k < 9; ++k) dst[(k * cin + i) * 32 + o] = t->v[((size_t)o * cin + i) * 9 + k];
+        if (int rc = pack_vec(m, kUnetP, "unet_e11.bias", "e11.b")) return rc;
+    }
+    const char *convs[] = {"e12", "e21", "e22", "e31", "e32", "e41", "e42", "e51", "e52",
+                           "d11", "d12", "d21", "d22", "d31", "d32", "d41", "d42"};
+    for (const char *n : convs)
+        if (int rc = pack_conv(m, kUnetP, std::string("unet_") + n, n)) return rc;
+    for (int l = 1; l <= 4; ++l) {   // ConvTranspose2d (Cin, Cout, 2, 2) -> [(dy*2+dx)*Cout + co][ci]
+        const std::string key = "unet_upconv" + std::to_string(l);
+        const HostTensor *t = m->find(key + ".weight", kUnetP);
+        if (!t) return fail(-4, "missing tensor %s.weight", key.c_str());
+        const int I = (int)t->shape[0], O = (int)t->shape[1], ld = round_up(I, 32);
+        float *dst = m->stage("up" + std::to_string(l) + ".w", (size_t)4 * O * ld);
+        for (int i = 0; i < I; ++i)
+            for (int o = 0; o < O; ++o)
+                for (int q = 0; q < 4; ++q) dst[((size_t)q * O + o) * ld + i] = t->v[((size_t)i * O + o) * 4 + q];
+        m->wld["up" + std::to_string(l)] = ld;
+        if (int rc = pack_vec(m, kUnetP, key + ".bias", "up" + std::to_string(l) + ".b")) return rc;
+    }
+    {   // unet_out (1, 32, 1, 1)
+        if (int rc = pack_vec(m, kUnetP, "unet_out.weight", "out.w")) return rc;
+        if (int rc = pack_vec(m, kUnetP, "unet_out.bias", "out.b")) return rc;
+    }
+    if (c.num_recurrent_unet > 0) {   // (4*hid, 2*hid, 1, 1): columns [x | h] (convlstm.py:41)
+        const HostTensor *t = m->find("lstm.cell_list.0.conv.weight", kUnetP);
+        if (!t) return fail(-4, "missing tensor lstm.cell_list.0.conv.weight");
+        const int O = (int)t->shape[0], I = (int)t->shape[1], hid = O / 4;
+        EVFLY_REQUIRE(I == 2 * hid && hid == 512, "ConvLSTM weight: expected (2048,1024,1,1)");
+        m->stage("clstm.wx", (size_t)O * hid);
+        m->stage("clstm.wh", (size_t)O * hid);   // staging may reallocate: take the pointers afterwards
+        float *wx = m->wstage.data() + m->woff["clstm.wx"], *wh = m->wstage.data() + m->woff["clstm.wh"];
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < hid; ++i) {
+                wx[(size_t)o * hid + i] = t->v[(size_t)o * I + i];
+                wh[(size_t)o * hid + i] = t->v[(size_t)o * I + hid + i];
+            }
+    }
+    return 0;
+}
+
+int pack_vit(evfly_model *m) {
+    const auto &c = m->cfg;
+    for (int s = 0; s < 2; ++s) {
+        if (c.vit_layers[s] == 0 && s == 1) continue;   // single-stage handle
+        const std::string P = "encoder_blocks." + std::to_string(s) + ".", N = "s" + std::to_string(s) + ".";
+        if (int rc = pack_conv(m, kVitP, P + "patchMerge.cn1", N + "pm")) return rc;
+        if (int rc = pack_vec(m, kVitP, P + "patchMerge.layerNorm.weight", N + "pm.g")) return rc;
+        if (int rc = pack_vec(m, kVitP, P + "patchMerge.layerNorm.bias", N + "pm.beta")) return rc;
+        for (int l = 0; l < c.vit_layers[s]; ++l) {
+            const std::string A = P + "_attn." + std::to_string(l) + ".", F = P + "_ffn." + std::to_string(l) + ".";
+            const std::string NL = N + std::to_string(l) + ".";
+            if (int rc = pack_conv(m, kVitP, A + "cn1", NL + "red")) return rc;
+            if (int rc = pack_vec(m, kVitP, A + "ln1.weight", NL + "ln1.g")) return rc;
+            if (int rc = pack_vec(m, kVitP, A + "ln1.bias", NL + "ln1.beta")) return rc;
+            if (int rc = pack_linear(m, kVitP, A + "keyValueExtractor", NL + "kv")) return rc;
+            if (int rc = pack_linear(m, kVitP, A + "query", NL + "q")) return rc;
+            if (int rc = pack_linear(m, kVitP, A + "finalLayer", NL + "fin")) return rc;
+            if (int rc = pack_linear(m, kVitP, F + "mlp1", NL + "mlp1")) return rc;
+            if (int rc = pack_vec(m, kVitP, F + "depthwise.weight", NL + "dw.w")) return rc;
+            if (int rc = pack_vec(m, kVitP, F + "depthwise.bias", NL + "dw.b")) return rc;
+            if (int rc = pack_linear(m, kVitP, F + "mlp2", NL + "mlp2")) return rc;
+            if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".weight", NL + "ln.g")) return rc;
+            if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".bias", NL + "ln.beta")) return rc;
+        }
+    }
+    if (c.head == EVFLY_HEAD_NONE) return 0;
+    if (int rc = pack_conv(m, kVitP, "down_sample", "ds")) return rc;
+    // decoder consumes out.flatten(1) of a (12,16,24) CHW tensor (vitfly_models.py:143); ours is HWC
+    std::vector<int> perm(4608);
+    for (int ch = 0; ch < 12; ++ch)
+        for (int p = 0; p < 384; ++p) perm[ch * 384 + p] = p * 12 + ch;
+    if (int rc = pack_linear(m, kVitP, "decoder", "dec", true, &perm)) return rc;
+    if (c.head == EVFLY_HEAD_LSTMNETVIT) {
+        // layer 0 input side as a GEMM over all frames; biases b_ih + b_hh folded into its bias
+        const HostTensor *wi0 = m->find("lstm.weight_ih_l0", kVitP);
+        if (!wi0) return fail(-4, "missing tensor lstm.weight_ih_l0");
+        const int G = (int)wi0->shape[0], I = (int)wi0->shape[1], ld = round_up(I, 32);
+        EVFLY_REQUIRE(G == 512 && I == 517, "lstm.weight_ih_l0: expected (512,517)");
+        float *d0 = m->stage("lstm.ih0.w", (size_t)G * ld);
+        for (int g = 0; g < G; ++g)
+            for (int i = 0; i < I; ++i) d0[(size_t)g * ld + i] = wi0->v[(size_t)g * I + i];
+        m->wld["lstm.ih0"] = ld;
+        for (int l = 0; l < 3; ++l) {
+            const std::string sl = std::to_string(l);
+            const HostTensor *bi = m->find("lstm.bias_ih_l" + sl, kVitP), *bh = m->find("lstm.bias_hh_l" + sl, kVitP);
+            const HostTensor *wh = m->find("lstm.weight_hh_l" + sl, kVitP);
+            if (!bi || !bh || !wh) return fail(-4, "missing nn.LSTM tensors of layer %d", l);
+            float *b = m->stage("lstm.b" + sl, 512);
+            for (int g = 0; g < 512; ++g) b[g] = bi->v[g] + bh->v[g];
+            float *wt = m->stage("lstm.hh" + sl, 128 * 512);    // [k][gate row]
+            for (int g = 0; g < 512; ++g)
+                for (int k = 0; k < 128; ++k) wt[k * 512 + g] = wh->v[g * 128 + k];
+            if (l > 0) {
+                const HostTensor *wi = m->find("lstm.weight_ih_l" + sl, kVitP);
+                if (!wi) return fail(-4, "missing lstm.weight_ih_l%d", l);
+                float *it = m->stage("lstm.ih" + sl, 128 * 512);
+                for (int g = 0; g < 512; ++g)
+                    for (int k = 0; k < 128; ++k) it[k * 512 + g] = wi->v[g * 128 + k];
+            }
+        }
+        if (int rc = pack_linear(m, kVitP, "nn_fc2", "fc2")) return rc;
+    } else {
+        if (int rc = pack_linear(m, kVitP, "nn_fc1", "fc1")) return rc;
+        if (int rc = pack_linear(m, kVitP, "nn_fc2", "fc2")) return rc;
+    }
+    return 0;
+}
+
+// ============================================================================ forward helpers
+struct Ctx {
+    evfly_model *m;
+    hipStream_t st;
+};
+
+// y[N,OH,OW,Cout] = act(conv(x) + b (+res))
+int conv(evfly_model *m, const char *pname, const std::string &wname, const float *x, int n, int H, int W, int C,
+         int64_t ldx, int cout, int kh, int kw, int stride, int pad, int act, const float *res, int64_t ldres, float *y,
+         int64_t ldy) {
+    ConvDesc d;
+    d.x = x; d.ldx = ldx; d.NI = n; d.H = H; d.W = W; d.C = C;
+    d.w = m->W(wname + ".w"); d.ldw = m->planning ? round_up(kh * kw * C, 32) : m->wld[wname];
+    d.bias = m->W(wname + ".b");
+    d.KH = kh; d.KW = kw; d.stride = stride; d.pad = pad;
+    conv_finish(d);
+    d.Nc = cout; d.res = res; d.ldres = ldres; d.act = act; d.y = y; d.ldy = ldy; d.dtype = m->cfg.compute_dtype;
+    if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", wname.c_str());
+    const double bytes = 4.0 * ((double)n * H * W * C + (double)d.M * cout + (double)cout * d.K);
+    RUN(m, pname, igemm_flops(d), bytes, igemm_launch(d, m->st));
+    return 0;
+}
+
+int linear(evfly_model *m, const char *pname, const std::string &wname, const float *x, int64_t rows, int K, int64_t ldx,
+           int cout, int act, const float *res, int64_t ldres, float *y, int64_t ldy) {
+    // rows can exceed int range only for absurd batches; NI is an int
+    return conv(m, pname, wname, x, (int)rows, 1, 1, K, ldx, cout, 1, 1, 1, 0, act, res, ldres, y, ldy);
+}
+
+}  // namespace
+
+// ============================================================================ U-Net forward (one chunk)
+static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *h_state, float *c_state,
+                      float *depth_out, float *upconv_out, float **depth_dev) {
+    const auto &c = m->cfg;
+    const int F = S * T;
+    const int cin = (c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels;
+    const int apply_form = (c.num_in_channels == 2 || c.form_bev > 0) ? 1 : 0;   // learner_models.py:523
+    hipStream_t st = m->st;
+
+    // ---- encoder (valid 3x3 convs; sizes of learner_models.py:373-390)
+    float *e11 = m->alloc((int64_t)F * 258 * 344 * 32);
+    RUN(m, "e11_direct", 2.0 * F * 258 * 344 * 32 * 9 * cin, 4.0 * F * (260.0 * 346 + 258.0 * 344 * 32),
+        launch_e11(frames, F, 260, 346, cin, c.form_bev, apply_form, c.evs_min_cutoff, m->W("e11.w"), m->W("e11.b"), e11, st));
+    struct Lvl { int H, W, C; float *y; } lv[5];
+    const float *cur = e11;
+    int H = 258, W = 344, C = 32;
+    const char *names[5][2] = {{nullptr, "e12"}, {"e21", "e22"}, {"e31", "e32"}, {"e41", "e42"}, {"e51", "e52"}};
+    const int chans[5] = {32, 64, 128, 256, 512};
+    for (int l = 0; l < 5; ++l) {
+        if (l > 0) {
+            float *p = m->alloc((int64_t)F * (H / 2) * (W / 2) * C);
+            RUN(m, "maxpool", 0, 4.0 * F * H * W * C * 1.25, launch_maxpool2x2(cur, F, H, W, C, p, st));
+            cur = p; H /= 2; W /= 2;
+            float *a = m->alloc((int64_t)F * (H - 2) * (W - 2) * chans[l]);
+            if (int rc = conv(m, "conv3x3", names[l][0], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, chans[l])) return rc;
+            cur = a; H -= 2; W -= 2; C = chans[l];
+        }
+        float *b = m->alloc((int64_t)F * (H - 2) * (W - 2) * chans[l]);
+        if (int rc = conv(m, "conv3x3", names[l][1], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, chans[l])) return rc;
+        cur = b; H -= 2; W -= 2; C = chans[l];
+        lv[l] = Lvl{H, W, C, b};
+        static const char *tn[5] = {"e1", "e2", "e3", "e4", "e5"};
+        m->tap(tn[l], b, F, H, W, C);
+    }
+    // ---- ConvLSTM bottleneck (batch-as-time: the T frames of a stream are its time steps)
+    float *y5 = lv[4].y;   // (F, 8, 13, 512)
+    if (c.num_recurrent_unet > 0) {
+        const int rpi = 8 * 13, hid = 512;
+        float *zx = m->alloc((int64_t)F * rpi * 4 * hid);
+        {   // input-side 1x1 conv for every frame at once
+            ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W("clstm.wx"); d.ldw = hid;
+            conv_finish(d); d.Nc = 4 * hid; d.y = zx; d.ldy = 4 * hid; d.dtype = c.compute_dtype;
+            RUN(m, "convlstm_x_gemm", igemm_flops(d), 4.0 * (d.M * 5.0 * hid + 4.0 * hid * hid), igemm_launch(d, st));
+        }
+        float *z = m->alloc((int64_t)S * rpi * 4 * hid);
+        float *hseq = m->alloc((int64_t)F * rpi * hid);
+        float *hs = h_state, *cs = c_state;
+        if (!hs) {
+            hs = m->alloc((int64_t)S * rpi * hid); cs = m->alloc((int64_t)S * rpi * hid);
+            if (!m->planning) {
+                EVFLY_HIP(hipMemsetAsync(hs, 0, (size_t)S * rpi * hid * 4, st));
+                EVFLY_HIP(hipMemsetAsync(cs, 0, (size_t)S * rpi * hid * 4, st));
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            ConvDesc d; d.x = hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W("clstm.wh"); d.ldw = hid;
+            conv_finish(d); d.Nc = 4 * hid; d.y = z; d.ldy = 4 * hid; d.dtype = c.compute_dtype;
+            d.res = zx + (int64_t)t * rpi * 4 * hid; d.ldres = 4 * hid; d.res_rpi = rpi; d.res_img_rows = (int64_t)T * rpi;
+            RUN(m, "convlstm_h_gemm", igemm_flops(d), 4.0 * (d.M * 9.0 * hid + 4.0 * hid * hid), igemm_launch(d, st));
+            RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
+                launch_convlstm_gates(z, (int64_t)S * rpi, hid, cs, hs, hseq + (int64_t)t * rpi * hid, rpi, (int64_t)T * rpi, st));
+        }
+        y5 = hseq;
+        m->tap("e5_lstm", hseq, F, 8, 13, 512);
+    }
+    // ---- decoder (learner_models.py:553-583)
+    static const int small[4][2] = {{16, 26}, {24, 44}, {40, 80}, {72, 152}};
+    const float *dcur = y5;
+    int dh = 8, dw = 13, dc = 512;
+    for (int l = 1; l <= 4; ++l) {
+        const Lvl &enc = lv[4 - l];
+        const int co = dc / 2, uh = 2 * dh, uw = 2 * dw;
+        EVFLY_REQUIRE(uh == small[l - 1][0] && uw == small[l - 1][1], "decoder geometry");
+        const int ccat = c.skip_type == EVFLY_SKIP_NONE ? co : 2 * co;
+        float *cat = m->alloc((int64_t)F * uh * uw * ccat);
+        float *up_dst = cat + (ccat - co);
+        if (c.skip_type == EVFLY_SKIP_INTERP)       // F.interpolate(y, size=small, bilinear, align_corners=False) (:514)
+            RUN(m, "skip_bilinear", 0, 4.0 * F * uh * uw * co * 5, launch_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, 0, st));
+        else if (c.skip_type == EVFLY_SKIP_CROP)    // centre crop (:512)
+            RUN(m, "skip_crop", 0, 4.0 * F * uh * uw * co * 2,
+                launch_crop(enc.y, F, enc.H, enc.W, enc.C, enc.H / 2 - uh / 2, enc.W / 2 - uw / 2, cat, uh, uw, ccat, st));
+        {   // ConvTranspose2d(k=2, s=2) as one GEMM with a 2x2 scatter epilogue into the concat buffer
+            const std::string un = "up" + std::to_string(l);
+            ConvDesc d; d.x = dcur; d.ldx = dc; d.NI = F; d.H = dh; d.W = dw; d.C = dc; d.w = m->W(un + ".w");
+            d.ldw = m->planning ? dc : m->wld[un]; d.bias = m->W(un + ".b");
+            conv_finish(d); d.Nc = 4 * co; d.y = up_dst; d.ldy = ccat; d.out_mode = OUT_UPCONV2X2; d.up_cout = co;
+            d.dtype = c.compute_dtype;
+            RUN(m, "upconv2x2", igemm_flops(d), 4.0 * F * dh * dw * (dc + 4.0 * co), igemm_launch(d, st));
+        }
+        float *a = m->alloc((int64_t)F * (uh - 2) * (uw - 2) * co);
+        const std::string n1 = "d" + std::to_string(l) + "1", n2 = "d" + std::to_string(l) + "2";
+        if (int rc = conv(m, "conv3x3", n1, cat, F, uh, uw, ccat, ccat, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, co)) return rc;
+        float *b = m->alloc((int64_t)F * (uh - 4) * (uw - 4) * co);
+        if (int rc = conv(m, "conv3x3", n2, a, F, uh - 2, uw - 2, co, co, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, co)) return rc;
+        dcur = b; dh = uh - 4; dw = uw - 4; dc = co;
+        static const char *tn[4] = {"d1", "d2", "d3", "d4"};
+        m->tap(tn[l - 1], b, F, dh, dw, dc);
+    }
+    // ---- unet_out (1x1, 32 -> 1) and form_output (:496-508)
+    float *up = upconv_out ? upconv_out : m->alloc((int64_t)F * 68 * 148);
+    RUN(m, "unet_out", 2.0 * F * 68 * 148 * 32, 4.0 * F * 68 * 148 * 33, launch_dot_out(dcur, (int64_t)F * 68 * 148, 32, m->W("out.w"), m->W("out.b"), up, st));
+    float *dp = depth_out ? depth_out : m->alloc((int64_t)F * c.input_h * c.input_w);
+    RUN(m, "depth_bilinear", 0, 4.0 * F * c.input_h * c.input_w * 2, launch_bilinear(up, F, 68, 148, 1, 1, dp, c.input_h, c.input_w, 1, 0, 0, st));
+    if (depth_dev) *depth_dev = dp;
+    return 0;
+}
+
+// ============================================================================ Mix-Transformer stage
+static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W, int Cin, float *y_out, float **y_ret,
+                     int *Ho, int *Wo) {
+    const auto &c = m->cfg;
+    hipStream_t st = m->st;
+    const int C = c.vit_width[s], heads = c.vit_heads[s], R = c.vit_reduction[s], E = C * c.vit_expansion;
+    const int k = c.vit_patch[s], sd = c.vit_stride[s], pd = c.vit_pad[s];
+    const int h = (H + 2 * pd - k) / sd + 1, w = (W + 2 * pd - k) / sd + 1;
+    const int64_t rows = (int64_t)n * h * w;
+    const std::string N = "s" + std::to_string(s) + ".";
+    // OverlapPatchMerging: conv + LayerNorm (ViTsubmodules.py:30-33)
+    float *t0 = m->alloc(rows * C);
+    if (int rc = conv(m, "vit_patch_conv", N + "pm", x, n, H, W, Cin, Cin, C, k, k, sd, pd, ACT_NONE, nullptr, 0, t0, C)) return rc;
+    float *xcur = m->alloc(rows * C);
+    RUN(m, "vit_layernorm", 0, 8.0 * rows * C, launch_layernorm(t0, nullptr, rows, C, m->W(N + "pm.g"), m->W(N + "pm.beta"), xcur, st));
+    const int rh = (h - R) / R + 1, rw = (w - R) / R + 1, nkv = rh * rw;
+    for (int l = 0; l < c.vit_layers[s]; ++l) {
+        const std::string NL = N + std::to_string(l) + ".";
+        // --- EfficientSelfAttention (:54-83)
+        float *red = m->alloc((int64_t)n * nkv * C);
+        if (int rc = conv(m, "vit_kv_reduce_conv", NL + "red", xcur, n, h, w, C, C, C, R, R, R, 0, ACT_NONE, nullptr, 0, red, C)) return rc;
+        float *redn = m->alloc((int64_t)n * nkv * C);
+        RUN(m, "vit_layernorm", 0, 8.0 * n * nkv * C, launch_layernorm(red, nullptr, (int64_t)n * nkv, C, m->W(NL + "ln1.g"), m->W(NL + "ln1.beta"), redn, st));
+        float *kv = m->alloc((int64_t)n * nkv * 2 * C);
+        if (int rc = linear(m, "vit_linear", NL + "kv", redn, (int64_t)n * nkv, C, C, 2 * C, ACT_NONE, nullptr, 0, kv, 2 * C)) return rc;
+        float *q = m->alloc(rows * C);
+        if (int rc = linear(m, "vit_linear", NL + "q", xcur, rows, C, C, C, ACT_NONE, nullptr, 0, q, C)) return rc;
+        float *att = m->alloc(rows * C);
+        RUN(m, "vit_attention", 4.0 * rows * C * nkv, 8.0 * rows * C, launch_attention(q, kv, n, h * w, nkv, C, heads, att, st));
+        float *x1 = m->alloc(rows * C);   // x = x + attn(x)   (:144)
+        if (int rc = linear(m, "vit_linear", NL + "fin", att, rows, C, C, C, ACT_NONE, xcur, C, x1, C)) return rc;
+        // --- MixFFN (:98-120)
+        float *h1 = m->alloc(rows * E);
+        if (int rc = linear(m, "vit_linear", NL + "mlp1", x1, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E)) return rc;
+        float *h2 = m->alloc(rows * E);
+        RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 8.0 * rows * E,
+            launch_grouped_conv_gelu(h1, n, h, w, E, m->W(NL + "dw.w"), m->W(NL + "dw.b"), h2, st));
+        float *x2 = m->alloc(rows * C);   // x = x + ffn(x)    (:145)
+        if (int rc = linear(m, "vit_linear", NL + "mlp2", h2, rows, E, E, C, ACT_NONE, x1, C, x2, C)) return rc;
+        const bool last = l == c.vit_layers[s] - 1;
+        float *xn = (last && y_out) ? y_out : m->alloc(rows * C);
+        RUN(m, "vit_layernorm", 0, 8.0 * rows * C, launch_layernorm(x2, nullptr, rows, C, m->W(NL + "ln.g"), m->W(NL + "ln.beta"), xn, st));
+        xcur = xn;
+    }
+    if (c.vit_layers[s] == 0 && y_out && !m->planning)
+        EVFLY_HIP(hipMemcpyAsync(y_out, xcur, (size_t)rows * C * 4, hipMemcpyDeviceToDevice, st));
+    if (y_ret) *y_ret = xcur;
+    *Ho = h; *Wo = w;
+    return 0;
+}
+
+// ============================================================================ velocity model forward (one chunk)
+static int vit_chunk(evfly_model *m, const float *img, int ih, int iw, int clip2x, const float *desvel, const float *quat,
+                     int S, int T, float *lstm_h, float *lstm_c, float *vel) {
+    const auto &c = m->cfg;
+    hipStream_t st = m->st;
+    const int F = S * T;
+    // refine_inputs (vitfly_models.py:27-29) + the depth hand-off clip (learner_models.py:634)
+    const float *vin = img;
+    if (ih != 60 || iw != 90 || clip2x) {
+        float *t = m->alloc((int64_t)F * 60 * 90);
+        RUN(m, "vit_input_resize", 0, 4.0 * F * (60.0 * 90 * 5), launch_bilinear(img, F, ih, iw, 1, 1, t, 60, 90, 1, 0, clip2x ? 1 : 0, st));
+        vin = t;
+    }
+    m->tap("vit_in", const_cast<float *>(vin), F, 60, 90, 1);
+    float *s1 = nullptr, *s2 = nullptr;
+    int h1, w1, h2, w2;
+    if (int rc = vit_stage(m, 0, vin, F, 60, 90, c.vit_in_channels, nullptr, &s1, &h1, &w1)) return rc;
+    m->tap("s1", s1, F, h1, w1, c.vit_width[0]);
+    if (int rc = vit_stage(m, 1, s1, F, h1, w1, c.vit_width[0], nullptr, &s2, &h2, &w2)) return rc;
+    m->tap("s2", s2, F, h2, w2, c.vit_width[1]);
+    EVFLY_REQUIRE(2 * h2 == 16 && 2 * w2 == 24, "ViT head expects a 16x24 map (got %dx%d)", 2 * h2, 2 * w2);
+    // cat[PixelShuffle(2)(s2), Upsample(s1 -> 16x24, align_corners=True)]   (vitfly_models.py:141)
+    const int c_ps = c.vit_width[1] / 4, ccat = c_ps + c.vit_width[0];
+    float *cat = m->alloc((int64_t)F * 16 * 24 * ccat);
+    RUN(m, "vit_pixel_shuffle", 0, 8.0 * F * 384 * c_ps, launch_pixel_shuffle2(s2, F, h2, w2, c.vit_width[1], cat, ccat, st));
+    RUN(m, "vit_upsample", 0, 8.0 * F * 384 * c.vit_width[0],
+        launch_bilinear(s1, F, h1, w1, c.vit_width[0], c.vit_width[0], cat + c_ps, 16, 24, ccat, 1, 0, st));
+    float *flat = m->alloc((int64_t)F * 4608);
+    if (int rc = conv(m, "vit_head_conv", "ds", cat, F, 16, 24, ccat, ccat, 12, 3, 3, 1, 1, ACT_NONE, nullptr, 0, flat, 12)) return rc;
+    m->tap("flat", flat, F, 16, 24, 12);
+    const int LD = 544;   // 517 padded to a multiple of 32
+    float *x517 = m->alloc((int64_t)F * LD);
+    if (int rc = linear(m, "vit_decoder_linear", "dec", flat, F, 4608, 4608, 512, ACT_NONE, nullptr, 0, x517, LD)) return rc;
+    RUN(m, "vit_meta_fill", 0, 4.0 * F * 32, launch_meta_fill(x517, F, LD, desvel, quat, st));
+    m->tap("x517", x517, F, LD, 1, 1);
+    if (c.head == EVFLY_HEAD_LSTMNETVIT) {
+        float *xg0 = m->alloc((int64_t)F * 512);
+        {
+            ConvDesc d; d.x = x517; d.ldx = LD; d.NI = F; d.C = LD; d.w = m->W("lstm.ih0.w"); d.ldw = LD; d.bias = m->W("lstm.b0");
+            conv_finish(d); d.Nc = 512; d.y = xg0; d.ldy = 512; d.dtype = c.compute_dtype;
+            RUN(m, "lstm_x_gemm", igemm_flops(d), 4.0 * (F * (LD + 512.0) + 512.0 * LD), igemm_launch(d, st));
+        }
+        LstmWeights w{};
+        for (int l = 0; l < 3; ++l) {
+            w.whh_t[l] = m->W("lstm.hh" + std::to_string(l));
+            w.wih_t[l] = l ? m->W("lstm.ih" + std::to_string(l)) : nullptr;
+            w.bias[l] = m->W("lstm.b" + std::to_string(l));
+        }
+        w.fc_w = m->W("fc2.w"); w.fc_b = m->W("fc2.b");
+        RUN(m, "lstm_recurrence", 2.0 * F * 5 * 128 * 512, 4.0 * F * 5 * 128 * 512, launch_lstm(xg0, S, T, w, lstm_h, lstm_c, vel, st));
+    } else {
+        float *f1 = m->alloc((int64_t)F * 256);
+        if (int rc = linear(m, "vit_fc", "fc1", x517, F, LD, LD, 256, ACT_LEAKY, nullptr, 0, f1, 256)) return rc;
+        if (int rc = linear(m, "vit_fc", "fc2", f1, F, 256, 256, 3, ACT_NONE, nullptr, 0, vel, 3)) return rc;
+    }
+    return 0;
+}
+
+// ============================================================================ chunked drivers
+namespace {
+
+template <typename Fn>
+int with_arena(evfly_model *m, Fn &&body) {
+    // pass 1: plan the arena, pass 2: run
+    m->planning = true; m->arena_off = 0; m->plan_peak = 0;
+    if (int rc = body()) { m->planning = false; return rc; }
+    m->planning = false;
+    if (m->plan_peak > m->arena_cap) {
+        if (m->arena) EVFLY_HIP(hipFree(m->arena));
+        m->arena = nullptr; m->arena_cap = 0;
+        EVFLY_HIP(hipMalloc(reinterpret_cast<void **>(&m->arena), m->plan_peak));
+        m->arena_cap = m->plan_peak;
+    }
+    m->arena_off = 0;
+    return body();
+}
+
+int check_model(evfly_model *m, void *stream) {
+    EVFLY_REQUIRE(m && m->finalized, "model handle is null or not finalized");
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev == m->device, "model handle lives on device %d, current device is %d", m->device, dev);
+    m->st = as_stream(stream);
+    return 0;
+}
+
+constexpr int kChunkFrames = 320;
+
+}  // namespace
+
+extern "C" int evfly_unet_forward(evfly_model *m, const float *frames, int n_streams, int T, float *h_state, float *c_state,
+                                  float *depth_out, float *upconv_out, void *stream) {
+    if (int rc = check_model(m, stream)) return rc;
+    EVFLY_REQUIRE(m->cfg.has_unet, "handle has no U-Net");
+    EVFLY_REQUIRE(frames && n_streams > 0 && T > 0, "unet_forward: empty batch");
+    EVFLY_REQUIRE((h_state == nullptr) == (c_state == nullptr), "unet_forward: h_state and c_state go together");
+    const int per = std::max(1, kChunkFrames / T);
+    const int64_t fr = (int64_t)m->cfg.input_h * m->cfg.input_w;
+    for (int s0 = 0; s0 < n_streams; s0 += per) {
+        const int S = std::min(per, n_streams - s0);
+        auto body = [&]() {
+            return unet_chunk(m, frames + (int64_t)s0 * T * fr, S, T, h_state ? h_state + (int64_t)s0 * 104 * 512 : nullptr,
+                              c_state ? c_state + (int64_t)s0 * 104 * 512 : nullptr,
+                              depth_out ? depth_out + (int64_t)s0 * T * fr : nullptr,
+                              upconv_out ? upconv_out + (int64_t)s0 * T * 68 * 148 : nullptr, nullptr);
+        };
+        if (int rc = with_arena(m, body)) return rc;
+    }
+    return 0;
+}
+
+extern "C" int evfly_vit_forward(evfly_model *m, const float *img, int img_h, int img_w, int clip2x, const float *desvel,
+                                 const float *quat, int n_streams, int T, float *lstm_h, float *lstm_c, float *vel_out,
+                                 void *stream) {
+    if (int rc = check_model(m, stream)) return rc;
+    EVFLY_REQUIRE(m->cfg.head != EVFLY_HEAD_NONE, "handle has no velocity head");
+    EVFLY_REQUIRE(img && desvel && vel_out && n_streams > 0 && T > 0, "vit_forward: null argument");
+    const int per = std::max(1, 4 * kChunkFrames / T);
+    for (int s0 = 0; s0 < n_streams; s0 += per) {
+        const int S = std::min(per, n_streams - s0);
+        const int64_t f0 = (int64_t)s0 * T;
+        auto body = [&]() {
+            return vit_chunk(m, img + f0 * img_h * img_w, img_h, img_w, clip2x, desvel + f0, quat ? quat + f0 * 4 : nullptr, S, T,
+                             lstm_h ? lstm_h + (int64_t)s0 * 384 : nullptr, lstm_c ? lstm_c + (int64_t)s0 * 384 : nullptr,
+                             vel_out + f0 * 3);
+        };
+        if (int rc = with_arena(m, body)) return rc;
+    }
+    return 0;
+}
+
+extern "C" int evfly_vit_stage_forward(evfly_model *m, int stage, const float *x, int n, int h, int w, float *y, void *stream) {
+    if (int rc = check_model(m, stream)) return rc;
+    EVFLY_REQUIRE(stage == 0 || stage == 1, "stage must be 0 or 1");
+    EVFLY_REQUIRE(x && y && n > 0, "vit_stage_forward: null argument");
+    const int cin = stage == 0 ? m->cfg.vit_in_channels : m->cfg.vit_width[0];
+    int ho, wo;
+    auto body = [&]() { return vit_stage(m, stage, x, n, h, w, cin, y, nullptr, &ho, &wo); };
+    return with_arena(m, body);
+}
+
+extern "C" int evfly_e2v_forward(evfly_model *m, const float *frames, const float *desvel, int n_streams, int T,
+                                 float *h_state, float *c_state, float *lstm_h, float *lstm_c, float *depth_out,
+                                 float *upconv_out, float *vel_out, void *stream) {
+    if (int rc = check_model(m, stream)) return rc;
+    EVFLY_REQUIRE(m->cfg.has_unet && m->cfg.head != EVFLY_HEAD_NONE, "e2v_forward needs a composite handle");
+    EVFLY_REQUIRE(frames && desvel && vel_out && n_streams > 0 && T > 0, "e2v_forward: null argument");
+    EVFLY_REQUIRE((h_state == nullptr) == (c_state == nullptr), "e2v_forward: h_state and c_state go together");
+    const int per = std::max(1, kChunkFrames / T);
+    const int H = m->cfg.input_h, Wd = m->cfg.input_w;
+    const int64_t fr = (int64_t)H * Wd;
+    for (int s0 = 0; s0 < n_streams; s0 += per) {
+        const int S = std::min(per, n_streams - s0);
+        const int64_t f0 = (int64_t)s0 * T;
+        auto body = [&]() {
+            float *depth = nullptr;
+            if (int rc = unet_chunk(m, frames + f0 * fr, S, T, h_state ? h_state + (int64_t)s0 * 104 * 512 : nullptr,
+                                    c_state ? c_state + (int64_t)s0 * 104 * 512 : nullptr,
+                                    depth_out ? depth_out + f0 * fr : nullptr, upconv_out ? upconv_out + f0 * 68 * 148 : nullptr,
+                                    &depth))
+                return rc;
+            // x_depth_input = clip(x_depth * 2, 0, 1) (learner_models.py:634), fused into the 60x90 resize
+            return vit_chunk(m, depth, H, Wd, 1, desvel + f0, nullptr, S, T, lstm_h ? lstm_h + (int64_t)s0 * 384 : nullptr,
+                             lstm_c ? lstm_c + (int64_t)s0 * 384 : nullptr, vel_out + f0 * 3);
+        };
+        if (int rc = with_arena(m, body)) return rc;
+    }
+    return 0;
+}
+
+// ============================================================================ lifecycle
+extern "C" int evfly_model_create(const evfly_model_config *cfg, evfly_model **out) {
+    EVFLY_REQUIRE(cfg && out, "model_create: null argument");
+    if (cfg->has_unet) {
+        EVFLY_REQUIRE(cfg->input_h == 260 && cfg->input_w == 346,
+                      "OrigUNet geometry is hard-wired for 260x346 (learner_models.py:373-419)");
+        EVFLY_REQUIRE(cfg->form_bev >= 0 && cfg->form_bev <= 2, "form_BEV should be 0/1/2, but is %d", cfg->form_bev);
+        EVFLY_REQUIRE(cfg->skip_type >= 0 && cfg->skip_type <= 2, "skip_type should be crop/interp/none");
+        EVFLY_REQUIRE(cfg->num_out_channels == 1, "num_out_channels != 1 is not built");
+        EVFLY_REQUIRE(cfg->num_recurrent_unet == 0 || cfg->num_recurrent_unet == 1, "only 0 or 1 ConvLSTM layers are built");
+    }
+    EVFLY_REQUIRE(cfg->compute_dtype == EVFLY_DTYPE_F32 || cfg->compute_dtype == EVFLY_DTYPE_BF16, "bad compute_dtype");
+    auto *m = new evfly_model();
+    m->cfg = *cfg;
+    if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(-2, "hipGetDevice failed"); }
+    *out = m;
+    return 0;
+}
+
+extern "C" int evfly_model_load_tensor(evfly_model *m, const char *key, const float *data_host, const int64_t *shape, int ndim) {
+    EVFLY_REQUIRE(m && key && data_host && ndim >= 0 && ndim <= 8, "load_tensor: bad argument");
+    EVFLY_REQUIRE(!m->finalized, "load_tensor after finalize");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.v.assign(data_host, data_host + t.numel());
+    m->host[key] = std::move(t);
+    return 0;
+}
+
+extern "C" int evfly_model_finalize(evfly_model *m) {
+    EVFLY_REQUIRE(m && !m->finalized, "finalize: bad handle");
+    if (m->cfg.has_unet)
+        if (int rc = pack_unet(m)) return rc;
+    bool any_vit = false;
+    for (auto &kv : m->host) any_vit |= kv.first.find("encoder_blocks.") != std::string::npos;
+    if (m->cfg.head != EVFLY_HEAD_NONE || any_vit)
+        if (int rc = pack_vit(m)) return rc;
+    EVFLY_REQUIRE(!m->wstage.empty(), "finalize: no tensors were loaded");
+    EVFLY_HIP(hipMalloc(reinterpret_cast<void **>(&m->wdev), m->wstage.size() * 4));
+    EVFLY_HIP(hipMemcpy(m->wdev, m->wstage.data(), m->wstage.size() * 4, hipMemcpyHostToDevice));
+    m->wstage.clear(); m->wstage.shrink_to_fit();
+    m->host.clear();
+    m->finalized = true;
+    return 0;
+}
+
+extern "C" void evfly_model_destroy(evfly_model *m) { delete m; }
+
+extern "C" int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_host, int64_t max_elems, int64_t *shape_out,
+                                   void *stream) {
+    EVFLY_REQUIRE(m && name && dst_host, "tap: null argument");
+    auto it = m->taps.find(name);
+    EVFLY_REQUIRE(it != m->taps.end(), "tap '%s' was not produced by the last forward", name);
+    int64_t n = 1;
+    for (int i = 0; i < 4; ++i) { n *= it->second.shape[i]; if (shape_out) shape_out[i] = it->second.shape[i]; }
+    EVFLY_REQUIRE(n <= max_elems, "tap '%s' has %lld elements, buffer holds %lld", name, (long long)n, (long long)max_elems);
+    EVFLY_HIP(hipStreamSynchronize(as_stream(stream)));
+    EVFLY_HIP(hipMemcpy(dst_host, it->second.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int evfly_model_set_profiling(evfly_model *m, int enable) {
+    EVFLY_REQUIRE(m, "null handle");
+    m->profiling = enable != 0;
+    return 0;
+}
+extern "C" int evfly_model_profile_count(evfly_model *m) {
+    if (!m) return 0;
+    if (m->prof_collect()) return 0;
+    return (int)m->agg.size();
+}
+extern "C" int evfly_model_profile_get(evfly_model *m, int i, char *name_out, int name_cap, double *ms_out, double *flops_out,
+                                       double *bytes_out, int *launches_out) {
+    EVFLY_REQUIRE(m && i >= 0 && i < (int)m->agg.size(), "profile_get: index out of range");
+    const ProfAgg &a = m->agg[i];
+    if (name_out && name_cap > 0) { std::strncpy(name_out, a.name.c_str(), name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (ms_out) *ms_out = a.ms;
+    if (flops_out) *flops_out = a.flops;
+    if (bytes_out) *bytes_out = a.bytes;
+    if (launches_out) *launches_out = a.launches;
+    return 0;
+}
+extern "C" int evfly_model_profile_reset(evfly_model *m) {
+    EVFLY_REQUIRE(m, "null handle");
+    if (int rc = m->prof_collect()) return rc;
+    m->agg.clear();
+    return 0;
+}
+
+// ============================================================================ single-operator entry point
+extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin, const float *w_packed, const float *bias,
+                                    int cout, int kh, int kw, int stride, int pad, int act, const float *res, float *y,
+                                    int dtype, void *stream) {
+    EVFLY_REQUIRE(x && w_packed && y, "op_conv2d: null argument");
+    ConvDesc d;
+    d.x = x; d.ldx = cin; d.NI = n; d.H = h; d.W = w; d.C = cin; d.w = w_packed; d.bias = bias;
+    d.KH = kh; d.KW = kw; d.stride = stride; d.pad = pad;
+    conv_finish(d);
+    EVFLY_REQUIRE(d.K % 32 == 0, "op_conv2d: kh*kw*cin must be a multiple of 32 (weights are [cout][kh][kw][cin] unpadded)");
+    d.ldw = d.K; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
+    return igemm_launch(d, as_stream(stream));
+}

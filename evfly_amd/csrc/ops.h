@@ -1,0 +1,47 @@
+// Non-GEMM kernels of the depth / velocity models (gfx950). All activations are fp32 NHWC.
+#pragma once
+#include "common.h"
+
+namespace evfly {
+
+// first U-Net conv with the input formation of learner_models.py:476-494 fused in
+int launch_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff,
+               const float *w_packed /*[9*cin][32]*/, const float *bias, float *y, hipStream_t st);
+int launch_maxpool2x2(const float *x, int n, int H, int W, int C, float *y, hipStream_t st);
+// bilinear resize (F.interpolate / nn.Upsample); y pixel stride ldy, written at channel offset 0 of y.
+// pre: 0 none, 1 clip(2*v, 0, 1) applied to every source sample (learner_models.py:634)
+int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, float *y, int Ho, int Wo, int64_t ldy,
+                    int align_corners, int pre, hipStream_t st);
+// centre crop of the skip tensor (skip_type == 'crop', learner_models.py:512)
+int launch_crop(const float *x, int n, int Hi, int Wi, int C, int top, int left, float *y, int Ho, int Wo, int64_t ldy,
+                hipStream_t st);
+// ConvLSTM cell epilogue (convlstm.py:44-51): z rows [i|f|o|g], updates c in place, writes h and a copy
+// h_copy row of state row r: (r / rpi) * copy_img_rows + r % rpi  (hseq[stream][t] for one t)
+int launch_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, float *h_copy, int rpi,
+                          int64_t copy_img_rows, hipStream_t st);
+// 1x1 conv to one channel (unet_out)
+int launch_dot_out(const float *x, int64_t rows, int C, const float *w, const float *bias, float *y, hipStream_t st);
+// y = LayerNorm(a (+ b)) over the last dim C (eps 1e-5)
+int launch_layernorm(const float *a, const float *b, int64_t rows, int C, const float *gamma, const float *beta,
+                     float *y, hipStream_t st);
+// spatial-reduction attention core (ViTsubmodules.py:74-80): q (frames*N, C), kv (frames*nkv, 2C) -> out (frames*N, C)
+int launch_attention(const float *q, const float *kv, int frames, int N, int nkv, int C, int heads, float *out,
+                     hipStream_t st);
+// MixFFN middle: grouped 3x3 'same' conv (groups = Ce/8, 8 in / 8 out per group) + bias + erf-GELU
+int launch_grouped_conv_gelu(const float *x, int n, int H, int W, int Ce, const float *w /*[Ce][8][3][3]*/,
+                             const float *bias, float *y, hipStream_t st);
+int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st);
+// x517 assembly (vitfly_models.py:144): cols [512] = desvel/10, [513..516] = quat (or 1,0,0,0), rest of the pad 0
+int launch_meta_fill(float *x517, int64_t rows, int ld, const float *desvel, const float *quat, hipStream_t st);
+// nn.LSTM (3 layers, hidden 128) over T steps for every stream + the final Linear(128 -> 3)
+struct LstmWeights {
+    const float *whh_t[3];   // [128][512]  (k-major)
+    const float *wih_t[3];   // layers 1, 2: [128][512]; layer 0 unused (input side precomputed)
+    const float *bias[3];    // b_ih + b_hh, layers 1, 2 (layer 0's is folded into xg0)
+    const float *fc_w;       // [3][128] spectral-norm folded
+    const float *fc_b;       // [3]
+};
+int launch_lstm(const float *xg0 /*(S*T, 512)*/, int n_streams, int T, LstmWeights w, float *h_state, float *c_state,
+                float *vel, hipStream_t st);
+
+}  // namespace evfly

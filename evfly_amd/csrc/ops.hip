@@ -1,0 +1,529 @@
+// Non-GEMM kernels (gfx950): memory-bound elementwise / stencil / small-reduction work around the
+// MFMA GEMMs. fp32, NHWC, 16-B vector accesses along channels, wave64 shuffles for row reductions.
+#include "ops.h"
+
+#include <algorithm>
+
+namespace evfly {
+namespace {
+
+constexpr int kMaxBlocks = 8 * kNumCU;   // grid-stride cap for memory-bound kernels
+
+inline int grid_for(int64_t work, int threads) { return (int)std::min<int64_t>(kMaxBlocks, cdiv(work, threads)); }
+
+// ------------------------------------------------------------------------------------------ e11
+// learner_models.py:476-494 (form_input) + unet_e11 (3x3 valid, Cin in {1,2} -> 32) + ReLU.
+// One thread = one output pixel x 8 output channels (4 threads write a pixel's 128 B).
+__device__ __forceinline__ float form_value(float x, int form_bev, int apply_form, float cutoff, int channel) {
+    if (!apply_form) return x;
+    if (fabsf(x) < cutoff) x = 0.0f;                 // :477 (NaN is not < cutoff and survives)
+    if (form_bev == 2) return x != 0.0f ? 1.0f : 0.0f;   // :489-490
+    if (form_bev == 1) return fabsf(x);                // :485
+    // form_bev == 0 (:479-481): both channels alias one buffer; the last write (positive part) wins
+    (void)channel;
+    return x > 0.0f ? x : 0.0f;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void k_e11(const float *__restrict__ frames, int n, int H, int W, int form_bev,
+                                              int apply_form, float cutoff, const float *__restrict__ wp,
+                                              const float *__restrict__ bias, float *__restrict__ y) {
+    const int OH = H - 2, OW = W - 2;
+    const int og = threadIdx.x & 3;                    // 8-channel group
+    float w[9 * CIN][8];
+#pragma unroll
+    for (int t = 0; t < 9 * CIN; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[t][c] = wp[t * 32 + og * 8 + c];
+    float b[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) b[c] = bias[og * 8 + c];
+    const int64_t total = (int64_t)n * OH * OW;
+    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; pix < total; pix += ((int64_t)gridDim.x * 256) >> 2) {
+        const int img = (int)(pix / (OH * OW));
+        const int rem = (int)(pix - (int64_t)img * OH * OW);
+        const int oy = rem / OW, ox = rem - oy * OW;
+        const float *src = frames + ((int64_t)img * H + oy) * W + ox;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = b[c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float raw = src[ky * W + kx];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float v = form_value(raw, form_bev, apply_form, cutoff, ci);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, w[(ky * 3 + kx) * CIN + ci][c], acc[c]);
+                }
+            }
+        float4 o0 = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+        float4 o1 = make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
+        float4 *dst = reinterpret_cast<float4 *>(y + pix * 32 + og * 8);
+        dst[0] = o0;
+        dst[1] = o1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ maxpool
+__global__ __launch_bounds__(256) void k_maxpool2x2(const float4 *__restrict__ x, int n, int H, int W, int C4,
+                                                    float4 *__restrict__ y) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = (int64_t)n * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ox = (int)(p % OW); p /= OW;
+        const int oy = (int)(p % OH);
+        const int img = (int)(p / OH);
+        const float4 *s = x + (((int64_t)img * H + 2 * oy) * W + 2 * ox) * C4 + c;
+        const float4 a = s[0], b = s[C4], cc = s[(int64_t)W * C4], d = s[(int64_t)W * C4 + C4];
+        float4 o;   // NaN-propagating max like torch: (a > b || isnan(a)) ? a : b
+#define MX(p, q) ((p) > (q) || (p) != (p) ? (p) : (q))
+        o.x = MX(MX(a.x, b.x), MX(cc.x, d.x)); o.y = MX(MX(a.y, b.y), MX(cc.y, d.y));
+        o.z = MX(MX(a.z, b.z), MX(cc.z, d.z)); o.w = MX(MX(a.w, b.w), MX(cc.w, d.w));
+#undef MX
+        y[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bilinear
+// ATen upsample_bilinear2d (aten/src/ATen/native/UpSample.h area_pixel_compute_* + cpu/UpSampleKernel.cpp):
+// fp32 scale, source index, lambdas; result = wh0*(ww0*v00 + ww1*v01) + wh1*(ww0*v10 + ww1*v11).
+__device__ __forceinline__ void src_index(int dst, int in_size, int out_size, float scale, int align, int &i0, int &i1,
+                                          float &l0, float &l1) {
+    if (in_size == out_size) { i0 = i1 = dst; l0 = 1.f; l1 = 0.f; return; }
+    float real = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = min((int)floorf(real), in_size - 1);
+    l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l0 = 1.f - l1;
+}
+
+__device__ __forceinline__ float pre_op(float v, int pre) {
+    if (pre == 1) { v = v * 2.0f; v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }   // torch.clip(x*2, 0, 1)
+    return v;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, int n, int Hi, int Wi, int C, int64_t ldx,
+                                                  float *__restrict__ y, int Ho, int Wo, int64_t ldy, int align, int pre,
+                                                  float sh, float sw) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)n * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CV) * VEC;
+        int64_t p = i / CV;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int img = (int)(p / Ho);
+        int y0, y1, x0, x1;
+        float hy0, hy1, wx0, wx1;
+        src_index(oy, Hi, Ho, sh, align, y0, y1, hy0, hy1);
+        src_index(ox, Wi, Wo, sw, align, x0, x1, wx0, wx1);
+        const float *b = x + (int64_t)img * Hi * Wi * ldx + c;
+        const float *p00 = b + ((int64_t)y0 * Wi + x0) * ldx, *p01 = b + ((int64_t)y0 * Wi + x1) * ldx;
+        const float *p10 = b + ((int64_t)y1 * Wi + x0) * ldx, *p11 = b + ((int64_t)y1 * Wi + x1) * ldx;
+        float *o = y + (((int64_t)img * Ho + oy) * Wo + ox) * ldy + c;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float t0 = pre_op(p00[e], pre) * wx0 + pre_op(p01[e], pre) * wx1;
+            const float t1 = pre_op(p10[e], pre) * wx0 + pre_op(p11[e], pre) * wx1;
+            o[e] = t0 * hy0 + t1 * hy1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_crop(const float4 *__restrict__ x, int n, int Hi, int Wi, int C4, int top, int left,
+                                              float4 *__restrict__ y, int Ho, int Wo, int64_t ldy4) {
+    const int64_t total = (int64_t)n * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int img = (int)(p / Ho);
+        y[(((int64_t)img * Ho + oy) * Wo + ox) * ldy4 + c] = x[(((int64_t)img * Hi + oy + top) * Wi + ox + left) * C4 + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ ConvLSTM gates
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void k_convlstm_gates(const float *__restrict__ z, int64_t rows, int hid,
+                                                        float *__restrict__ c, float *__restrict__ h,
+                                                        float *__restrict__ h_copy, int rpi, int64_t copy_img_rows) {
+    const int64_t total = rows * hid;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / hid;
+        const int j = (int)(i - r * hid);
+        const float *zr = z + r * 4 * hid;
+        const float gi = sigmoidf_(zr[j]), gf = sigmoidf_(zr[hid + j]), go = sigmoidf_(zr[2 * hid + j]);
+        const float gg = tanhf(zr[3 * hid + j]);                           // convlstm.py:44-48 (i, f, o, g)
+        const float cn = gf * c[i] + gi * gg;                             // :50
+        const float hn = go * tanhf(cn);                                  // :51
+        c[i] = cn;
+        h[i] = hn;
+        if (h_copy) {
+            const int64_t g = r / rpi;
+            h_copy[(g * copy_img_rows + (r - g * rpi)) * hid + j] = hn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 1x1 conv -> 1 channel
+__global__ __launch_bounds__(256) void k_dot_out(const float *__restrict__ x, int64_t rows, int C, const float *__restrict__ w,
+                                                 const float *__restrict__ bias, float *__restrict__ y) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        const float4 *p = reinterpret_cast<const float4 *>(x + r * C);
+        float acc = 0.f;
+        for (int c = 0; c < C / 4; ++c) {
+            const float4 v = p[c];
+            const float4 ww = reinterpret_cast<const float4 *>(w)[c];
+            acc = fmaf(v.x, ww.x, acc); acc = fmaf(v.y, ww.y, acc); acc = fmaf(v.z, ww.z, acc); acc = fmaf(v.w, ww.w, acc);
+        }
+        y[r] = acc + bias[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// one wave per row; C <= 64 * 8
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ a, const float *__restrict__ b, int64_t rows,
+                                                   int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t r = wave; r < rows; r += n_waves) {
+        float v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = lane + 64 * k;
+            v[k] = 0.f;
+            if (c < C) {
+                v[k] = a[r * C + c];
+                if (b) v[k] += b[r * C + c];
+                s += v[k];
+            }
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) y[r * C + c] = (v[k] - mean) * rstd * gamma[c] + beta[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// One thread per (token, head), head dim 32. ViTsubmodules.py:74-80: keyVal rows are [2][heads][d].
+constexpr int kMaxKV = 16;
+__global__ __launch_bounds__(256) void k_attention(const float *__restrict__ q, const float *__restrict__ kv, int frames,
+                                                   int N, int nkv, int C, int heads, float *__restrict__ out) {
+    const int64_t total = (int64_t)frames * N * heads;
+    const float dim_head = sqrtf((float)(C / heads));   // scores are DIVIDED by sqrt(d) after q.k (ViTsubmodules.py:78-79)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int hd = (int)(i % heads);
+        const int64_t tok = i / heads;
+        const int f = (int)(tok / N);
+        const float4 *qp = reinterpret_cast<const float4 *>(q + tok * C + hd * 32);
+        float4 qv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) qv[k] = qp[k];
+        float sc[kMaxKV];
+        float mx = -INFINITY;
+        for (int j = 0; j < nkv; ++j) {
+            const float4 *kp = reinterpret_cast<const float4 *>(kv + ((int64_t)f * nkv + j) * 2 * C + hd * 32);
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 kk = kp[k];
+                s = fmaf(qv[k].x, kk.x, s); s = fmaf(qv[k].y, kk.y, s); s = fmaf(qv[k].z, kk.z, s); s = fmaf(qv[k].w, kk.w, s);
+            }
+            s = s / dim_head;
+            sc[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float den = 0.f;
+        for (int j = 0; j < nkv; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+        float4 o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = make_float4(0, 0, 0, 0);
+        for (int j = 0; j < nkv; ++j) {
+            const float p = sc[j] / den;
+            const float4 *vp = reinterpret_cast<const float4 *>(kv + ((int64_t)f * nkv + j) * 2 * C + C + hd * 32);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 vv = vp[k];
+                o[k].x = fmaf(p, vv.x, o[k].x); o[k].y = fmaf(p, vv.y, o[k].y);
+                o[k].z = fmaf(p, vv.z, o[k].z); o[k].w = fmaf(p, vv.w, o[k].w);
+            }
+        }
+        float4 *op = reinterpret_cast<float4 *>(out + tok * C + hd * 32);   // (attn@v).transpose(1,2).reshape(B,N,C)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) op[k] = o[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ MixFFN grouped conv + GELU
+// Conv2d(Ce, Ce, 3, padding='same', groups=Ce/8): output channel co reads the 8 input channels of its
+// group (ViTsubmodules.py:92). Thread = one output channel (72 weights in registers) walking a strip
+// of pixels; the 8 threads of a group issue identical input addresses (one request, broadcast).
+constexpr int kGcPix = 8;
+__global__ __launch_bounds__(256) void k_grouped_conv_gelu(const float *__restrict__ x, int n, int H, int W, int Ce,
+                                                           const float *__restrict__ w, const float *__restrict__ bias,
+                                                           float *__restrict__ y) {
+    const int co = blockIdx.y * 256 + threadIdx.x;
+    if (co >= Ce) return;
+    const int g8 = (co >> 3) << 3;
+    float wr[72];
+#pragma unroll
+    for (int k = 0; k < 72; ++k) wr[k] = w[(int64_t)co * 72 + k];   // [ci][ky][kx]
+    const float b = bias[co];
+    const int64_t total = (int64_t)n * H * W;
+    for (int64_t p0 = (int64_t)blockIdx.x * kGcPix; p0 < total; p0 += (int64_t)gridDim.x * kGcPix) {
+        for (int pp = 0; pp < kGcPix && p0 + pp < total; ++pp) {
+            const int64_t pix = p0 + pp;
+            const int img = (int)(pix / (H * W));
+            const int rem = (int)(pix - (int64_t)img * H * W);
+            const int oy = rem / W, ox = rem - oy * W;
+            float acc = b;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy + ky - 1;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox + kx - 1;
+                    if (ix < 0 || ix >= W) continue;
+                    const float4 *s = reinterpret_cast<const float4 *>(x + (((int64_t)img * H + iy) * W + ix) * Ce + g8);
+                    const float4 v0 = s[0], v1 = s[1];
+                    const int t = ky * 3 + kx;
+                    acc = fmaf(v0.x, wr[0 * 9 + t], acc); acc = fmaf(v0.y, wr[1 * 9 + t], acc);
+                    acc = fmaf(v0.z, wr[2 * 9 + t], acc); acc = fmaf(v0.w, wr[3 * 9 + t], acc);
+                    acc = fmaf(v1.x, wr[4 * 9 + t], acc); acc = fmaf(v1.y, wr[5 * 9 + t], acc);
+                    acc = fmaf(v1.z, wr[6 * 9 + t], acc); acc = fmaf(v1.w, wr[7 * 9 + t], acc);
+                }
+            }
+            y[pix * Ce + co] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));   // nn.GELU() (erf form)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ head helpers
+// nn.PixelShuffle(2) on NHWC: out[n, y, x, c] = in[n, y/2, x/2, c*4 + (y%2)*2 + (x%2)]
+__global__ __launch_bounds__(256) void k_pixel_shuffle2(const float *__restrict__ x, int n, int H, int W, int C,
+                                                        float *__restrict__ y, int64_t ldy) {
+    const int Co = C / 4;
+    const int64_t total = (int64_t)n * 2 * H * 2 * W * Co;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Co);
+        int64_t p = i / Co;
+        const int ox = (int)(p % (2 * W)); p /= 2 * W;
+        const int oy = (int)(p % (2 * H));
+        const int img = (int)(p / (2 * H));
+        y[(((int64_t)img * 2 * H + oy) * 2 * W + ox) * ldy + c] =
+            x[(((int64_t)img * H + (oy >> 1)) * W + (ox >> 1)) * C + c * 4 + (oy & 1) * 2 + (ox & 1)];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_meta_fill(float *__restrict__ x517, int64_t rows, int ld, const float *__restrict__ desvel,
+                                                   const float *__restrict__ quat) {
+    const int pad = ld - 512;
+    const int64_t total = rows * pad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / pad;
+        const int c = (int)(i - r * pad);
+        float v = 0.f;
+        if (c == 0) v = desvel[r] / 10.0f;                                  // vitfly_models.py:144  X[1]/10
+        else if (c <= 4) v = quat ? quat[r * 4 + c - 1] : (c == 1 ? 1.f : 0.f);   // :24-25 default [1,0,0,0]
+        x517[r * ld + 512 + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ nn.LSTM + fc
+// One block per stream, 512 threads = the 4*128 gate rows. torch.nn.LSTM gate order i, f, g, o.
+__global__ __launch_bounds__(512) void k_lstm(const float *__restrict__ xg0, int T, LstmWeights w, float *__restrict__ h_state,
+                                              float *__restrict__ c_state, float *__restrict__ vel) {
+    __shared__ float h[3][128], c[3][128], gates[512];
+    const int s = blockIdx.x, j = threadIdx.x;
+    if (j < 384) {
+        h[j >> 7][j & 127] = h_state ? h_state[(int64_t)s * 384 + j] : 0.f;
+        c[j >> 7][j & 127] = c_state ? c_state[(int64_t)s * 384 + j] : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int64_t row = (int64_t)s * T + t;
+#pragma unroll 1
+        for (int l = 0; l < 3; ++l) {
+            float g;
+            if (l == 0) g = xg0[row * 512 + j];
+            else {
+                g = w.bias[l][j];
+                const float *wi = w.wih_t[l];
+                for (int k = 0; k < 128; ++k) g = fmaf(wi[k * 512 + j], h[l - 1][k], g);
+            }
+            const float *wh = w.whh_t[l];
+            for (int k = 0; k < 128; ++k) g = fmaf(wh[k * 512 + j], h[l][k], g);
+            gates[j] = g;
+            __syncthreads();
+            if (j < 128) {
+                const float gi = sigmoidf_(gates[j]), gf = sigmoidf_(gates[128 + j]);
+                const float gg = tanhf(gates[256 + j]), go = sigmoidf_(gates[384 + j]);
+                const float cn = gf * c[l][j] + gi * gg;
+                c[l][j] = cn;
+                h[l][j] = go * tanhf(cn);
+            }
+            __syncthreads();
+        }
+        if (j < 3) {
+            float v = w.fc_b[j];
+            for (int k = 0; k < 128; ++k) v = fmaf(w.fc_w[j * 128 + k], h[2][k], v);
+            vel[row * 3 + j] = v;
+        }
+    }
+    __syncthreads();
+    if (j < 384) {
+        if (h_state) h_state[(int64_t)s * 384 + j] = h[j >> 7][j & 127];
+        if (c_state) c_state[(int64_t)s * 384 + j] = c[j >> 7][j & 127];
+    }
+}
+
+}  // namespace
+
+// ============================================================================ launchers
+int launch_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff,
+               const float *w_packed, const float *bias, float *y, hipStream_t st) {
+    EVFLY_REQUIRE(cin == 1 || cin == 2, "e11: cin must be 1 or 2 (got %d)", cin);
+    const int64_t work = (int64_t)n * (H - 2) * (W - 2) * 4;
+    const int grid = grid_for(work, 256);
+    if (cin == 1)
+        hipLaunchKernelGGL(k_e11<1>, dim3(grid), dim3(256), 0, st, frames, n, H, W, form_bev, apply_form, cutoff, w_packed, bias, y);
+    else
+        hipLaunchKernelGGL(k_e11<2>, dim3(grid), dim3(256), 0, st, frames, n, H, W, form_bev, apply_form, cutoff, w_packed, bias, y);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_maxpool2x2(const float *x, int n, int H, int W, int C, float *y, hipStream_t st) {
+    EVFLY_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
+    const int64_t work = (int64_t)n * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(k_maxpool2x2, dim3(grid_for(work, 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(x), n, H, W,
+                       C / 4, reinterpret_cast<float4 *>(y));
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, float *y, int Ho, int Wo, int64_t ldy,
+                    int align_corners, int pre, hipStream_t st) {
+    // area_pixel_compute_scale<float>
+    float sh, sw;
+    if (align_corners) {
+        sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+        sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    } else {
+        sh = (float)Hi / (float)Ho;
+        sw = (float)Wi / (float)Wo;
+    }
+    if (C % 4 == 0) {
+        const int64_t work = (int64_t)n * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL(k_bilinear<4>, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy,
+                           align_corners, pre, sh, sw);
+    } else {
+        const int64_t work = (int64_t)n * Ho * Wo * C;
+        hipLaunchKernelGGL(k_bilinear<1>, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy,
+                           align_corners, pre, sh, sw);
+    }
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_crop(const float *x, int n, int Hi, int Wi, int C, int top, int left, float *y, int Ho, int Wo, int64_t ldy,
+                hipStream_t st) {
+    EVFLY_REQUIRE(C % 4 == 0 && ldy % 4 == 0, "crop: C %% 4");
+    const int64_t work = (int64_t)n * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(k_crop, dim3(grid_for(work, 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(x), n, Hi, Wi,
+                       C / 4, top, left, reinterpret_cast<float4 *>(y), Ho, Wo, ldy / 4);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, float *h_copy, int rpi,
+                          int64_t copy_img_rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_convlstm_gates, dim3(grid_for(rows * hid, 256)), dim3(256), 0, st, z, rows, hid, c, h, h_copy, rpi,
+                       copy_img_rows);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_dot_out(const float *x, int64_t rows, int C, const float *w, const float *bias, float *y, hipStream_t st) {
+    EVFLY_REQUIRE(C % 4 == 0, "dot_out: C %% 4");
+    hipLaunchKernelGGL(k_dot_out, dim3(grid_for(rows, 256)), dim3(256), 0, st, x, rows, C, w, bias, y);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_layernorm(const float *a, const float *b, int64_t rows, int C, const float *gamma, const float *beta, float *y,
+                     hipStream_t st) {
+    EVFLY_REQUIRE(C <= 512, "layernorm: C > 512");
+    hipLaunchKernelGGL(k_layernorm, dim3(grid_for(rows * 64, 256)), dim3(256), 0, st, a, b, rows, C, gamma, beta, y);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_attention(const float *q, const float *kv, int frames, int N, int nkv, int C, int heads, float *out,
+                     hipStream_t st) {
+    EVFLY_REQUIRE(C / heads == 32 && C % heads == 0, "attention: head dim must be 32 (C=%d heads=%d)", C, heads);
+    EVFLY_REQUIRE(nkv >= 1 && nkv <= kMaxKV, "attention: %d reduced keys (max %d)", nkv, kMaxKV);
+    hipLaunchKernelGGL(k_attention, dim3(grid_for((int64_t)frames * N * heads, 256)), dim3(256), 0, st, q, kv, frames, N, nkv,
+                       C, heads, out);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_grouped_conv_gelu(const float *x, int n, int H, int W, int Ce, const float *w, const float *bias, float *y,
+                             hipStream_t st) {
+    EVFLY_REQUIRE(Ce % 8 == 0, "grouped conv: Ce %% 8");
+    const int64_t strips = cdiv((int64_t)n * H * W, kGcPix);
+    const dim3 grid((unsigned)std::min<int64_t>(strips, 4 * kNumCU), cdiv(Ce, 256));
+    hipLaunchKernelGGL(k_grouped_conv_gelu, grid, dim3(256), 0, st, x, n, H, W, Ce, w, bias, y);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st) {
+    EVFLY_REQUIRE(C % 4 == 0, "pixel_shuffle: C %% 4");
+    hipLaunchKernelGGL(k_pixel_shuffle2, dim3(grid_for((int64_t)n * H * W * C, 256)), dim3(256), 0, st, x, n, H, W, C, y, ldy);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_meta_fill(float *x517, int64_t rows, int ld, const float *desvel, const float *quat, hipStream_t st) {
+    hipLaunchKernelGGL(k_meta_fill, dim3(grid_for(rows * (ld - 512), 256)), dim3(256), 0, st, x517, rows, ld, desvel, quat);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_lstm(const float *xg0, int n_streams, int T, LstmWeights w, float *h_state, float *c_state, float *vel,
+                hipStream_t st) {
+    hipLaunchKernelGGL(k_lstm, dim3(n_streams), dim3(512), 0, st, xg0, T, w, h_state, c_state, vel);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace evfly

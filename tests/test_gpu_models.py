@@ -1,0 +1,253 @@
+"""GPU parity: the HIP depth / velocity models vs the golden fixtures (generated from the reference)
+and the CPU oracle. Bar from BASELINE.json north_star: depth / velocity within 1e-3 relative in
+fp32; the fp32-MFMA path is held to a tighter 1e-4 here so a wrong kernel cannot hide."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from evfly_amd import synthetic as syn
+from oracle import models as om
+
+from _util import cond_frames, filled_sd, golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # fp32 path (north-star bar: 1e-3)
+TOL_BF16 = 3e-2     # bf16-operand MFMA path vs the fp32 oracle (separate looser bound)
+
+
+def _unet(dev, **kw):
+    import evfly_amd.learner_models as lm
+    base = dict(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346], velpred=0,
+                form_BEV=2, evs_min_cutoff=0.15, skip_type="interp", logger=lambda *a: None)
+    base.update(kw)
+    m = lm.OrigUNet(**base)
+    sd = syn.fill_state_dict(m.state_dict(), "origunet.")
+    m.load_state_dict(sd)
+    return m.to(dev).float().eval(), sd
+
+
+# ------------------------------------------------------------------ the GEMM kernel on its own
+@pytest.mark.parametrize("shape", [
+    # n, h, w, cin, cout, k, stride, pad
+    (2, 20, 23, 32, 32, 3, 1, 0),      # e12-like, N = 32 tile
+    (1, 17, 19, 64, 64, 3, 1, 0),      # N = 64 tile
+    (1, 12, 17, 256, 512, 3, 1, 0),    # 128x128 tile, deep K
+    (3, 15, 23, 32, 64, 3, 2, 1),      # stride 2 + padding (ViT stage-2 patch embed)
+    (2, 15, 23, 32, 32, 8, 8, 0),      # reduction conv k = s = 8
+    (5, 1, 1, 4608, 512, 1, 1, 0),     # Linear 4608 -> 512, M = 5
+    (1, 8, 13, 512, 2048, 1, 1, 0),    # ConvLSTM 1x1
+    (1, 9, 9, 32, 12, 3, 1, 1),        # N = 12 (masked columns)
+])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_kernel_vs_torch(gpu_device, shape, dtype):
+    from evfly_amd import _lib
+    n, h, w, cin, cout, k, s, p = shape
+    rs = np.random.RandomState(sum(shape))
+    x = torch.from_numpy(rs.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rs.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(cout).astype(np.float32))
+    want = F.relu(F.conv2d(x, wt, b, stride=s, padding=p))
+    xg = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+    wg = wt.permute(0, 2, 3, 1).contiguous().to(gpu_device)          # asymmetric, [O][kh][kw][I]
+    bg = b.to(gpu_device)
+    oh, ow = want.shape[-2:]
+    y = torch.empty(n, oh, ow, cout, device=gpu_device)
+    L = _lib.lib()
+    _lib.check(L.evfly_op_conv2d_nhwc(_lib.ptr(xg), n, h, w, cin, _lib.ptr(wg), _lib.ptr(bg), cout, k, k, s, p, 1, None,
+                                      _lib.ptr(y), 0 if dtype == "f32" else 1, _lib.cur_stream()))
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, want) < (2e-5 if dtype == "f32" else 2e-2)
+
+
+# ------------------------------------------------------------------ G4 Mix-Transformer stages
+def test_mix_stages_vs_golden(gpu_device):
+    from evfly_amd.ViTsubmodules import MixTransformerEncoderLayer
+    g = golden("g4_mixstage")
+    rs = np.random.RandomState(40)
+    x1 = torch.from_numpy(rs.rand(2, 1, 60, 90).astype(np.float32))
+    st1 = MixTransformerEncoderLayer(1, 32, patch_size=7, stride=4, padding=3, n_layers=2, reduction_ratio=8, num_heads=1,
+                                     expansion_factor=8)
+    st1.load_state_dict(syn.fill_state_dict(st1.state_dict(), "vitfly_vitlstm.encoder_blocks.0."))
+    y1 = st1.to(gpu_device)(x1.to(gpu_device))
+    x2 = torch.from_numpy(rs.standard_normal((2, 32, 15, 23)).astype(np.float32))
+    st2 = MixTransformerEncoderLayer(32, 64, patch_size=3, stride=2, padding=1, n_layers=2, reduction_ratio=4, num_heads=2,
+                                     expansion_factor=8)
+    st2.load_state_dict(syn.fill_state_dict(st2.state_dict(), "vitfly_vitlstm.encoder_blocks.1."))
+    y2 = st2.to(gpu_device)(x2.to(gpu_device))
+    assert y1.shape == (2, 32, 15, 23) and y2.shape == (2, 64, 8, 12)
+    assert rel_err(y1.cpu(), g["y1"]) < TOL and rel_err(y2.cpu(), g["y2"]) < TOL
+
+
+# ------------------------------------------------------------------ G5 LSTMNetVIT / ViT
+def test_lstmnetvit_vs_golden(gpu_device):
+    import evfly_amd.vitfly_models as vm
+    g = golden("g5_vit")
+    rs = np.random.RandomState(50)
+    img = torch.from_numpy(rs.rand(4, 1, 60, 90).astype(np.float32)).to(gpu_device)
+    desvel = torch.tensor([[4.0], [3.0], [5.0], [4.0]], device=gpu_device)
+    net = vm.LSTMNetVIT()
+    net.load_state_dict(syn.fill_state_dict(net.state_dict(), "vitfly_vitlstm."))
+    net = net.to(gpu_device).eval()
+    v, (h, c) = net([img.clone(), desvel.clone(), None])
+    assert h.shape == (3, 128)
+    assert rel_err(v.cpu(), g["lstm_seq_vel"]) < TOL and rel_err(h.cpu(), g["lstm_seq_h"]) < TOL
+    assert rel_err(c.cpu(), g["lstm_seq_c"]) < TOL
+    vi = torch.cat([net([img[i:i + 1].clone(), desvel[i:i + 1].clone(), None])[0] for i in range(4)])
+    assert rel_err(vi.cpu(), g["lstm_ind_vel"]) < TOL
+    # the same four frames as four independent 1-step streams in ONE call
+    vs, _ = net.forward_streams([img.clone(), desvel.clone(), None], n_streams=4, T=1)
+    assert rel_err(vs.cpu(), g["lstm_ind_vel"]) < TOL
+    quat = torch.from_numpy(rs.standard_normal((4, 4)).astype(np.float32)).to(gpu_device)
+    va, st = net([img[:2].clone(), desvel[:2].clone(), quat[:2].clone()])
+    vb, st2 = net([img[2:].clone(), desvel[2:].clone(), quat[2:].clone(), st])
+    assert rel_err(torch.cat([va, vb]).cpu(), g["lstm_state_vel"]) < TOL and rel_err(st2[0].cpu(), g["lstm_state_h"]) < TOL
+    big = torch.from_numpy(rs.rand(2, 1, 260, 346).astype(np.float32)).to(gpu_device)
+    assert rel_err(net([big, desvel[:2].clone(), None])[0].cpu(), g["lstm_resize_vel"]) < TOL
+    # CPU tensors in -> CPU tensors out (device staging like run.py:247,267)
+    vc, (hc, _) = net([img.cpu(), desvel.cpu(), None])
+    assert not vc.is_cuda and not hc.is_cuda and rel_err(vc, g["lstm_seq_vel"]) < TOL
+
+
+def test_vit_fc_head_vs_golden(gpu_device):
+    import evfly_amd.vitfly_models as vm
+    g = golden("g5_vit")
+    rs = np.random.RandomState(50)
+    img = torch.from_numpy(rs.rand(4, 1, 60, 90).astype(np.float32)).to(gpu_device)
+    desvel = torch.tensor([[4.0], [3.0], [5.0], [4.0]], device=gpu_device)
+    vit = vm.ViT()
+    vit.load_state_dict(syn.fill_state_dict(vit.state_dict(), "vit."))
+    v, h = vit.to(gpu_device).eval()([img, desvel, None])
+    assert h is None and rel_err(v.cpu(), g["vit_vel"]) < TOL
+
+
+# ------------------------------------------------------------------ G7 OrigUNet (+ G6 ConvLSTM through its taps)
+@pytest.mark.parametrize("tag,kw", [("interp_bev2", dict(skip_type="interp", form_BEV=2)),
+                                    ("crop_bev2", dict(skip_type="crop", form_BEV=2)),
+                                    ("interp_bev0", dict(skip_type="interp", form_BEV=0)),
+                                    ("interp_bev1", dict(skip_type="interp", form_BEV=1))])
+def test_origunet_vs_golden(gpu_device, tag, kw):
+    g = golden("g7_origunet")
+    net, sd = _unet(gpu_device, **kw)
+    x = cond_frames(70, 2)
+    xin = x.clone().to(gpu_device)
+    y_vel, (y_interp, y_upconv, (h_unet, h_vp)) = net([xin, None, None])
+    assert y_interp.shape == (2, 1, 260, 346) and y_upconv.shape == (2, 1, 68, 148) and h_vp is None
+    assert rel_err(y_upconv.cpu(), g[f"{tag}_upconv"]) < TOL
+    if tag == "interp_bev2":
+        assert rel_err(y_interp.cpu(), g[f"{tag}_depth"]) < TOL
+        assert h_unet[0][0].shape == (1, 512, 8, 13)
+        assert rel_err(h_unet[0][0].cpu(), g[f"{tag}_h"]) < TOL and rel_err(h_unet[0][1].cpu(), g[f"{tag}_c"]) < TOL
+        assert np.array_equal(y_vel.numpy(), g[f"{tag}_vel"])
+        # per-layer taps against the oracle (localises a wrong kernel)
+        (_, taps) = om.origunet_forward(sd, x, None, return_taps=True, **kw)
+        hh = net.hip()
+        for name, key in (("e5", "y_e5_pre"), ("e5_lstm", "y_e5"), ("d1", "y_d1"), ("d2", "y_d2"), ("d3", "y_d3"),
+                          ("d4", "y_d4")):
+            got = hh.tap(name).permute(0, 3, 1, 2)
+            assert rel_err(got, taps[key]) < TOL, name
+    else:
+        want = float(g[f"{tag}_depth_sum"])
+        assert abs(y_interp.double().sum().item() - want) < 1e-4 * abs(want)
+
+
+def test_origunet_norec_and_statefulness(gpu_device):
+    g = golden("g7_origunet")
+    net, sd = _unet(gpu_device, num_recurrent=[0, 0])
+    x = cond_frames(70, 2).to(gpu_device)
+    _, (_, y_upconv, (h, _)) = net([x, None, None])
+    assert h is None and rel_err(y_upconv.cpu(), g["norec_upconv"]) < TOL
+    # recurrent: [frame0] then [frame1] with the carried state == both frames in one call
+    net, sd = _unet(gpu_device)
+    _, (_, up01, (st01, _)) = net([x.clone(), None, None])
+    _, (_, up0, (st0, _)) = net([x[:1].clone(), None, None])
+    _, (_, up1, (st1, _)) = net([x[1:].clone(), None, (st0, None)])
+    assert rel_err(torch.cat([up0, up1]).cpu(), up01.cpu()) < 1e-6
+    assert rel_err(st1[0][1].cpu(), st01[0][1].cpu()) < 1e-6
+
+
+# ------------------------------------------------------------------ G8 composite, run.py pattern
+def _composite(dev, dtype="f32"):
+    import evfly_amd.learner_models as lm
+    m = lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
+                                     input_shape=[1, 1, 260, 346], velpred=0, enc_params={}, dec_params={}, fc_params={},
+                                     form_BEV=2, evs_min_cutoff=0.15, skip_type="interp", is_deployment=False,
+                                     logger=lambda *a: None)
+    sd = syn.fill_state_dict(m.state_dict())
+    m.load_state_dict(sd)
+    m.set_compute_dtype(dtype)
+    return m.to(dev).float().eval(), sd
+
+
+def test_composite_stateful_vs_golden(gpu_device):
+    g = golden("g8_composite")
+    net, sd = _composite(gpu_device)
+    x = cond_frames(80, 3).to(gpu_device)
+    desvel = torch.tensor([[4.0]], device=gpu_device)
+    h_unet, h_vit = None, None
+    vels, ups = [], []
+    for i in range(3):                                                # evfly_ros/run.py:259-262
+        v, (d, up, ((h_unet, _), h_vit)) = net([x[i:i + 1].clone(), desvel, [h_unet, None], h_vit])
+        vels.append(v); ups.append(up)
+        assert abs(d.double().sum().item() - g["depth_sum"][i]) < 1e-4 * abs(g["depth_sum"][i])
+    assert rel_err(torch.cat(vels).cpu(), g["vel"]) < TOL and rel_err(torch.cat(ups).cpu(), g["upconv"]) < TOL
+    assert rel_err(d.cpu(), g["depth_last"]) < TOL
+    assert rel_err(h_vit[0].cpu(), g["lstm_h"]) < TOL and rel_err(h_vit[1].cpu(), g["lstm_c"]) < TOL
+    v3, _ = net([x.clone(), desvel.repeat(3, 1), [None, None], None])
+    assert rel_err(v3.cpu(), g["vel_batch"]) < TOL
+
+
+def test_composite_checkpoint_loading_paths(gpu_device):
+    """run.py:150-167: per-sub-module load_state_dict must refresh the native weights."""
+    net, sd = _composite(gpu_device)
+    x = cond_frames(80, 1).to(gpu_device)
+    desvel = torch.tensor([[4.0]], device=gpu_device)
+    v0, _ = net([x.clone(), desvel, [None, None], None])
+    sd_un = {k[len("origunet."):]: v * 1.01 for k, v in sd.items() if k.startswith("origunet.")}
+    net.origunet.load_state_dict(sd_un)
+    v1, _ = net([x.clone(), desvel, [None, None], None])
+    assert not torch.equal(v0, v1)
+    net.origunet.load_state_dict({k[len("origunet."):]: v for k, v in sd.items() if k.startswith("origunet.")})
+    v2, _ = net([x.clone(), desvel, [None, None], None])
+    assert torch.equal(v0, v2)
+
+
+def test_multi_stream_matches_per_stream_oracle(gpu_device):
+    """The throughput entry (streams batched, batch-as-time inside each) == every stream run alone."""
+    net, sd = _composite(gpu_device)
+    S, T = 3, 2
+    x = cond_frames(90, S * T)
+    desvel = torch.full((S * T, 1), 4.0)
+    v, (d, up, ((hu, _), (lh, lc))) = net.forward_streams([x.to(gpu_device), desvel.to(gpu_device), [None, None], None], S, T)
+    v_ref, d_ref = om.composite_streams(sd, x, desvel, S, T)
+    assert rel_err(v.cpu(), v_ref) < TOL and rel_err(d.cpu(), d_ref) < TOL
+    assert hu[0][0].shape == (S, 512, 8, 13) and lh.shape == (S, 3, 128)
+    # and the streams really are independent: permuting streams permutes outputs
+    perm = [2, 0, 1]
+    xp = x.reshape(S, T, 1, 260, 346)[perm].reshape(S * T, 1, 260, 346)
+    vp, _ = net.forward_streams([xp.to(gpu_device), desvel.to(gpu_device), [None, None], None], S, T)
+    assert rel_err(vp.reshape(S, T, 3).cpu(), v.reshape(S, T, 3)[perm].cpu()) < 1e-6
+
+
+def test_composite_bf16_mfma(gpu_device):
+    """bf16-operand MFMA path (BASELINE configs C3/C5) against the fp32 oracle, looser bound."""
+    net, sd = _composite(gpu_device, "bf16")
+    x = cond_frames(80, 2)
+    desvel = torch.full((2, 1), 4.0)
+    v, (d, _, _) = net([x.to(gpu_device), desvel.to(gpu_device), [None, None], None])
+    v_ref, (d_ref, _, _) = om.composite_forward(sd, [x, desvel, [None, None], None])
+    assert rel_err(d.cpu(), d_ref) < TOL_BF16 and rel_err(v.cpu(), v_ref) < TOL_BF16
+
+
+def test_errors_are_loud(gpu_device):
+    import evfly_amd.learner_models as lm
+    with pytest.raises(ValueError):
+        lm.OrigUNet(form_BEV=3, num_recurrent=[0, 0], input_shape=[1, 1, 260, 346])
+    with pytest.raises(ValueError):
+        lm.OrigUNet(form_BEV=2, num_recurrent=[0, 0], input_shape=[1, 1, 260, 346], skip_type="nope")
+    net, _ = _unet(gpu_device)
+    sd = net.state_dict()
+    sd.pop("unet_e22.bias")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(sd)                                      # torch's own missing-key error
