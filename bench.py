@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: event-frames/s of the event -> frame -> depth -> velocity hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the whole path over one batch of synthetic event streams that are already
+resident in HBM: voxelize (B streams x T windows) -> q97 conditioning -> OrigUNet + ConvLSTM (depth)
+-> LSTMNetVIT (velocity), batch-as-time inside every stream. Workload = BASELINE.json
+configs[1] ("C2"): B = 64 streams, T = 5 windows, 260x346, 60 000 events / window, fp32, the
+reference-size ("tiny") Mix-Transformer. With N GPUs every rank runs its own B streams (weak
+scaling, no data-path collective) and the ranks all_gather their velocity rows over RCCL.
+
+Prints ONE JSON line (contract in the task brief) with two extra objects:
+  roofline     -- the dominant kernel (3x3 implicit-GEMM conv on the fp32 matrix cores), timed with HIP
+                  events on the launch stream inside the timed region (evfly_model_set_profiling)
+  cpu_baseline -- the CPU oracle (oracle/, a port) on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+H, W = 260, 346
+PEAK = {"f32": 157.3, "bf16": 2500.0}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=64, help="streams per GPU (C2: 64)")
+    ap.add_argument("--windows", type=int, default=5, help="time windows per stream (C2: 5)")
+    ap.add_argument("--events-per-window", type=int, default=60_000)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_model(dtype):
+    from evfly_amd import synthetic as syn
+    import evfly_amd.learner_models as lm
+    m = lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
+                                     input_shape=[1, 1, H, W], velpred=0, form_BEV=2, evs_min_cutoff=0.15,
+                                     skip_type="interp", logger=lambda *a: None)       # eval_config_real.txt
+    sd = syn.fill_state_dict(m.state_dict())
+    m.load_state_dict(sd)
+    m.set_compute_dtype(dtype)
+    return m.to("cuda").float().eval(), sd
+
+
+def cpu_baseline(sd, T, epw, budget_s):
+    """The oracle (CPU port of the reference path) on a bounded sample: streams of T windows through
+    C voxelizer port -> conditioning -> composite forward, all host cores torch may use."""
+    from evfly_amd import synthetic as syn
+    from oracle import accum as oaccum, conditioning as ocond, models as om, voxel as ovox
+    threads = torch.get_num_threads()
+    frames_done, t0, s = 0, time.perf_counter(), 0
+    while True:
+        ev, edges = syn.make_stream(10_000 + s, T, H, W, epw)
+        tt = time.perf_counter()
+        c = oaccum.window_counts_c(ev["x"], ev["y"], ev["t"], ev["p"], edges, H, W, 0)
+        fr = ovox.signed_frame(c[:, 0], c[:, 1]).astype(np.float32)[:, None]
+        x, _ = ocond.q97_normalize(fr)
+        with torch.no_grad():
+            om.composite_forward(sd, [x, torch.full((T, 1), 4.0), [None, None], None])
+        frames_done += T
+        s += 1
+        if s == 1:
+            t0 = tt            # do not charge the synthetic-event generation of the first stream
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(frames_done / dt, 3), "unit": "event-frames/s", "cores": threads, "kind": "port",
+            "sample": f"{s} stream(s) x {T} windows x {epw} events, 260x346, C voxelizer port + torch-CPU fp32 "
+                      f"oracle forward (batch-as-time), {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL over xGMI
+
+    from evfly_amd import synthetic as syn, voxelizer
+    from evfly_amd.distributed import gather_velocities
+    B, T = a.streams, a.windows
+    model, sd = build_model(a.dtype)
+    batch = syn.make_batch(B, T, H, W, a.events_per_window, first_stream=rank * B)
+    ev = voxelizer.upload_events(batch)
+    n_events = int(batch["offsets"][-1])
+    desvel = torch.full((B * T, 1), 4.0, device="cuda")                            # run.py:255
+    frames = torch.empty(B, T, H, W, device="cuda")
+    hip = model.hip()
+    L = hip._L
+
+    def step():
+        voxelizer.voxelize_windows(ev, H, W, out="f32", frames=frames)
+        x = voxelizer.condition_frames(frames.view(B * T, H, W))
+        vel, _ = model.forward_streams([x, desvel, [None, None], None], B, T)
+        return gather_velocities(vel, dist)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            vel_all = step()
+        L.evfly_model_profile_reset(hip.h)
+        L.evfly_model_set_profiling(hip.h, 1)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            vel_all = step()
+        sync()
+        dt = time.perf_counter() - t0
+        L.evfly_model_set_profiling(hip.h, 0)
+    if dist is not None:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert vel_all.shape == (world * B * T, 3) and torch.isfinite(vel_all).all()
+
+    # stage timings outside the timed region (torch events see the current stream, which is the one
+    # every evfly_amd launch uses)
+    def time_stage(fn, reps=5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    with torch.no_grad():
+        vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, H, W, out="f32", frames=frames))
+        cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, H, W)))
+    vox_bytes = 13.0 * n_events + 4.0 * B * T * H * W          # read events once, write frames once
+
+    prof = hip.profile()
+    dom = max(prof, key=lambda p: p["ms"])
+    frames_per_step = world * B * T
+    out = {
+        "metric": "event-frames/sec (260x346, 5 bins) event->depth->velocity fwd (voxelize + U-Net/ConvLSTM + ViT/LSTM)",
+        "value": round(frames_per_step * a.steps / dt, 2), "unit": "event-frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"C2: {B} streams x {T} windows per GPU, 260x346, {a.events_per_window} events/window, "
+                               f"OrigUNet+ConvLSTM -> LSTMNetVIT (reference-size ViT), batch-as-time per stream",
+                   "streams_per_gpu": B, "windows": T, "events_per_step_per_gpu": n_events,
+                   "parallelism": f"streams sharded x{world}, all_gather of velocities" if world > 1 else "single GPU"},
+    }
+    if rank == 0:
+        tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["flops"] else 0.0
+        if dom["flops"]:
+            out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(tfl, 2), "peak": PEAK[a.dtype],
+                               "unit": "TFLOP/s", "frac": round(tfl / PEAK[a.dtype], 4), "traffic": None,
+                               "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                               "flops_per_launch": dom["flops"] / dom["launches"]}
+        else:
+            gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                               "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4)}
+        model_ms = sum(p["ms"] for p in prof)
+        out["kernels"] = [{"name": p["name"], "ms_per_step": round(p["ms"] / a.steps, 3), "launches_per_step": p["launches"] // a.steps,
+                           "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2) if p["flops"] and p["ms"] else None,
+                           "gbs_algorithmic": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] else None}
+                          for p in sorted(prof, key=lambda p: -p["ms"])]
+        out["model_ms_per_step"] = round(model_ms / a.steps, 3)
+        out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_GBs_algorithmic": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
+                         "voxelize_frac_of_hbm_peak": round(vox_bytes / (vox_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms / a.steps, 3)}
+        mf = sum(p["flops"] for p in prof if p["flops"]) / a.steps
+        out["mfma_flops_per_frame"] = mf / (B * T)
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sd, T, a.events_per_window, a.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,50 @@
+"""world_size-2 gloo test of the N > 1 path (CPU): stream sharding + the velocity all_gather."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from _util import GOLDEN  # noqa: F401
+from evfly_amd.distributed import gather_velocities, shard_streams
+
+
+def _worker(rank, world, port, n_streams, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s0, s1 = shard_streams(n_streams, rank, world)
+    # velocity rows of this rank's streams: row value encodes (stream, t) so order is checkable
+    vel = torch.tensor([[s, t, s * 100 + t] for s in range(s0, s1) for t in range(T)], dtype=torch.float32).reshape(-1, 3)
+    out = gather_velocities(vel, dist)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_streams", [8, 7])          # even and ragged shards
+def test_shard_and_gather(n_streams):
+    world, T = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n_streams) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.tensor([[s, t, s * 100 + t] for s in range(n_streams) for t in range(T)], dtype=torch.float32)
+    for r in range(world):
+        assert torch.equal(outs[r], want)
+
+
+def test_shard_covers_all_streams():
+    for n in (1, 5, 64, 2048):
+        for w in (1, 2, 3, 8):
+            spans = [shard_streams(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
