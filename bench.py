@@ -155,7 +155,14 @@ def main():
         cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, H, W)))
     vox_bytes = 13.0 * n_events + 4.0 * B * T * H * W          # read events once, write frames once
 
-    prof = hip.profile()
+    layers = hip.profile()                         # per launch site ("family/layer")
+    fam = {}
+    for p in layers:
+        f = fam.setdefault(p["name"].split("/")[0],
+                           dict(name=p["name"].split("/")[0], ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        for k in ("ms", "flops", "bytes", "launches"):
+            f[k] += p[k]
+    prof = list(fam.values())
     dom = max(prof, key=lambda p: p["ms"])
     frames_per_step = world * B * T
     out = {
@@ -186,6 +193,9 @@ def main():
                            "gbs_algorithmic": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] else None}
                           for p in sorted(prof, key=lambda p: -p["ms"])]
         out["model_ms_per_step"] = round(model_ms / a.steps, 3)
+        out["conv_layers"] = [{"name": p["name"], "ms_per_step": round(p["ms"] / a.steps, 3),
+                               "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)}
+                              for p in layers if p["name"].startswith(dom["name"] + "/")]
         out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_GBs_algorithmic": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
                          "voxelize_frac_of_hbm_peak": round(vox_bytes / (vox_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms / a.steps, 3)}

@@ -353,7 +353,8 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     d.Nc = cout; d.res = res; d.ldres = ldres; d.act = act; d.y = y; d.ldy = ldy; d.dtype = m->cfg.compute_dtype;
     if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", wname.c_str());
     const double bytes = 4.0 * ((double)n * H * W * C + (double)d.M * cout + (double)cout * d.K);
-    RUN(m, pname, igemm_flops(d), bytes, igemm_launch(d, m->st));
+    const std::string pn = std::string(pname) + "/" + wname;   // family/layer: bench.py groups by family
+    RUN(m, pn.c_str(), igemm_flops(d), bytes, igemm_launch(d, m->st));
     return 0;
 }
 
