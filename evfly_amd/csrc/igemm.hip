@@ -29,6 +29,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-
     return (unsigned short)(u >> 16);
 }
 
+// component-wise select (a float4-level `c ? v : zero` makes hipcc select between ADDRESSES and
+// pushes the staging registers to scratch)
+__device__ __forceinline__ void keep_or_zero(float4 &v, bool keep) {
+    v.x = keep ? v.x : 0.f; v.y = keep ? v.y : 0.f; v.z = keep ? v.z : 0.f; v.w = keep ? v.w : 0.f;
+}
+
 template <bool BF16> struct LdsElem { using type = float; };
 template <> struct LdsElem<true> { using type = unsigned short; };
 
@@ -62,41 +68,63 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     const int wm = wv / WAVES_N, wn = wv % WAVES_N;
     const int lrow = tid >> 3, lchunk = tid & 7;                    // loader: row within 32, 16-B fp32 chunk
 
-    // ---- per-thread A row descriptors (fixed over the K loop)
-    int64_t a_base[PA];
+    // ---- per-thread A row descriptors (fixed over the K loop). 32-bit decode of the first row, the
+    // others follow incrementally (+32 pixels), so the prologue has one pair of integer divisions.
+    const float *a_ptr[PA];
     int a_iy[PA], a_ix[PA];
     bool a_ok[PA];
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        const int64_t m = m0 + lrow + 32 * p;
-        a_ok[p] = m < d.M;
-        const int64_t mm = a_ok[p] ? m : 0;
+    {
         const int ohw = d.OH * d.OW;
-        const int img = (int)(mm / ohw);
-        const int rem = (int)(mm - (int64_t)img * ohw);
-        const int oy = rem / d.OW, ox = rem - oy * d.OW;
-        a_iy[p] = oy * d.stride - d.pad;
-        a_ix[p] = ox * d.stride - d.pad;
-        a_base[p] = (((int64_t)img * d.H + a_iy[p]) * d.W + a_ix[p]) * d.ldx;
+        const int mfirst = (int)min(m0 + lrow, d.M - 1);
+        int img = mfirst / ohw;
+        int rem = mfirst - img * ohw;
+        int oy = rem / d.OW, ox = rem - oy * d.OW;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            a_ok[p] = m0 + lrow + 32 * p < d.M;
+            a_iy[p] = oy * d.stride - d.pad;
+            a_ix[p] = ox * d.stride - d.pad;
+            a_ptr[p] = d.x + (((int64_t)img * d.H + a_iy[p]) * d.W + a_ix[p]) * d.ldx + lchunk * 4;
+            if (a_ok[p] && m0 + lrow + 32 * (p + 1) < d.M) {   // advance 32 output pixels
+                ox += 32;
+                while (ox >= d.OW) { ox -= d.OW; if (++oy == d.OH) { oy = 0; ++img; } }
+            }
+        }
     }
     const bool padded = d.pad > 0;
+    const float *b_ptr[PB];
+    bool b_ok[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int n = n0 + lrow + 32 * p;
+        b_ok[p] = n < d.Nc;
+        b_ptr[p] = d.w + (int64_t)(b_ok[p] ? n : 0) * d.ldw + lchunk * 4;
+    }
 
+    // tap cursor of the NEXT load_tiles call (VEC mode): k0 = (tky*KW + tkx)*C + tc0
+    int tc0 = 0, tkx = 0, tky = 0;
+    unsigned a_mask = 0;   // rows of the staged A registers that are valid (zeroing happens at LDS-store time so
+                           // that no VALU op consumes the loads before the MFMA block: they stay in flight under it)
     float4 ra[PA], rb[PB];
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
         if (VEC) {   // C % 32 == 0: the whole K-step lies inside one (ky, kx) tap
-            const int tap = k0 / d.C, c0 = k0 - tap * d.C;
-            const int ky = tap / d.KW, kx = tap - ky * d.KW;
-            const int64_t toff = ((int64_t)ky * d.W + kx) * d.ldx + c0 + lchunk * 4;
+            const int64_t toff = ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
+            a_mask = 0;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 bool ok = a_ok[p];
                 if (padded) {
-                    const int iy = a_iy[p] + ky, ix = a_ix[p] + kx;
+                    const int iy = a_iy[p] + tky, ix = a_ix[p] + tkx;
                     ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
                 }
-                ra[p] = ok ? *reinterpret_cast<const float4 *>(d.x + a_base[p] + toff) : make_float4(0, 0, 0, 0);
+                // branch-free: masked rows read a valid dummy address and are zeroed by the select
+                const float *src = ok ? a_ptr[p] + toff : d.x;
+                ra[p] = *reinterpret_cast<const float4 *>(src);
+                a_mask |= (ok ? 1u : 0u) << p;
             }
+            tc0 += BK;
+            if (tc0 == d.C) { tc0 = 0; if (++tkx == d.KW) { tkx = 0; ++tky; } }
         } else {     // generic gather: any C / K (tiny layers only)
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -110,22 +138,24 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                         const int ky = tap / d.KW, kx = tap - ky * d.KW;
                         const int iy = a_iy[p] + ky, ix = a_ix[p] + kx;
                         if (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
-                            val = d.x[a_base[p] + ((int64_t)ky * d.W + kx) * d.ldx + c];
+                            val = a_ptr[p][((int64_t)ky * d.W + kx) * d.ldx + c - lchunk * 4];
                     }
                     v[e] = val;
                 }
                 ra[p] = make_float4(v[0], v[1], v[2], v[3]);
             }
+            a_mask = ~0u;
         }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {   // weights are zero padded along k to ldw (multiple of 32)
-            const int n = n0 + lrow + 32 * p;
-            rb[p] = n < d.Nc ? *reinterpret_cast<const float4 *>(d.w + (int64_t)n * d.ldw + k0 + lchunk * 4)
-                             : make_float4(0, 0, 0, 0);
-        }
+        for (int p = 0; p < PB; ++p)     // weights are zero padded along k to ldw (multiple of 32)
+            rb[p] = *reinterpret_cast<const float4 *>(b_ptr[p] + k0);
     };
     auto store_tiles = [&](int buf) {
         elem_t *as = As + buf * BM * BK, *bs = Bs + buf * BN * BK;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) keep_or_zero(ra[p], (a_mask >> p) & 1u);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) keep_or_zero(rb[p], b_ok[p]);
         if (BF16) {
             // 4 fp32 -> 4 bf16 = half a 16-B chunk (8 B store)
 #pragma unroll
@@ -216,41 +246,65 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int ncol0 = n0 + wn * WN + frow;
+    if (d.out_mode == OUT_UPCONV2X2) {
+        float bj[TN];
+        int64_t coloff[TN];
+        bool nok[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
+            const int n = ncol0 + j * 32;
+            nok[j] = n < d.Nc;
+            const int q = n / d.up_cout, co = n - q * d.up_cout;
+            bj[j] = (d.bias && nok[j]) ? d.bias[co] : 0.f;
+            coloff[j] = ((int64_t)(q >> 1) * (2 * d.OW) + (q & 1)) * d.ldy + co;
+        }
+        const int hw = d.OH * d.OW;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const int64_t m = m0 + row;
-            if (m >= d.M) continue;
-            int64_t orow = m;
-            if (d.out_mode == OUT_UPCONV2X2) {
-                const int hw = d.OH * d.OW;
-                const int img = (int)(m / hw);
-                const int rem = (int)(m - (int64_t)img * hw);
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= d.M) continue;
+                const int mi = (int)m;
+                const int img = mi / hw, rem = mi - img * hw;
                 const int iy = rem / d.OW, ix = rem - iy * d.OW;
-                orow = ((int64_t)img * 2 * d.OH + 2 * iy) * (2 * d.OW) + 2 * ix;   // (dy, dx) added per column
-            }
+                float *yr = d.y + (((int64_t)img * 2 * d.OH + 2 * iy) * (2 * d.OW) + 2 * ix) * d.ldy;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 32 + frow;
-                if (n >= d.Nc) continue;
-                float v = acc[i][j][r];
-                if (d.out_mode == OUT_UPCONV2X2) {
-                    const int q = n / d.up_cout, co = n - q * d.up_cout;
-                    if (d.bias) v += d.bias[co];
-                    const int64_t o = orow + (int64_t)(q >> 1) * (2 * d.OW) + (q & 1);
-                    d.y[o * d.ldy + co] = v;
-                } else {
-                    if (d.bias) v += d.bias[n];
-                    if (d.res) {
-                        int64_t rr = m;
-                        if (d.res_rpi > 0) { const int64_t g = m / d.res_rpi; rr = g * d.res_img_rows + (m - g * d.res_rpi); }
-                        v += d.res[rr * d.ldres + n];
-                    }
+                for (int j = 0; j < TN; ++j)
+                    if (nok[j]) yr[coloff[j]] = acc[i][j][r] + bj[j];
+            }
+        }
+    } else {
+        float bj[TN];
+        bool nok[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = ncol0 + j * 32;
+            nok[j] = n < d.Nc;
+            bj[j] = (d.bias && nok[j]) ? d.bias[n] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= d.M) continue;
+                float *yr = d.y + m * d.ldy + ncol0;
+                const float *rr = nullptr;
+                if (d.res) {
+                    int64_t rrow = m;
+                    if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
+                    rr = d.res + rrow * d.ldres + ncol0;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!nok[j]) continue;
+                    float v = acc[i][j][r] + bj[j];
+                    if (rr) v += rr[j * 32];
                     if (d.act == ACT_RELU) v = v > 0.f ? v : 0.f;
                     else if (d.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                    d.y[m * d.ldy + n] = v;
+                    yr[j * 32] = v;
                 }
             }
         }
@@ -288,6 +342,7 @@ int igemm_launch(const ConvDesc &d, hipStream_t st) {
     EVFLY_REQUIRE(d.ldw % BK == 0 && d.ldw >= d.K, "igemm: weights must be zero padded to a multiple of 32 (ldw=%d K=%d)",
                   d.ldw, d.K);
     EVFLY_REQUIRE(((uintptr_t)d.w) % 16 == 0, "igemm: weights not 16-byte aligned");
+    EVFLY_REQUIRE(d.M < (int64_t)1 << 31, "igemm: more than 2^31 output pixels in one launch");
     EVFLY_REQUIRE(d.out_mode == OUT_ROWS || (d.up_cout > 0 && d.Nc == 4 * d.up_cout && !d.res && d.act == ACT_NONE),
                   "igemm: bad upconv epilogue");
     const bool vec = d.C % BK == 0 && d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0;
