@@ -33,6 +33,7 @@ struct ConvDesc {
     int out_mode = OUT_ROWS;
     int up_cout = 0;            // OUT_UPCONV2X2: n = (dy*2+dx)*up_cout + co, bias indexed by co
     int dtype = EVFLY_DTYPE_F32;
+    const float *zeros = nullptr;   // >= 16 B of zeros in global memory (set by igemm_launch)
 };
 
 // Fills OH/OW/M/K from the geometry (conv arithmetic of torch.nn.Conv2d).
@@ -44,6 +45,13 @@ inline void conv_finish(ConvDesc &d) {
 }
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Position of weight element (tap = ky*KW + kx, channel c) along K. C % 32 == 0: chunk-major (the taps of a
+// 32-channel chunk are adjacent); otherwise tap-major (k = tap*C + c). The kernel walks K in this order.
+inline int conv_k_index(int tap, int c, int C, int ntaps) {
+    if (C % 32 == 0) return ((c / 32) * ntaps + tap) * 32 + c % 32;
+    return tap * C + c;
+}
 
 // Enqueue the GEMM on `st`. Returns 0 / negative (evfly_last_error).
 int igemm_launch(const ConvDesc &d, hipStream_t st);

@@ -14,6 +14,8 @@
 // shared by neighbouring pixel tiles are re-read from that XCD's L2, not from HBM.
 #include "igemm.h"
 
+#include <cstdlib>
+
 namespace evfly {
 namespace {
 
@@ -46,16 +48,16 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16>
-__global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, int cpx) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16, int NBUF>
+__global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, int cpx, int dbg) {
     using elem_t = typename LdsElem<BF16>::type;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM / 32, PB = BN / 32;   // rows each loader thread owns in the A / W tile
     static_assert(WAVES_M * WAVES_N == 4 && WM % 32 == 0 && WN % 32 == 0, "tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    elem_t *As = reinterpret_cast<elem_t *>(smem_raw);              // [2][BM][BK]
-    elem_t *Bs = As + 2 * BM * BK;                                  // [2][BN][BK]
+    elem_t *As = reinterpret_cast<elem_t *>(smem_raw);              // [NBUF][BM][BK]
+    elem_t *Bs = As + NBUF * BM * BK;                               // [NBUF][BN][BK]
 
     // ---- XCD-contiguous tile mapping (placement only affects speed)
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
@@ -67,6 +69,11 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WAVES_N, wn = wv % WAVES_N;
     const int lrow = tid >> 3, lchunk = tid & 7;                    // loader: row within 32, 16-B fp32 chunk
+    // DMA mode (fp32, C % 32 == 0): tiles go HBM/L2 -> LDS with global_load_lds (no staging registers, no
+    // ds_write, no select). The LDS image of a wave's instruction is lane-linear (8 rows x 128 B), so the
+    // XOR swizzle is applied on the SOURCE chunk and again on the fragment read (same involution).
+    constexpr bool DMA = VEC && !BF16 && NBUF == 2;
+    const int gchunk = DMA ? (lchunk ^ ((lrow >> 1) & 7)) : lchunk;
 
     // ---- per-thread A row descriptors (fixed over the K loop). 32-bit decode of the first row, the
     // others follow incrementally (+32 pixels), so the prologue has one pair of integer divisions.
@@ -75,7 +82,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     bool a_ok[PA];
     {
         const int ohw = d.OH * d.OW;
-        const int mfirst = (int)min(m0 + lrow, d.M - 1);
+        const int64_t m0a = dbg == 3 ? (int64_t)(mt % 16) * BM : m0;   // dbg 3: every block gathers from 16 hot tiles
+        const int mfirst = (int)min(m0a + lrow, d.M - 1);
         int img = mfirst / ohw;
         int rem = mfirst - img * ohw;
         int oy = rem / d.OW, ox = rem - oy * d.OW;
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             a_ok[p] = m0 + lrow + 32 * p < d.M;
             a_iy[p] = oy * d.stride - d.pad;
             a_ix[p] = ox * d.stride - d.pad;
-            a_ptr[p] = d.x + (((int64_t)img * d.H + a_iy[p]) * d.W + a_ix[p]) * d.ldx + lchunk * 4;
+            a_ptr[p] = d.x + (((int64_t)img * d.H + a_iy[p]) * d.W + a_ix[p]) * d.ldx + gchunk * 4;
             if (a_ok[p] && m0 + lrow + 32 * (p + 1) < d.M) {   // advance 32 output pixels
                 ox += 32;
                 while (ox >= d.OW) { ox -= d.OW; if (++oy == d.OH) { oy = 0; ++img; } }
@@ -98,10 +106,14 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     for (int p = 0; p < PB; ++p) {
         const int n = n0 + lrow + 32 * p;
         b_ok[p] = n < d.Nc;
-        b_ptr[p] = d.w + (int64_t)(b_ok[p] ? n : 0) * d.ldw + lchunk * 4;
+        b_ptr[p] = d.w + (int64_t)(b_ok[p] ? n : 0) * d.ldw + gchunk * 4;
     }
 
-    // tap cursor of the NEXT load_tiles call (VEC mode): k0 = (tky*KW + tkx)*C + tc0
+    // tap cursor of the NEXT tile load (VEC mode). K order when C % 32 == 0 is "chunk-major":
+    //   k = ((c / 32) * KH*KW + ky*KW + kx) * 32 + c % 32
+    // i.e. the 9 taps of one 32-channel chunk are consecutive K-steps, so the input bytes a block re-reads
+    // for neighbouring taps are still in the XCD's L2 (tap-major order spreads them over the whole K loop).
+    // Weights are packed in the same order (conv_k_index in igemm.h).
     int tc0 = 0, tkx = 0, tky = 0;
     unsigned a_mask = 0;   // rows of the staged A registers that are valid (zeroing happens at LDS-store time so
                            // that no VALU op consumes the loads before the MFMA block: they stay in flight under it)
@@ -123,8 +135,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 ra[p] = *reinterpret_cast<const float4 *>(src);
                 a_mask |= (ok ? 1u : 0u) << p;
             }
-            tc0 += BK;
-            if (tc0 == d.C) { tc0 = 0; if (++tkx == d.KW) { tkx = 0; ++tky; } }
+            if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } }   // taps fastest, channel chunk slowest
         } else {     // generic gather: any C / K (tiny layers only)
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -150,6 +161,51 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
         for (int p = 0; p < PB; ++p)     // weights are zero padded along k to ldw (multiple of 32)
             rb[p] = *reinterpret_cast<const float4 *>(b_ptr[p] + k0);
     };
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto dma_tiles = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        const int64_t toff = ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
+        float *as = reinterpret_cast<float *>(As) + buf * BM * BK + (wv * 8) * BK;
+        float *bs = reinterpret_cast<float *>(Bs) + buf * BN * BK + (wv * 8) * BK;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            bool ok = a_ok[p];
+            if (padded) {
+                const int iy = a_iy[p] + tky, ix = a_ix[p] + tkx;
+                ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            }
+            const float *src = ok ? a_ptr[p] + toff : d.zeros;    // masked rows copy 16 B of zeros
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(as + p * 32 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const float *src = b_ok[p] ? b_ptr[p] + k0 : d.zeros;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(bs + p * 32 * BK), 16, 0, 0);
+        }
+        if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } }
+    };
+    // one row group q of the next tile (q < PA: activations, else weights); used to spread the requests
+    // between the MFMAs of a K-step instead of issuing them as one burst
+    auto dma_one = [&](int q, int kt, int buf) {
+        if (q < PA) {
+            const int64_t toff = ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
+            float *as = reinterpret_cast<float *>(As) + buf * BM * BK + (wv * 8) * BK;
+            bool ok = a_ok[q];
+            if (padded) {
+                const int iy = a_iy[q] + tky, ix = a_ix[q] + tkx;
+                ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            }
+            const float *src = ok ? a_ptr[q] + toff : d.zeros;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(as + q * 32 * BK), 16, 0, 0);
+        } else {
+            const int p = q - PA;
+            float *bs = reinterpret_cast<float *>(Bs) + buf * BN * BK + (wv * 8) * BK;
+            const float *src = b_ok[p] ? b_ptr[p] + kt * BK : d.zeros;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(bs + p * 32 * BK), 16, 0, 0);
+        }
+    };
+    auto dma_advance = [&]() { if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } } };
     auto store_tiles = [&](int buf) {
         elem_t *as = As + buf * BM * BK, *bs = Bs + buf * BN * BK;
 #pragma unroll
@@ -193,15 +249,19 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     const int nk = (d.K + BK - 1) / BK;
     const int frow = lane & 31, fh = lane >> 5;
 
-    load_tiles(0);
-    store_tiles(0);
+    if (DMA) {
+        dma_tiles(0, 0);
+    } else {
+        load_tiles(0);
+        store_tiles(0);
+    }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles(kt + 1);
         const elem_t *as = As + cur * BM * BK + (wm * WM) * BK;
         const elem_t *bs = Bs + cur * BN * BK + (wn * WN) * BK;
         if (BF16) {
+            if (kt + 1 < nk) load_tiles(kt + 1);
             // lane half h supplies k = 16*s + 8*h .. +7 (chunk 2s+h) for MFMA step s
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -219,30 +279,62 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
+            // All fragment reads of the K-step are issued right after the barrier (registers are plentiful:
+            // the f32 MFMA is 64 cycles, so LDS latency, not bandwidth, is what must be covered), then the
+            // next tile's global loads, then 16 * TM * TN MFMAs back to back.
+            float4 a[4][TM], b[4][TN];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                float4 a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    a[i] = *reinterpret_cast<const float4 *>(as + lds_off<false>(i * 32 + frow, 2 * jj + fh));
+                    a[jj][i] = *reinterpret_cast<const float4 *>(as + lds_off<false>(i * 32 + frow, 2 * jj + fh));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(bs + lds_off<false>(j * 32 + frow, 2 * jj + fh));
+                    b[jj][j] = *reinterpret_cast<const float4 *>(bs + lds_off<false>(j * 32 + frow, 2 * jj + fh));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next tile is requested AFTER the fragment reads in program order: hipcc orders an LDS-DMA
+            // against every later ds_read with a vmcnt(0) (it cannot see that the buffers differ)
+            const bool more = kt + 1 < nk && dbg != 1;
+            if (!DMA && more) load_tiles(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // DMA mode: the PA + PB tile requests are spread between the MFMAs (one every STRIDE MFMAs). A
+            // vector-memory issue that has to queue behind the other waves' requests then stalls this wave
+            // while its previous MFMA is still executing, instead of delaying the whole MFMA burst.
+            constexpr int NMFMA = 16 * TM * TN, NREQ = PA + PB, STRIDE = NMFMA / NREQ;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
-                            const float bv = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
+                            const float av = e == 0 ? a[jj][i].x : e == 1 ? a[jj][i].y : e == 2 ? a[jj][i].z : a[jj][i].w;
+                            const float bv = e == 0 ? b[jj][j].x : e == 1 ? b[jj][j].y : e == 2 ? b[jj][j].z : b[jj][j].w;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                            const int idx = ((jj * 4 + e) * TM + i) * TN + j;
+                            if (DMA && idx % STRIDE == 1 && idx / STRIDE < NREQ) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (more) dma_one(idx / STRIDE, kt + 1, cur ^ 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
             }
+            if (DMA && more) dma_advance();
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (NBUF == 2) {
+            if (!DMA && kt + 1 < nk && dbg == 0) store_tiles(cur ^ 1);
+            // pin the barrier (and the vmcnt(0) hipcc attaches to it while an LDS-DMA is in flight) BELOW the
+            // MFMAs: they are register-only, so the scheduler would otherwise sink them under the barrier
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (dbg == 0 || DMA) cur ^= 1;
+        } else {   // one LDS buffer (half the LDS, one more resident block per CU): two barriers per K-step
+            __syncthreads();
+            if (kt + 1 < nk && dbg == 0) store_tiles(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -311,33 +403,59 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16, int NBUF>
 int launch_cfg(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv(d.M, BM), n_nt = cdiv(d.Nc, BN);
     const int cpx = cdiv(n_mt, kNumXCD);
-    const int lds = 2 * (BM + BN) * BK * (BF16 ? 2 : 4);
-    auto kern = k_igemm<BM, BN, WAVES_M, WAVES_N, VEC, BF16>;
+    const int lds = NBUF * (BM + BN) * BK * (BF16 ? 2 : 4);
+    auto kern = k_igemm<BM, BN, WAVES_M, WAVES_N, VEC, BF16, NBUF>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt), dim3(256), lds, st, d, n_mt, n_nt, cpx);
+    static const int dbg = getenv("EVFLY_IGEMM_DBG") ? atoi(getenv("EVFLY_IGEMM_DBG")) : 0;
+    hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt), dim3(256), lds, st, d, n_mt, n_nt, cpx, dbg);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
 
 template <bool VEC, bool BF16>
 int launch_by_n(const ConvDesc &d, hipStream_t st) {
-    if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, BF16>(d, st);
-    if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, BF16>(d, st);
-    return launch_cfg<256, 32, 4, 1, VEC, BF16>(d, st);
+    static const int nbuf = getenv("EVFLY_IGEMM_NBUF") ? atoi(getenv("EVFLY_IGEMM_NBUF")) : 2;
+    if (nbuf == 2) {
+        if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, BF16, 2>(d, st);
+        if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, BF16, 2>(d, st);
+        return launch_cfg<256, 32, 4, 1, VEC, BF16, 2>(d, st);
+    }
+    if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, BF16, 1>(d, st);
+    if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, BF16, 1>(d, st);
+    return launch_cfg<256, 32, 4, 1, VEC, BF16, 1>(d, st);
 }
 
 }  // namespace
 
-int igemm_launch(const ConvDesc &d, hipStream_t st) {
+namespace {
+int zero_page(const float **out) {
+    static const float *pages[64] = {};
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!pages[dev]) {
+        void *p = nullptr;
+        EVFLY_HIP(hipMalloc(&p, 256));
+        EVFLY_HIP(hipMemset(p, 0, 256));
+        pages[dev] = static_cast<const float *>(p);
+    }
+    *out = pages[dev];
+    return 0;
+}
+}  // namespace
+
+int igemm_launch(const ConvDesc &d_in, hipStream_t st) {
+    ConvDesc d = d_in;
+    if (int rc = zero_page(&d.zeros)) return rc;
     EVFLY_REQUIRE(d.x && d.w && d.y && d.M > 0 && d.Nc > 0 && d.K > 0, "igemm: empty problem");
     EVFLY_REQUIRE(d.ldw % BK == 0 && d.ldw >= d.K, "igemm: weights must be zero padded to a multiple of 32 (ldw=%d K=%d)",
                   d.ldw, d.K);
@@ -345,7 +463,8 @@ int igemm_launch(const ConvDesc &d, hipStream_t st) {
     EVFLY_REQUIRE(d.M < (int64_t)1 << 31, "igemm: more than 2^31 output pixels in one launch");
     EVFLY_REQUIRE(d.out_mode == OUT_ROWS || (d.up_cout > 0 && d.Nc == 4 * d.up_cout && !d.res && d.act == ACT_NONE),
                   "igemm: bad upconv epilogue");
-    const bool vec = d.C % BK == 0 && d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0;
+    const bool vec = d.C % BK == 0;   // decides the K order: the packer applies the same rule
+    EVFLY_REQUIRE(!vec || (d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0), "igemm: input not 16-byte aligned");
     const bool bf16 = d.dtype == EVFLY_DTYPE_BF16;
     if (vec) return bf16 ? launch_by_n<true, true>(d, st) : launch_by_n<true, false>(d, st);
     return bf16 ? launch_by_n<false, true>(d, st) : launch_by_n<false, false>(d, st);

@@ -167,7 +167,7 @@ int pack_conv(evfly_model *m, const char *prefix, const std::string &key, const 
         for (int i = 0; i < I; ++i)
             for (int y = 0; y < kh; ++y)
                 for (int x = 0; x < kw; ++x)
-                    dst[(size_t)o * ld + (y * kw + x) * I + i] = t->v[(((size_t)o * I + i) * kh + y) * kw + x];
+                    dst[(size_t)o * ld + conv_k_index(y * kw + x, i, I, kh * kw)] = t->v[(((size_t)o * I + i) * kh + y) * kw + x];
     m->wld[name] = ld;
     const HostTensor *b = m->find(key + ".bias", prefix);
     if (b) std::memcpy(m->stage(name + ".b", b->v.size()), b->v.data(), b->v.size() * 4);
@@ -793,6 +793,12 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
     d.KH = kh; d.KW = kw; d.stride = stride; d.pad = pad;
     conv_finish(d);
     EVFLY_REQUIRE(d.K % 32 == 0, "op_conv2d: kh*kw*cin must be a multiple of 32 (weights are [cout][kh][kw][cin] unpadded)");
+    if (cin % 32 == 0 && kh * kw > 1) {   // the kernel walks K chunk-major (igemm.h conv_k_index): permute a copy
+        void *scr = nullptr;
+        if (int rc = scratch_get((size_t)cout * d.K * 4, &scr)) return rc;
+        if (int rc = launch_repack_chunk_major(w_packed, cout, kh * kw, cin, static_cast<float *>(scr), as_stream(stream))) return rc;
+        d.w = static_cast<const float *>(scr);
+    }
     d.ldw = d.K; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
     return igemm_launch(d, as_stream(stream));
 }

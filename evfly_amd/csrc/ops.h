@@ -44,4 +44,7 @@ struct LstmWeights {
 int launch_lstm(const float *xg0 /*(S*T, 512)*/, int n_streams, int T, LstmWeights w, float *h_state, float *c_state,
                 float *vel, hipStream_t st);
 
+// [cout][tap][cin] -> chunk-major K order of igemm.h conv_k_index (cin % 32 == 0)
+int launch_repack_chunk_major(const float *w, int cout, int ntaps, int cin, float *out, hipStream_t st);
+
 }  // namespace evfly

@@ -404,9 +404,26 @@ __global__ __launch_bounds__(512) void k_lstm(const float *__restrict__ xg0, int
     }
 }
 
+__global__ __launch_bounds__(256) void k_repack_chunk_major(const float *__restrict__ w, int cout, int ntaps, int cin,
+                                                            float *__restrict__ out) {
+    const int K = ntaps * cin;
+    const int64_t total = (int64_t)cout * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int o = (int)(i / K), k = (int)(i - (int64_t)o * K);
+        const int tap = k / cin, c = k - tap * cin;
+        out[(int64_t)o * K + ((c / 32) * ntaps + tap) * 32 + c % 32] = w[i];
+    }
+}
+
 }  // namespace
 
 // ============================================================================ launchers
+int launch_repack_chunk_major(const float *w, int cout, int ntaps, int cin, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_repack_chunk_major, dim3(grid_for((int64_t)cout * ntaps * cin, 256)), dim3(256), 0, st, w, cout, ntaps, cin, out);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff,
                const float *w_packed, const float *bias, float *y, hipStream_t st) {
     EVFLY_REQUIRE(cin == 1 || cin == 2, "e11: cin must be 1 or 2 (got %d)", cin);
