@@ -35,7 +35,8 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // ---- per-device growable scratch for the stateless entry points (voxelizer, accumulators,
 // conditioning). Growth frees + reallocates (hipFree synchronises, so no kernel still uses the
 // old block). Model handles own their own arenas.
-int scratch_get(size_t bytes, void **out);
+// slot 0: entry-point scratch; slot 1: split-K partial sums of the GEMM launcher (may be live together)
+int scratch_get(size_t bytes, void **out, int slot = 0);
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -26,15 +26,15 @@ struct Scratch {
     void *ptr = nullptr;
     size_t cap = 0;
 };
-std::map<int, Scratch> g_scratch;
+std::map<std::pair<int, int>, Scratch> g_scratch;   // (device, slot)
 std::mutex g_scratch_mu;
 }  // namespace
 
-int scratch_get(size_t bytes, void **out) {
+int scratch_get(size_t bytes, void **out, int slot) {
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    Scratch &s = g_scratch[dev];
+    Scratch &s = g_scratch[{dev, slot}];
     if (s.cap < bytes) {
         if (s.ptr) EVFLY_HIP(hipFree(s.ptr));
         s.ptr = nullptr;

@@ -47,12 +47,29 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
             for (int i = threadIdx.x; i < 512; i += kCondThreads) (&hist[0][0])[i] = 0u;
             __syncthreads();
             const unsigned p0 = prefix[0], p1 = prefix[1];
-            for (int i = threadIdx.x; i < n_px; i += kCondThreads) {
-                const unsigned key = __float_as_uint(fabsf(cond_load(a, frame, i)));
-                const unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
+            for (int i0 = 0; i0 < n_px; i0 += kCondThreads) {      // uniform trip count: ballots below need the whole wave
+                const int i = i0 + threadIdx.x;
+                const bool live = i < n_px;
+                const unsigned key = live ? __float_as_uint(fabsf(cond_load(a, frame, i))) : 0u;
+                unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
+                if (!live) hi = 0xffffffffu;                         // matches no prefix (prefixes have < 32 bits)
                 const unsigned byte = (key >> shift) & 0xffu;
-                if (hi == p0) atomicAdd(&hist[0][byte], 1u);
-                if (hi == p1) atomicAdd(&hist[1][byte], 1u);
+                // wave-aggregated histogram update: event frames have few distinct values (k * 0.2), so most
+                // lanes of a wave hit the same bin; one atomic per distinct (target, byte) instead of one per lane
+                unsigned tag = (hi == p0 ? 0x100u : 0u) | (hi == p1 ? 0x200u : 0u);
+                tag = tag ? (tag | byte) : 0u;
+                unsigned long long todo = __ballot(tag != 0u);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const unsigned t = __shfl(tag, leader);
+                    const unsigned long long same = __ballot(tag == t);
+                    if ((int)(threadIdx.x & 63) == leader) {
+                        const unsigned c = (unsigned)__popcll(same);
+                        if (t & 0x100u) atomicAdd(&hist[0][t & 0xffu], c);
+                        if (t & 0x200u) atomicAdd(&hist[1][t & 0xffu], c);
+                    }
+                    todo &= ~same;
+                }
             }
             __syncthreads();
             if (threadIdx.x < 2) {   // two lanes: one per target rank

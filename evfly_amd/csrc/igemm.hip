@@ -14,6 +14,7 @@
 // shared by neighbouring pixel tiles are re-read from that XCD's L2, not from HBM.
 #include "igemm.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace evfly {
@@ -49,7 +50,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16, int NBUF>
-__global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, int cpx, int dbg) {
+__global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, int cpx, int dbg, int splits, float *slab) {
     using elem_t = typename LdsElem<BF16>::type;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -114,7 +115,15 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     // i.e. the 9 taps of one 32-channel chunk are consecutive K-steps, so the input bytes a block re-reads
     // for neighbouring taps are still in the XCD's L2 (tap-major order spreads them over the whole K loop).
     // Weights are packed in the same order (conv_k_index in igemm.h).
+    // split-K: blockIdx.y owns the K-steps [kt0, nk) of the total (partial sums go to `slab`, reduced later)
+    const int nk_total = (d.K + BK - 1) / BK;
+    const int kt0 = (int)((int64_t)nk_total * blockIdx.y / splits);
+    const int nk = (int)((int64_t)nk_total * (blockIdx.y + 1) / splits);
     int tc0 = 0, tkx = 0, tky = 0;
+    if (VEC && kt0 > 0) {
+        const int ntaps = d.KH * d.KW, cc = kt0 / ntaps, tap = kt0 - cc * ntaps;
+        tc0 = cc * BK; tky = tap / d.KW; tkx = tap - tky * d.KW;
+    }
     unsigned a_mask = 0;   // rows of the staged A registers that are valid (zeroing happens at LDS-store time so
                            // that no VALU op consumes the loads before the MFMA block: they stay in flight under it)
     float4 ra[PA], rb[PB];
@@ -246,18 +255,17 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (d.K + BK - 1) / BK;
     const int frow = lane & 31, fh = lane >> 5;
 
     if (DMA) {
-        dma_tiles(0, 0);
+        dma_tiles(kt0, 0);
     } else {
-        load_tiles(0);
+        load_tiles(kt0);
         store_tiles(0);
     }
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const elem_t *as = As + cur * BM * BK + (wm * WM) * BK;
         const elem_t *bs = Bs + cur * BN * BK + (wn * WN) * BK;
         if (BF16) {
@@ -339,6 +347,20 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int ncol0 = n0 + wn * WN + frow;
+    if (slab) {   // split-K partial sums: raw accumulators, [split][M][Nc]
+        float *base = slab + (int64_t)blockIdx.y * d.M * d.Nc;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= d.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (ncol0 + j * 32 < d.Nc) base[m * d.Nc + ncol0 + j * 32] = acc[i][j][r];
+            }
+        return;
+    }
     if (d.out_mode == OUT_UPCONV2X2) {
         float bj[TN];
         int64_t coloff[TN];
@@ -403,6 +425,26 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     }
 }
 
+// split-K second pass: y = act(sum_z slab[z] + bias (+ res)), OUT_ROWS only
+__global__ __launch_bounds__(256) void k_splitk_reduce(ConvDesc d, int splits, const float *__restrict__ slab) {
+    const int64_t total = d.M * d.Nc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / d.Nc;
+        const int n = (int)(i - m * d.Nc);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += slab[(int64_t)z * total + i];
+        if (d.bias) v += d.bias[n];
+        if (d.res) {
+            int64_t rrow = m;
+            if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
+            v += d.res[rrow * d.ldres + n];
+        }
+        if (d.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (d.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+        d.y[m * d.ldy + n] = v;
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16, int NBUF>
 int launch_cfg(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv(d.M, BM), n_nt = cdiv(d.Nc, BN);
@@ -416,8 +458,24 @@ int launch_cfg(const ConvDesc &d, hipStream_t st) {
         attr_set = true;
     }
     static const int dbg = getenv("EVFLY_IGEMM_DBG") ? atoi(getenv("EVFLY_IGEMM_DBG")) : 0;
-    hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt), dim3(256), lds, st, d, n_mt, n_nt, cpx, dbg);
+    // few tiles but a long K loop (ViT reduction convs, decoder Linear, small-batch deep layers): split K so that
+    // the launch has >= ~256 workgroups; partial sums go to a scratch slab and a second pass applies the epilogue
+    const int nk = (d.K + BK - 1) / BK, tiles = n_mt * n_nt;
+    int splits = 1;
+    if (d.out_mode == OUT_ROWS && tiles < 128 && nk >= 8) splits = std::max(1, std::min(nk / 4, 256 / tiles));
+    float *slab = nullptr;
+    if (splits > 1) {
+        void *scr = nullptr;
+        if (int rc = scratch_get((size_t)splits * d.M * d.Nc * sizeof(float), &scr, 1)) return rc;
+        slab = static_cast<float *>(scr);
+    }
+    hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt, splits), dim3(256), lds, st, d, n_mt, n_nt, cpx, dbg, splits, slab);
     EVFLY_LAUNCH_CHECK();
+    if (splits > 1) {
+        const int blocks = (int)std::min<int64_t>(2048, cdiv(d.M * d.Nc, 256));
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, st, d, splits, slab);
+        EVFLY_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -28,25 +28,27 @@ template <int CIN>
 __global__ __launch_bounds__(256) void k_e11(const float *__restrict__ frames, int n, int H, int W, int form_bev,
                                               int apply_form, float cutoff, const float *__restrict__ wp,
                                               const float *__restrict__ bias, float *__restrict__ y) {
+    // thread = one output pixel x 4 channels: the 8 threads of a pixel store its 128 B back to back, so a
+    // wave's store instruction covers 1 KiB of contiguous NHWC output (the kernel is write-bound: 11.4 MB/frame)
     const int OH = H - 2, OW = W - 2;
-    const int og = threadIdx.x & 3;                    // 8-channel group
-    float w[9 * CIN][8];
+    const int og = threadIdx.x & 7;
+    float w[9 * CIN][4];
 #pragma unroll
     for (int t = 0; t < 9 * CIN; ++t)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) w[t][c] = wp[t * 32 + og * 8 + c];
-    float b[8];
+        for (int c = 0; c < 4; ++c) w[t][c] = wp[t * 32 + og * 4 + c];
+    float b[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) b[c] = bias[og * 8 + c];
-    const int64_t total = (int64_t)n * OH * OW;
-    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; pix < total; pix += ((int64_t)gridDim.x * 256) >> 2) {
-        const int img = (int)(pix / (OH * OW));
-        const int rem = (int)(pix - (int64_t)img * OH * OW);
-        const int oy = rem / OW, ox = rem - oy * OW;
+    for (int c = 0; c < 4; ++c) b[c] = bias[og * 4 + c];
+    // one block per output row: no per-pixel integer division
+    for (int row = blockIdx.x; row < n * OH; row += gridDim.x) {
+      const int img = row / OH, oy = row - img * OH;
+      for (int ox = threadIdx.x >> 3; ox < OW; ox += 32) {
+        const int64_t pix = (int64_t)row * OW + ox;
         const float *src = frames + ((int64_t)img * H + oy) * W + ox;
-        float acc[8];
+        float acc[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = b[c];
+        for (int c = 0; c < 4; ++c) acc[c] = b[c];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -56,14 +58,12 @@ __global__ __launch_bounds__(256) void k_e11(const float *__restrict__ frames, i
                 for (int ci = 0; ci < CIN; ++ci) {
                     const float v = form_value(raw, form_bev, apply_form, cutoff, ci);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, w[(ky * 3 + kx) * CIN + ci][c], acc[c]);
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, w[(ky * 3 + kx) * CIN + ci][c], acc[c]);
                 }
             }
-        float4 o0 = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-        float4 o1 = make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
-        float4 *dst = reinterpret_cast<float4 *>(y + pix * 32 + og * 8);
-        dst[0] = o0;
-        dst[1] = o1;
+        *reinterpret_cast<float4 *>(y + pix * 32 + og * 4) =
+            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+      }
     }
 }
 
@@ -176,15 +176,17 @@ __global__ __launch_bounds__(256) void k_convlstm_gates(const float *__restrict_
 // ------------------------------------------------------------------------------------------ 1x1 conv -> 1 channel
 __global__ __launch_bounds__(256) void k_dot_out(const float *__restrict__ x, int64_t rows, int C, const float *__restrict__ w,
                                                  const float *__restrict__ bias, float *__restrict__ y) {
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
-        const float4 *p = reinterpret_cast<const float4 *>(x + r * C);
+    // 8 lanes per row (one float4 each per 32 channels): a wave reads 8 rows x 128 B contiguously
+    const int sub = threadIdx.x & 7;
+    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; r < rows; r += ((int64_t)gridDim.x * 256) >> 3) {
         float acc = 0.f;
-        for (int c = 0; c < C / 4; ++c) {
-            const float4 v = p[c];
+        for (int c = sub; c < C / 4; c += 8) {
+            const float4 v = reinterpret_cast<const float4 *>(x + r * C)[c];
             const float4 ww = reinterpret_cast<const float4 *>(w)[c];
             acc = fmaf(v.x, ww.x, acc); acc = fmaf(v.y, ww.y, acc); acc = fmaf(v.z, ww.z, acc); acc = fmaf(v.w, ww.w, acc);
         }
-        y[r] = acc + bias[0];
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        if (sub == 0) y[r] = acc + bias[0];
     }
 }
 
@@ -325,6 +327,51 @@ __global__ __launch_bounds__(256) void k_grouped_conv_gelu(const float *__restri
     }
 }
 
+// LDS-tiled variant for small maps (H*W*32*4 B <= 64 KB; both ViT stages): one block = one frame x a slab
+// of 32 channels (4 groups). The slab is staged once; thread = (output channel of the slab, pixel lane),
+// its 72 weights live in registers, the 8 threads of a group read identical LDS addresses (broadcast).
+__global__ __launch_bounds__(256) void k_grouped_conv_gelu_lds(const float *__restrict__ x, int H, int W, int Ce,
+                                                               const float *__restrict__ w, const float *__restrict__ bias,
+                                                               float *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [H*W][32]
+    const int img = blockIdx.x, slab = blockIdx.y;
+    const int hw = H * W;
+    const float *src = x + (int64_t)img * hw * Ce + slab * 32;
+    for (int i = threadIdx.x; i < hw * 8; i += 256) {
+        const int p = i >> 3, c4 = i & 7;
+        reinterpret_cast<float4 *>(tile)[i] = *reinterpret_cast<const float4 *>(src + (int64_t)p * Ce + c4 * 4);
+    }
+    const int col = threadIdx.x & 31, plane = threadIdx.x >> 5;
+    const int co = slab * 32 + col, g8 = (col >> 3) << 3;
+    float wr[72];
+#pragma unroll
+    for (int k = 0; k < 72; ++k) wr[k] = w[(int64_t)co * 72 + k];
+    const float b = bias[co];
+    __syncthreads();
+    for (int p = plane; p < hw; p += 8) {
+        const int oy = p / W, ox = p - oy * W;
+        float acc = b;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const float4 *sp = reinterpret_cast<const float4 *>(tile + (iy * W + ix) * 32 + g8);
+                const float4 v0 = sp[0], v1 = sp[1];
+                const int t = ky * 3 + kx;
+                acc = fmaf(v0.x, wr[0 * 9 + t], acc); acc = fmaf(v0.y, wr[1 * 9 + t], acc);
+                acc = fmaf(v0.z, wr[2 * 9 + t], acc); acc = fmaf(v0.w, wr[3 * 9 + t], acc);
+                acc = fmaf(v1.x, wr[4 * 9 + t], acc); acc = fmaf(v1.y, wr[5 * 9 + t], acc);
+                acc = fmaf(v1.z, wr[6 * 9 + t], acc); acc = fmaf(v1.w, wr[7 * 9 + t], acc);
+            }
+        }
+        y[((int64_t)img * hw + p) * Ce + co] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
+    }
+}
+
 // ------------------------------------------------------------------------------------------ head helpers
 // nn.PixelShuffle(2) on NHWC: out[n, y, x, c] = in[n, y/2, x/2, c*4 + (y%2)*2 + (x%2)]
 __global__ __launch_bounds__(256) void k_pixel_shuffle2(const float *__restrict__ x, int n, int H, int W, int C,
@@ -427,8 +474,7 @@ int launch_repack_chunk_major(const float *w, int cout, int ntaps, int cin, floa
 int launch_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff,
                const float *w_packed, const float *bias, float *y, hipStream_t st) {
     EVFLY_REQUIRE(cin == 1 || cin == 2, "e11: cin must be 1 or 2 (got %d)", cin);
-    const int64_t work = (int64_t)n * (H - 2) * (W - 2) * 4;
-    const int grid = grid_for(work, 256);
+    const int grid = std::min(n * (H - 2), 64 * kNumCU);
     if (cin == 1)
         hipLaunchKernelGGL(k_e11<1>, dim3(grid), dim3(256), 0, st, frames, n, H, W, form_bev, apply_form, cutoff, w_packed, bias, y);
     else
@@ -490,7 +536,7 @@ int launch_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float
 
 int launch_dot_out(const float *x, int64_t rows, int C, const float *w, const float *bias, float *y, hipStream_t st) {
     EVFLY_REQUIRE(C % 4 == 0, "dot_out: C %% 4");
-    hipLaunchKernelGGL(k_dot_out, dim3(grid_for(rows, 256)), dim3(256), 0, st, x, rows, C, w, bias, y);
+    hipLaunchKernelGGL(k_dot_out, dim3(grid_for(rows * 8, 256)), dim3(256), 0, st, x, rows, C, w, bias, y);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
@@ -516,6 +562,11 @@ int launch_attention(const float *q, const float *kv, int frames, int N, int nkv
 int launch_grouped_conv_gelu(const float *x, int n, int H, int W, int Ce, const float *w, const float *bias, float *y,
                              hipStream_t st) {
     EVFLY_REQUIRE(Ce % 8 == 0, "grouped conv: Ce %% 8");
+    if (Ce % 32 == 0 && H * W * 128 <= 64 * 1024) {
+        hipLaunchKernelGGL(k_grouped_conv_gelu_lds, dim3(n, Ce / 32), dim3(256), H * W * 128, st, x, H, W, Ce, w, bias, y);
+        EVFLY_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t strips = cdiv((int64_t)n * H * W, kGcPix);
     const dim3 grid((unsigned)std::min<int64_t>(strips, 4 * kNumCU), cdiv(Ce, 256));
     hipLaunchKernelGGL(k_grouped_conv_gelu, grid, dim3(256), 0, st, x, n, H, W, Ce, w, bias, y);
