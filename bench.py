@@ -28,7 +28,9 @@ import numpy as np
 import torch
 
 H, W = 260, 346
-PEAK = {"f32": 157.3, "bf16": 2500.0}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md. bf16x3 issues 3 bf16 MFMAs per algorithmic product,
+# so its algorithmic-flop ceiling is a third of the bf16 peak.
+PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -40,8 +42,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU (C2: 64)")
     ap.add_argument("--windows", type=int, default=5, help="time windows per stream (C2: 5)")
     ap.add_argument("--events-per-window", type=int, default=60_000)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x3 pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -63,9 +66,7 @@ def cpu_baseline(sd, T, epw, budget_s):
     C voxelizer port -> conditioning -> composite forward, all host cores torch may use."""
     from evfly_amd import synthetic as syn
     from oracle import accum as oaccum, conditioning as ocond, models as om, voxel as ovox
-    threads = torch.get_num_threads()
-    frames_done, t0, s = 0, time.perf_counter(), 0
-    while True:
+    def one_stream(s):
         ev, edges = syn.make_stream(10_000 + s, T, H, W, epw)
         tt = time.perf_counter()
         c = oaccum.window_counts_c(ev["x"], ev["y"], ev["t"], ev["p"], edges, H, W, 0)
@@ -73,13 +74,25 @@ def cpu_baseline(sd, T, epw, budget_s):
         x, _ = ocond.q97_normalize(fr)
         with torch.no_grad():
             om.composite_forward(sd, [x, torch.full((T, 1), 4.0), [None, None], None])
+        return time.perf_counter() - tt
+
+    # oneDNN on a many-core host is not fastest with every core on a 5-frame batch: try a few thread
+    # counts on one stream each (after a warm-up) and keep the best for the measured sample
+    nproc = torch.get_num_threads()
+    one_stream(0)
+    best, threads = None, nproc
+    for th in sorted({nproc, min(nproc, 64), min(nproc, 32), min(nproc, 16)}, reverse=True):
+        torch.set_num_threads(th)
+        t = one_stream(1)
+        if best is None or t < best:
+            best, threads = t, th
+    torch.set_num_threads(threads)
+    frames_done, dt, s = 0, 0.0, 0
+    while dt < budget_s:
+        dt += one_stream(2 + s)           # synthetic-event generation is not charged
         frames_done += T
         s += 1
-        if s == 1:
-            t0 = tt            # do not charge the synthetic-event generation of the first stream
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
+    torch.set_num_threads(nproc)
     return {"value": round(frames_done / dt, 3), "unit": "event-frames/s", "cores": threads, "kind": "port",
             "sample": f"{s} stream(s) x {T} windows x {epw} events, 260x346, C voxelizer port + torch-CPU fp32 "
                       f"oracle forward (batch-as-time), {dt:.1f} s"}
@@ -201,6 +214,25 @@ def main():
                          "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms / a.steps, 3)}
         mf = sum(p["flops"] for p in prof if p["flops"]) / a.steps
         out["mfma_flops_per_frame"] = mf / (B * T)
+        if world == 1 and a.dtype == "f32" and not a.no_alt:
+            # Informational second precision mode, NOT the headline `value`: fp32 operands split into two bf16
+            # (x = hi + lo), 3 bf16 MFMAs per product, fp32 accumulate. Same inputs, same weights; the velocity
+            # deviation from the exact-fp32 run above is reported with it.
+            vel_f32 = vel_all.clone()
+            model.set_compute_dtype("bf16x3")
+            with torch.no_grad():
+                for _ in range(max(1, a.warmup)):
+                    v3 = step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    v3 = step()
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t1
+            out["alt_precision"] = {"dtype": "bf16x3", "value": round(B * T * a.steps / dt3, 2), "unit": "event-frames/s",
+                                    "ms_per_step": round(1e3 * dt3 / a.steps, 3),
+                                    "max_rel_dev_velocity_vs_f32": float(((v3 - vel_f32).abs().max() / vel_f32.abs().max()).item()),
+                                    "note": "fp32-grade split precision (error ~2^-16 per product); informational"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd, T, a.events_per_window, a.cpu_seconds)
         print(json.dumps(out))

@@ -90,7 +90,7 @@ class HipModule(nn.Module):
         self._bump()
 
     def set_compute_dtype(self, name):
-        self.compute_dtype = {"f32": 0, "fp32": 0, "bf16": 1}[name]
+        self.compute_dtype = {"f32": 0, "fp32": 0, "bf16": 1, "bf16x3": 2}[name]
         self._bump()
         return self
 

@@ -38,8 +38,20 @@ __device__ __forceinline__ void keep_or_zero(float4 &v, bool keep) {
     v.x = keep ? v.x : 0.f; v.y = keep ? v.y : 0.f; v.z = keep ? v.z : 0.f; v.w = keep ? v.w : 0.f;
 }
 
-template <bool BF16> struct LdsElem { using type = float; };
-template <> struct LdsElem<true> { using type = unsigned short; };
+template <int PREC> struct LdsElem { using type = unsigned short; };
+template <> struct LdsElem<0> { using type = float; };
+
+// bf16x3 operand split: x = hi + lo with hi = RNE_bf16(x) and lo = trunc_bf16(x - hi) (x - hi is exact in
+// fp32). a*w ~= ah*wh + ah*wl + al*wh drops only al*wl and the truncation of lo: relative error <= ~2^-16 per
+// product, accumulated in fp32 -- fp32-grade results (1e-5) at 3 bf16 MFMAs per 16 k-values.
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const unsigned h0 = (u0 + 0x7fffu + ((u0 >> 16) & 1u)) & 0xffff0000u;
+    const unsigned h1 = (u1 + 0x7fffu + ((u1 >> 16) & 1u)) & 0xffff0000u;
+    const float l0 = x0 - __uint_as_float(h0), l1 = x1 - __uint_as_float(h1);
+    hi = h1 | (h0 >> 16);
+    lo = (__float_as_uint(l1) & 0xffff0000u) | (__float_as_uint(l0) >> 16);
+}
 
 // swizzled offset (in elements) of 16-B chunk `chunk` of LDS row `row`; a row holds 32 k-values:
 // f32 -> 8 chunks of 4, bf16 -> 4 chunks of 8.
@@ -49,16 +61,20 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16, int NBUF>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, int PREC, int NBUF>
 __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, int cpx, int dbg, int splits, float *slab) {
-    using elem_t = typename LdsElem<BF16>::type;
+    constexpr bool BF16 = PREC != 0;      // bf16 LDS tiles (PREC 1: plain bf16 operands, PREC 2: hi + lo tiles)
+    constexpr bool X3 = PREC == 2;
+    using elem_t = typename LdsElem<PREC>::type;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM / 32, PB = BN / 32;   // rows each loader thread owns in the A / W tile
     static_assert(WAVES_M * WAVES_N == 4 && WM % 32 == 0 && WN % 32 == 0, "tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     elem_t *As = reinterpret_cast<elem_t *>(smem_raw);              // [NBUF][BM][BK]
-    elem_t *Bs = As + NBUF * BM * BK;                               // [NBUF][BN][BK]
+    elem_t *Al = As + NBUF * BM * BK;                               // X3 only: low halves of A
+    elem_t *Bs = X3 ? Al + NBUF * BM * BK : Al;                     // [NBUF][BN][BK]
+    elem_t *Bl = Bs + NBUF * BN * BK;                               // X3 only: low halves of W
 
     // ---- XCD-contiguous tile mapping (placement only affects speed)
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
@@ -221,7 +237,27 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
         for (int p = 0; p < PA; ++p) keep_or_zero(ra[p], (a_mask >> p) & 1u);
 #pragma unroll
         for (int p = 0; p < PB; ++p) keep_or_zero(rb[p], b_ok[p]);
-        if (BF16) {
+        if (X3) {
+            elem_t *al = Al + buf * BM * BK, *bl = Bl + buf * BN * BK;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int off = lds_off<true>(lrow + 32 * p, lchunk >> 1) + (lchunk & 1) * 4;
+                uint2 h, l;
+                split_pair(ra[p].x, ra[p].y, h.x, l.x);
+                split_pair(ra[p].z, ra[p].w, h.y, l.y);
+                *reinterpret_cast<uint2 *>(as + off) = h;
+                *reinterpret_cast<uint2 *>(al + off) = l;
+            }
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int off = lds_off<true>(lrow + 32 * p, lchunk >> 1) + (lchunk & 1) * 4;
+                uint2 h, l;
+                split_pair(rb[p].x, rb[p].y, h.x, l.x);
+                split_pair(rb[p].z, rb[p].w, h.y, l.y);
+                *reinterpret_cast<uint2 *>(bs + off) = h;
+                *reinterpret_cast<uint2 *>(bl + off) = l;
+            }
+        } else if (BF16) {
             // 4 fp32 -> 4 bf16 = half a 16-B chunk (8 B store)
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -268,7 +304,33 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     for (int kt = kt0; kt < nk; ++kt) {
         const elem_t *as = As + cur * BM * BK + (wm * WM) * BK;
         const elem_t *bs = Bs + cur * BN * BK + (wn * WN) * BK;
-        if (BF16) {
+        if (X3) {
+            if (kt + 1 < nk) load_tiles(kt + 1);
+            const elem_t *al = Al + cur * BM * BK + (wm * WM) * BK;
+            const elem_t *bl = Bl + cur * BN * BK + (wn * WN) * BK;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 ah[TM], alo[TM], bh[TN], blo[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(as + lds_off<true>(i * 32 + frow, 2 * s + fh));
+                    alo[i] = *reinterpret_cast<const bf16x8 *>(al + lds_off<true>(i * 32 + frow, 2 * s + fh));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8 *>(bs + lds_off<true>(j * 32 + frow, 2 * s + fh));
+                    blo[j] = *reinterpret_cast<const bf16x8 *>(bl + lds_off<true>(j * 32 + frow, 2 * s + fh));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blo[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if (BF16) {
             if (kt + 1 < nk) load_tiles(kt + 1);
             // lane half h supplies k = 16*s + 8*h .. +7 (chunk 2s+h) for MFMA step s
 #pragma unroll
@@ -445,12 +507,12 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvDesc d, int splits, c
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool BF16, int NBUF>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, int PREC, int NBUF>
 int launch_cfg(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv(d.M, BM), n_nt = cdiv(d.Nc, BN);
     const int cpx = cdiv(n_mt, kNumXCD);
-    const int lds = NBUF * (BM + BN) * BK * (BF16 ? 2 : 4);
-    auto kern = k_igemm<BM, BN, WAVES_M, WAVES_N, VEC, BF16, NBUF>;
+    const int lds = NBUF * (BM + BN) * BK * (PREC == 1 ? 2 : 4);
+    auto kern = k_igemm<BM, BN, WAVES_M, WAVES_N, VEC, PREC, NBUF>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -479,17 +541,17 @@ int launch_cfg(const ConvDesc &d, hipStream_t st) {
     return 0;
 }
 
-template <bool VEC, bool BF16>
+template <bool VEC, int PREC>
 int launch_by_n(const ConvDesc &d, hipStream_t st) {
     static const int nbuf = getenv("EVFLY_IGEMM_NBUF") ? atoi(getenv("EVFLY_IGEMM_NBUF")) : 2;
     if (nbuf == 2) {
-        if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, BF16, 2>(d, st);
-        if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, BF16, 2>(d, st);
-        return launch_cfg<256, 32, 4, 1, VEC, BF16, 2>(d, st);
+        if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, PREC, 2>(d, st);
+        if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, PREC, 2>(d, st);
+        return launch_cfg<256, 32, 4, 1, VEC, PREC, 2>(d, st);
     }
-    if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, BF16, 1>(d, st);
-    if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, BF16, 1>(d, st);
-    return launch_cfg<256, 32, 4, 1, VEC, BF16, 1>(d, st);
+    if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, PREC, 1>(d, st);
+    if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, PREC, 1>(d, st);
+    return launch_cfg<256, 32, 4, 1, VEC, PREC, 1>(d, st);
 }
 
 }  // namespace
@@ -523,9 +585,9 @@ int igemm_launch(const ConvDesc &d_in, hipStream_t st) {
                   "igemm: bad upconv epilogue");
     const bool vec = d.C % BK == 0;   // decides the K order: the packer applies the same rule
     EVFLY_REQUIRE(!vec || (d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0), "igemm: input not 16-byte aligned");
-    const bool bf16 = d.dtype == EVFLY_DTYPE_BF16;
-    if (vec) return bf16 ? launch_by_n<true, true>(d, st) : launch_by_n<true, false>(d, st);
-    return bf16 ? launch_by_n<false, true>(d, st) : launch_by_n<false, false>(d, st);
+    if (d.dtype == EVFLY_DTYPE_BF16X3) return vec ? launch_by_n<true, 2>(d, st) : launch_by_n<false, 2>(d, st);
+    if (d.dtype == EVFLY_DTYPE_BF16) return vec ? launch_by_n<true, 1>(d, st) : launch_by_n<false, 1>(d, st);
+    return vec ? launch_by_n<true, 0>(d, st) : launch_by_n<false, 0>(d, st);
 }
 
 }  // namespace evfly

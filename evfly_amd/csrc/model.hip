@@ -705,7 +705,7 @@ extern "C" int evfly_model_create(const evfly_model_config *cfg, evfly_model **o
         EVFLY_REQUIRE(cfg->num_out_channels == 1, "num_out_channels != 1 is not built");
         EVFLY_REQUIRE(cfg->num_recurrent_unet == 0 || cfg->num_recurrent_unet == 1, "only 0 or 1 ConvLSTM layers are built");
     }
-    EVFLY_REQUIRE(cfg->compute_dtype == EVFLY_DTYPE_F32 || cfg->compute_dtype == EVFLY_DTYPE_BF16, "bad compute_dtype");
+    EVFLY_REQUIRE(cfg->compute_dtype >= EVFLY_DTYPE_F32 && cfg->compute_dtype <= EVFLY_DTYPE_BF16X3, "bad compute_dtype");
     auto *m = new evfly_model();
     m->cfg = *cfg;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(-2, "hipGetDevice failed"); }

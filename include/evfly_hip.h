@@ -122,6 +122,8 @@ typedef struct evfly_model evfly_model;
 
 #define EVFLY_DTYPE_F32 0  /* f32-input MFMA, exact fp32 */
 #define EVFLY_DTYPE_BF16 1 /* bf16 MFMA operands, fp32 accumulate / statistics */
+#define EVFLY_DTYPE_BF16X3 2 /* fp32 operands split x = hi + lo (two bf16), a*w ~ ah*wh + ah*wl + al*wh on the bf16
+                              * MFMA, fp32 accumulate: ~2^-16 relative error per product (fp32-grade, not bit-exact) */
 
 typedef struct evfly_model_config {
     /* OrigUNet.__init__ arguments, learner/learner_models.py:340 */

@@ -217,10 +217,21 @@ def refine_inputs(X):
     return X
 
 
+_STAGES = [VIT_STAGES]   # trunk hyper-parameters used by vit_trunk; see use_trunk()
+
+
+def use_trunk(heads=(1, 2), layers=(2, 2), reductions=(8, 4)):
+    """Select the Mix-Transformer trunk the oracle runs (reference: heads (1,2), layers (2,2), reductions
+    (8,4), learner/vitfly_models.py:118-121). The build-defined "ViT-base" of BASELINE configs C3/C4 is
+    heads (4,8), layers (4,4) (evfly_amd.vitfly_models.BASE); widths come from the weights."""
+    _STAGES[0] = (dict(patch=7, stride=4, padding=3, n_layers=layers[0], reduction=reductions[0], heads=heads[0]),
+                  dict(patch=3, stride=2, padding=1, n_layers=layers[1], reduction=reductions[1], heads=heads[1]))
+
+
 def vit_trunk(sd, prefix, img, return_taps=False):
     """Shared trunk of LSTMNetVIT / ViT: learner/vitfly_models.py:136-143 (== :174-181)."""
-    s1 = mix_stage_forward(sd, prefix + "encoder_blocks.0.", img, **VIT_STAGES[0])
-    s2 = mix_stage_forward(sd, prefix + "encoder_blocks.1.", s1, **VIT_STAGES[1])
+    s1 = mix_stage_forward(sd, prefix + "encoder_blocks.0.", img, **_STAGES[0][0])
+    s2 = mix_stage_forward(sd, prefix + "encoder_blocks.1.", s1, **_STAGES[0][1])
     up = F.interpolate(s1, size=(16, 24), mode="bilinear", align_corners=True)      # :128
     out = torch.cat([F.pixel_shuffle(s2, 2), up], dim=1)                            # :141
     out = _conv(sd, prefix + "down_sample.", out, padding=1)                        # :142

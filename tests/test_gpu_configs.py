@@ -1,0 +1,82 @@
+"""GPU parity on slices shaped like BASELINE.json's other configs (parity-test cases, not bench lines):
+C3: 480x640 events, T windows -> centre crop -> U-Net -> "ViT-base" velocity head, bf16-operand MFMA
+C5: one stream, seq_len 16 through the ConvLSTM U-Net (batch-as-time), bf16 and fp32
+plus the build-defined ViT-base trunk on its own in fp32 against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from evfly_amd import synthetic as syn
+from oracle import conditioning as ocond
+from oracle import models as om
+from oracle import voxel as ovox
+
+from _util import cond_frames, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def base_trunk():
+    import evfly_amd.vitfly_models as vm
+    om.use_trunk(heads=vm.BASE["heads"], layers=vm.BASE["layers"], reductions=vm.BASE["reductions"])
+    yield vm.BASE
+    om.use_trunk()
+
+
+def test_vit_base_fp32(gpu_device, base_trunk):
+    import evfly_amd.vitfly_models as vm
+    net = vm.LSTMNetVIT(**base_trunk)
+    sd = syn.fill_state_dict(net.state_dict(), "vitfly_vitlstm.")
+    net.load_state_dict(sd)
+    net = net.to(gpu_device).eval()
+    rs = np.random.RandomState(123)
+    img = torch.from_numpy(rs.rand(6, 1, 60, 90).astype(np.float32))
+    desvel = torch.full((6, 1), 4.0)
+    v, (h, c) = net.forward_streams([img.to(gpu_device), desvel.to(gpu_device), None], n_streams=2, T=3)
+    for s in range(2):
+        vr, (hr, cr) = om.lstmnetvit_forward(sd, [img[3 * s:3 * s + 3], desvel[3 * s:3 * s + 3], None])
+        assert rel_err(v[3 * s:3 * s + 3].cpu(), vr) < 1e-4 and rel_err(h[s].cpu(), hr) < 1e-4
+
+
+def test_c3_slice_sensor_crop_base_bf16(gpu_device, base_trunk):
+    """events at 480x640 -> voxelize -> centre crop 260x346 + q97 -> U-Net+ConvLSTM -> ViT-base (bf16 MFMA)."""
+    import evfly_amd.learner_models as lm
+    from evfly_amd import voxelizer
+    S, T, Hs, Ws = 2, 3, 480, 640
+    batch = syn.make_batch(S, T, Hs, Ws, events_per_window=200_000, seed_base=4321)
+    ev = voxelizer.upload_events(batch)
+    frames, counts = voxelizer.voxelize_windows(ev, Hs, Ws, out=("f32", "counts"))
+    want_counts = ovox.batch_window_counts(batch, Hs, Ws)
+    assert np.array_equal(counts.cpu().numpy(), want_counts)                     # bit-exact at sensor size
+    x = voxelizer.condition_frames(frames.reshape(S * T, Hs, Ws), out_hw=(260, 346))
+    fr = ovox.signed_frame(want_counts[:, :, 0], want_counts[:, :, 1]).astype(np.float32).reshape(S * T, 1, Hs, Ws)
+    x_ref, _ = ocond.q97_normalize(ocond.center_crop(torch.from_numpy(fr)))
+    assert torch.equal(x.cpu(), x_ref)
+    net = lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
+                                       input_shape=[1, 1, 260, 346], velpred=0, form_BEV=2, evs_min_cutoff=0.15,
+                                       skip_type="interp", logger=lambda *a: None, vit_trunk=base_trunk)
+    sd = syn.fill_state_dict(net.state_dict())
+    net.load_state_dict(sd)
+    net.set_compute_dtype("bf16")
+    net = net.to(gpu_device).eval()
+    desvel = torch.full((S * T, 1), 4.0)
+    v, (d, _, _) = net.forward_streams([x, desvel.to(gpu_device), [None, None], None], S, T)
+    v_ref, d_ref = om.composite_streams(sd, x_ref, desvel, S, T)
+    assert rel_err(d.cpu(), d_ref) < 3e-2 and rel_err(v.cpu(), v_ref) < 3e-2       # bf16 operands vs fp32 oracle
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 3e-2)])
+def test_c5_convlstm_seq16(gpu_device, dtype, tol):
+    import evfly_amd.learner_models as lm
+    net = lm.OrigUNet(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346],
+                      velpred=0, form_BEV=2, evs_min_cutoff=0.15, skip_type="interp", logger=lambda *a: None)
+    sd = syn.fill_state_dict(net.state_dict(), "origunet.")
+    net.load_state_dict(sd)
+    net.set_compute_dtype(dtype)
+    net = net.to(gpu_device).eval()
+    x = cond_frames(160, 16)
+    _, (depth, up, (st, _)) = net([x.clone().to(gpu_device), None, None])
+    _, (d_ref, up_ref, (st_ref, _)) = om.origunet_forward(sd, x, None)
+    assert rel_err(up.cpu(), up_ref) < tol and rel_err(depth.cpu(), d_ref) < tol
+    assert rel_err(st[0][0].cpu(), st_ref[0][0]) < tol and rel_err(st[0][1].cpu(), st_ref[0][1]) < tol

@@ -39,7 +39,7 @@ def _unet(dev, **kw):
     (1, 8, 13, 512, 2048, 1, 1, 0),    # ConvLSTM 1x1
     (1, 9, 9, 32, 12, 3, 1, 1),        # N = 12 (masked columns)
 ])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 def test_conv_kernel_vs_torch(gpu_device, shape, dtype):
     from evfly_amd import _lib
     n, h, w, cin, cout, k, s, p = shape
@@ -55,10 +55,10 @@ def test_conv_kernel_vs_torch(gpu_device, shape, dtype):
     y = torch.empty(n, oh, ow, cout, device=gpu_device)
     L = _lib.lib()
     _lib.check(L.evfly_op_conv2d_nhwc(_lib.ptr(xg), n, h, w, cin, _lib.ptr(wg), _lib.ptr(bg), cout, k, k, s, p, 1, None,
-                                      _lib.ptr(y), 0 if dtype == "f32" else 1, _lib.cur_stream()))
+                                      _lib.ptr(y), {"f32": 0, "bf16": 1, "bf16x3": 2}[dtype], _lib.cur_stream()))
     torch.cuda.synchronize()
     got = y.permute(0, 3, 1, 2).cpu()
-    assert rel_err(got, want) < (2e-5 if dtype == "f32" else 2e-2)
+    assert rel_err(got, want) < {"f32": 2e-5, "bf16": 2e-2, "bf16x3": 5e-5}[dtype]
 
 
 # ------------------------------------------------------------------ G4 Mix-Transformer stages
@@ -239,6 +239,18 @@ def test_composite_bf16_mfma(gpu_device):
     v, (d, _, _) = net([x.to(gpu_device), desvel.to(gpu_device), [None, None], None])
     v_ref, (d_ref, _, _) = om.composite_forward(sd, [x, desvel, [None, None], None])
     assert rel_err(d.cpu(), d_ref) < TOL_BF16 and rel_err(v.cpu(), v_ref) < TOL_BF16
+
+
+def test_composite_bf16x3_split_precision(gpu_device):
+    """bf16x3 (fp32 operands split into two bf16, 3 MFMAs per product): fp32-grade parity, far inside the
+    1e-3 north-star bar."""
+    g = golden("g8_composite")
+    net, sd = _composite(gpu_device, "bf16x3")
+    x = cond_frames(80, 3).to(gpu_device)
+    desvel = torch.tensor([[4.0]], device=gpu_device)
+    v3, (d3, up3, _) = net([x.clone(), desvel.repeat(3, 1), [None, None], None])
+    assert rel_err(v3.cpu(), g["vel_batch"]) < 2e-4 and rel_err(up3.cpu(), g["upconv"]) < 2e-4
+    assert rel_err(d3[2:].cpu(), g["depth_last"]) < 2e-4
 
 
 def test_errors_are_loud(gpu_device):
