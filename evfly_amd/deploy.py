@@ -1,0 +1,58 @@
+"""Non-ROS mirror of the deployment node's per-frame processing (evfly_ros/run.py:245-362).
+
+`EventDepthVelocityNode` keeps the reference node's data flow and attribute names without rospy:
+`image_callback(bytes)` (run.py:325-328) stores the accumulator image, `evs_process()` (run.py:330-362)
+decodes / crops / conditions it on the GPU, runs the stateful model (run.py:245-268) and prepares the
+three published quantities. SURVEY.md §8f row N1.
+"""
+import numpy as np
+import torch
+
+from . import voxelizer
+
+
+class EventDepthVelocityNode:
+    def __init__(self, model, evcam_hw=(480, 640), model_hw=(260, 346), des_fwd_vel=1.0, dodge_scaler=2.0,
+                 des_z=0.8, desvel=4.0, device="cuda"):
+        self.model = model.to(device).float().eval()
+        self.device = device
+        self.evcam_height, self.evcam_width = evcam_hw                 # run.py:41
+        self.model_hw = model_hw
+        self.des_fwd_vel, self.dodge_scaler, self.des_z = des_fwd_vel, dodge_scaler, des_z   # run.py:36-39
+        self.desvel = desvel                                           # run.py:255 (hard-coded 4.0)
+        self.proc_evs = None
+        self.origunet_hidden_state = None                              # run.py:173-174
+        self.velpred_hidden_state = None
+        self.pred_vel = self.pred_depth = self.evframe = None
+
+    def image_callback(self, data):
+        """run.py:325-328: UInt8MultiArray payload -> (480, 640) uint8 view."""
+        self.proc_evs = np.frombuffer(data, dtype=np.uint8).reshape(self.evcam_height, self.evcam_width)
+
+    def run_model(self, frame_u8):
+        """run.py:334-350 + 245-268 for one accumulator image (decode, centre crop, q97, forward)."""
+        x = voxelizer.condition_frames(torch.from_numpy(np.ascontiguousarray(frame_u8))[None], out_hw=self.model_hw)
+        desvel = torch.tensor([[self.desvel]], device=x.device)
+        full_input = [x, desvel, [self.origunet_hidden_state, None], self.velpred_hidden_state]
+        with torch.no_grad():
+            x_vel, (x_depth, _, ((self.origunet_hidden_state, _), self.velpred_hidden_state)) = self.model(full_input)
+        self.evframe = x
+        self.pred_vel = x_vel.cpu().detach().numpy().squeeze()         # run.py:267
+        self.pred_depth = x_depth.cpu().detach().numpy().squeeze() if x_depth is not None else None
+        return self.pred_vel, self.pred_depth
+
+    def evs_process(self):
+        if self.proc_evs is None:
+            return None
+        self.run_model(self.proc_evs.copy())                           # run.py:334 copies the shared buffer
+        return dict(pred_depth=self.publish_pred_depth(), pred_vel=self.publish_pred_vel())
+
+    def publish_pred_depth(self):
+        """run.py:284-288: clip to [0,1], scale to uint8 (the Image message payload)."""
+        return (np.clip(self.pred_depth, 0.0, 1.0) * 255).astype(np.uint8)
+
+    def publish_pred_vel(self, odom_z=None):
+        """run.py:297-309: TwistStamped.linear (x, y, z)."""
+        v = self.pred_vel * self.des_fwd_vel                           # :299 (scale up from 1 m/s)
+        z = 1.5 * (self.des_z - odom_z) if odom_z is not None else 0.0
+        return np.array([v[0], v[1] * self.dodge_scaler, z], dtype=np.float64)
