@@ -19,8 +19,7 @@ struct CondArgs {
     float *dst, *q_out;
 };
 
-__device__ __forceinline__ float cond_load(const CondArgs &a, int frame, int i) {
-    const int r = i / a.out_w, c = i - r * a.out_w;
+__device__ __forceinline__ float cond_load(const CondArgs &a, int frame, int r, int c) {
     const int64_t src = ((int64_t)frame * a.in_h + (r + a.top)) * a.in_w + (c + a.left);
     if (a.u8) return (float)((int)a.u8[src] - 128) * 0.2f;   // run.py:334-336 (numpy float32 ops)
     return a.f32[src];
@@ -31,6 +30,7 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
     __shared__ unsigned prefix[2], kth[2];
     const int frame = blockIdx.x;
     const int n_px = a.out_h * a.out_w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float q = 1.0f;
     if (a.quantile > 0.0f) {
         // torch.quantile (linear): rank = q * (n-1) in fp32, below = floor, above = ceil,
@@ -47,10 +47,13 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
             for (int i = threadIdx.x; i < 512; i += kCondThreads) (&hist[0][0])[i] = 0u;
             __syncthreads();
             const unsigned p0 = prefix[0], p1 = prefix[1];
-            for (int i0 = 0; i0 < n_px; i0 += kCondThreads) {      // uniform trip count: ballots below need the whole wave
-                const int i = i0 + threadIdx.x;
-                const bool live = i < n_px;
-                const unsigned key = live ? __float_as_uint(fabsf(cond_load(a, frame, i))) : 0u;
+            // wave w walks rows w, w+16, ...; lanes walk the columns (no per-element division). Trip counts are
+            // wave-uniform: the ballots below need the whole wave.
+            for (int r = wave; r < a.out_h; r += kCondThreads / 64)
+              for (int c0 = 0; c0 < a.out_w; c0 += 64) {
+                const int c = c0 + lane;
+                const bool live = c < a.out_w;
+                const unsigned key = live ? __float_as_uint(fabsf(cond_load(a, frame, r, c))) : 0u;
                 unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
                 if (!live) hi = 0xffffffffu;                         // matches no prefix (prefixes have < 32 bits)
                 const unsigned byte = (key >> shift) & 0xffu;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
                     const int leader = __ffsll((long long)todo) - 1;
                     const unsigned t = __shfl(tag, leader);
                     const unsigned long long same = __ballot(tag == t);
-                    if ((int)(threadIdx.x & 63) == leader) {
+                    if (lane == leader) {
                         const unsigned c = (unsigned)__popcll(same);
                         if (t & 0x100u) atomicAdd(&hist[0][t & 0xffu], c);
                         if (t & 0x200u) atomicAdd(&hist[1][t & 0xffu], c);
@@ -94,14 +97,15 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
         if (threadIdx.x == 0 && a.q_out) a.q_out[frame] = q;
     }
     float *dst = a.dst + (int64_t)frame * n_px;
-    for (int i = threadIdx.x; i < n_px; i += kCondThreads) {
-        float v = cond_load(a, frame, i);
-        if (a.quantile > 0.0f) {
-            v = v / q;                                   // run.py:253; IEEE division (0/0 = NaN survives)
-            v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);  // torch.clip keeps NaN
+    for (int r = wave; r < a.out_h; r += kCondThreads / 64)
+        for (int c = lane; c < a.out_w; c += 64) {
+            float v = cond_load(a, frame, r, c);
+            if (a.quantile > 0.0f) {
+                v = v / q;                                   // run.py:253; IEEE division (0/0 = NaN survives)
+                v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);  // torch.clip keeps NaN
+            }
+            dst[r * a.out_w + c] = v;
         }
-        dst[i] = v;
-    }
 }
 
 }  // namespace

@@ -40,30 +40,36 @@ __global__ __launch_bounds__(256) void k_e11(const float *__restrict__ frames, i
     float b[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) b[c] = bias[og * 4 + c];
-    // one block per output row: no per-pixel integer division
+    // one block per output row: the three input rows are formed (cutoff / BEV) once into LDS, then every
+    // output pixel reads its 9 taps from there (no per-pixel division, no repeated form_value, no global re-reads)
+    __shared__ float rows[CIN][3][352];
     for (int row = blockIdx.x; row < n * OH; row += gridDim.x) {
-      const int img = row / OH, oy = row - img * OH;
-      for (int ox = threadIdx.x >> 3; ox < OW; ox += 32) {
-        const int64_t pix = (int64_t)row * OW + ox;
-        const float *src = frames + ((int64_t)img * H + oy) * W + ox;
-        float acc[4];
+        const int img = row / OH, oy = row - img * OH;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * W; i += 256) {
+            const int r = i / W, c = i - r * W;
+            const float raw = frames[((int64_t)img * H + oy + r) * W + c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = b[c];
+            for (int ci = 0; ci < CIN; ++ci) rows[ci][r][c] = form_value(raw, form_bev, apply_form, cutoff, ci);
+        }
+        __syncthreads();
+        for (int ox = threadIdx.x >> 3; ox < OW; ox += 32) {
+            float acc[4];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int c = 0; c < 4; ++c) acc[c] = b[c];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float raw = src[ky * W + kx];
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    const float v = form_value(raw, form_bev, apply_form, cutoff, ci);
+                for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, w[(ky * 3 + kx) * CIN + ci][c], acc[c]);
-                }
-            }
-        *reinterpret_cast<float4 *>(y + pix * 32 + og * 4) =
-            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-      }
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const float v = rows[ci][ky][ox + kx];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, w[(ky * 3 + kx) * CIN + ci][c], acc[c]);
+                    }
+            *reinterpret_cast<float4 *>(y + ((int64_t)row * OW + ox) * 32 + og * 4) =
+                make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+        }
     }
 }
 
@@ -474,6 +480,7 @@ int launch_repack_chunk_major(const float *w, int cout, int ntaps, int cin, floa
 int launch_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff,
                const float *w_packed, const float *bias, float *y, hipStream_t st) {
     EVFLY_REQUIRE(cin == 1 || cin == 2, "e11: cin must be 1 or 2 (got %d)", cin);
+    EVFLY_REQUIRE(W <= 352, "e11: frame wider than the 352-column LDS row buffer");
     const int grid = std::min(n * (H - 2), 64 * kNumCU);
     if (cin == 1)
         hipLaunchKernelGGL(k_e11<1>, dim3(grid), dim3(256), 0, st, frames, n, H, W, form_bev, apply_form, cutoff, w_packed, bias, y);
