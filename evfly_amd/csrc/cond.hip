@@ -10,6 +10,7 @@ namespace evfly {
 namespace {
 
 constexpr int kCondThreads = 1024;
+constexpr int kBatch = 6;   // columns fetched per lane before binning (6 x 64 >= 346)
 
 struct CondArgs {
     const uint8_t *u8;
@@ -50,30 +51,40 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
             // wave w walks rows w, w+16, ...; lanes walk the columns (no per-element division). Trip counts are
             // wave-uniform: the ballots below need the whole wave.
             for (int r = wave; r < a.out_h; r += kCondThreads / 64)
-              for (int c0 = 0; c0 < a.out_w; c0 += 64) {
-                const int c = c0 + lane;
-                const bool live = c < a.out_w;
-                const unsigned key = live ? __float_as_uint(fabsf(cond_load(a, frame, r, c))) : 0u;
-                unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
-                if (!live) hi = 0xffffffffu;                         // matches no prefix (prefixes have < 32 bits)
-                const unsigned byte = (key >> shift) & 0xffu;
-                // wave-aggregated histogram update: event frames have few distinct values (k * 0.2), so most
-                // lanes of a wave hit the same bin; one atomic per distinct (target, byte) instead of one per lane
-                unsigned tag = (hi == p0 ? 0x100u : 0u) | (hi == p1 ? 0x200u : 0u);
-                tag = tag ? (tag | byte) : 0u;
-                unsigned long long todo = __ballot(tag != 0u);
-                while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const unsigned t = __shfl(tag, leader);
-                    const unsigned long long same = __ballot(tag == t);
-                    if (lane == leader) {
-                        const unsigned c = (unsigned)__popcll(same);
-                        if (t & 0x100u) atomicAdd(&hist[0][t & 0xffu], c);
-                        if (t & 0x200u) atomicAdd(&hist[1][t & 0xffu], c);
-                    }
-                    todo &= ~same;
+              for (int c0 = 0; c0 < a.out_w; c0 += 64 * kBatch) {
+                // the loop is L2-latency bound (ballots / LDS atomics keep hipcc from pipelining it): fetch a
+                // batch of columns first, then bin them
+                float vals[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const int c = c0 + 64 * k + lane;
+                    vals[k] = c < a.out_w ? cond_load(a, frame, r, c) : 0.f;
                 }
-            }
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const bool live = c0 + 64 * k + lane < a.out_w;
+                    const unsigned key = live ? __float_as_uint(fabsf(vals[k])) : 0u;
+                    unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
+                    if (!live) hi = 0xffffffffu;                     // matches no prefix (prefixes have < 32 bits)
+                    const unsigned byte = (key >> shift) & 0xffu;
+                    // wave-aggregated histogram update: event frames have few distinct values (k * 0.2), so most
+                    // lanes of a wave hit the same bin; one atomic per distinct (target, byte), not one per lane
+                    unsigned tag = (hi == p0 ? 0x100u : 0u) | (hi == p1 ? 0x200u : 0u);
+                    tag = tag ? (tag | byte) : 0u;
+                    unsigned long long todo = __ballot(tag != 0u);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const unsigned t = __shfl(tag, leader);
+                        const unsigned long long same = __ballot(tag == t);
+                        if (lane == leader) {
+                            const unsigned c = (unsigned)__popcll(same);
+                            if (t & 0x100u) atomicAdd(&hist[0][t & 0xffu], c);
+                            if (t & 0x200u) atomicAdd(&hist[1][t & 0xffu], c);
+                        }
+                        todo &= ~same;
+                    }
+                }
+              }
             __syncthreads();
             if (threadIdx.x < 2) {   // two lanes: one per target rank
                 const int j = threadIdx.x;
@@ -98,6 +109,7 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
     }
     float *dst = a.dst + (int64_t)frame * n_px;
     for (int r = wave; r < a.out_h; r += kCondThreads / 64)
+#pragma unroll 6
         for (int c = lane; c < a.out_w; c += 64) {
             float v = cond_load(a, frame, r, c);
             if (a.quantile > 0.0f) {
