@@ -99,20 +99,33 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     bool a_ok[PA];
     {
         const int ohw = d.OH * d.OW;
-        const int64_t m0a = dbg == 3 ? (int64_t)(mt % 16) * BM : m0;   // dbg 3: every block gathers from 16 hot tiles
-        const int mfirst = (int)min(m0a + lrow, d.M - 1);
+        const int mfirst = (int)min(m0 + lrow, d.M - 1);
         int img = mfirst / ohw;
         int rem = mfirst - img * ohw;
         int oy = rem / d.OW, ox = rem - oy * d.OW;
+        // one 64-bit address computation; the following rows advance the pointer by constant strides
+        const int64_t px = d.ldx;                                          // floats per input pixel
+        const int64_t step_x = (int64_t)d.stride * px;                     // ox + 1
+        const int64_t wrap_x = ((int64_t)d.stride * d.W - (int64_t)d.OW * d.stride) * px;   // ox -= OW, oy += 1
+        const int64_t wrap_y = ((int64_t)d.H - (int64_t)d.OH * d.stride) * d.W * px;        // oy = 0, img += 1
+        const float *ptr = d.x + (((int64_t)img * d.H + (oy * d.stride - d.pad)) * d.W + (ox * d.stride - d.pad)) * px + gchunk * 4;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             a_ok[p] = m0 + lrow + 32 * p < d.M;
             a_iy[p] = oy * d.stride - d.pad;
             a_ix[p] = ox * d.stride - d.pad;
-            a_ptr[p] = d.x + (((int64_t)img * d.H + a_iy[p]) * d.W + a_ix[p]) * d.ldx + gchunk * 4;
+            a_ptr[p] = ptr;
             if (a_ok[p] && m0 + lrow + 32 * (p + 1) < d.M) {   // advance 32 output pixels
                 ox += 32;
-                while (ox >= d.OW) { ox -= d.OW; if (++oy == d.OH) { oy = 0; ++img; } }
+                ptr += 32 * step_x;
+                if (ox >= d.OW) {          // at most one wrap when OW >= 32 (the loop below covers narrow maps)
+                    ox -= d.OW; ptr += wrap_x;
+                    if (++oy == d.OH) { oy = 0; ++img; ptr += wrap_y; }
+                    while (ox >= d.OW) {
+                        ox -= d.OW; ptr += wrap_x;
+                        if (++oy == d.OH) { oy = 0; ++img; ptr += wrap_y; }
+                    }
+                }
             }
         }
     }
@@ -133,8 +146,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     // Weights are packed in the same order (conv_k_index in igemm.h).
     // split-K: blockIdx.y owns the K-steps [kt0, nk) of the total (partial sums go to `slab`, reduced later)
     const int nk_total = (d.K + BK - 1) / BK;
-    const int kt0 = (int)((int64_t)nk_total * blockIdx.y / splits);
-    const int nk = (int)((int64_t)nk_total * (blockIdx.y + 1) / splits);
+    const int kt0 = splits == 1 ? 0 : (int)((unsigned)nk_total * blockIdx.y / (unsigned)splits);
+    const int nk = splits == 1 ? nk_total : (int)((unsigned)nk_total * (blockIdx.y + 1) / (unsigned)splits);
     int tc0 = 0, tkx = 0, tky = 0;
     if (VEC && kt0 > 0) {
         const int ntaps = d.KH * d.KW, cc = kt0 / ntaps, tap = kt0 - cc * ntaps;
@@ -460,28 +473,37 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             nok[j] = n < d.Nc;
             bj[j] = (d.bias && nok[j]) ? d.bias[n] : 0.f;
         }
+        const int act = d.act;
+        const bool plain_res = d.res && d.res_rpi == 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // rows of this lane in tile i: m_base + {0,1,2,3, 8,..,11, 16,..,19, 24,..,27}: walk them with a
+            // running pointer (one 64-bit multiply per tile instead of one per row)
+            const int64_t m_base = m0 + wm * WM + i * 32 + 4 * fh;
+            float *yr = d.y + m_base * d.ldy + ncol0;
+            const float *rr = plain_res ? d.res + m_base * d.ldres + ncol0 : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= d.M) continue;
-                float *yr = d.y + m * d.ldy + ncol0;
-                const float *rr = nullptr;
-                if (d.res) {
-                    int64_t rrow = m;
-                    if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
-                    rr = d.res + rrow * d.ldres + ncol0;
-                }
+                const int64_t m = m_base + (r & 3) + 8 * (r >> 2);
+                if (m < d.M) {
+                    const float *rrow = rr;
+                    if (d.res && !plain_res) {
+                        const int g = (int)m / d.res_rpi;
+                        rrow = d.res + ((int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi)) * d.ldres + ncol0;
+                    }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (!nok[j]) continue;
-                    float v = acc[i][j][r] + bj[j];
-                    if (rr) v += rr[j * 32];
-                    if (d.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (d.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                    yr[j * 32] = v;
+                    for (int j = 0; j < TN; ++j) {
+                        if (!nok[j]) continue;
+                        float v = acc[i][j][r] + bj[j];
+                        if (rrow) v += rrow[j * 32];
+                        if (act == ACT_RELU) v = v < 0.f ? 0.f : v;             // NaN-propagating like torch.relu
+                        else if (act == ACT_LEAKY) v = v < 0.f ? 0.01f * v : v;
+                        yr[j * 32] = v;
+                    }
                 }
+                const int64_t adv = (r & 3) == 3 ? 5 : 1;    // next row of this lane
+                yr += adv * d.ldy;
+                if (rr) rr += adv * d.ldres;
             }
         }
     }

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void k_e11(const float *__restrict__ frames, i
                         for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, w[(ky * 3 + kx) * CIN + ci][c], acc[c]);
                     }
             *reinterpret_cast<float4 *>(y + ((int64_t)row * OW + ox) * 32 + og * 4) =
-                make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+                make_float4(acc[0] < 0.f ? 0.f : acc[0], acc[1] < 0.f ? 0.f : acc[1], acc[2] < 0.f ? 0.f : acc[2],
+                            acc[3] < 0.f ? 0.f : acc[3]);   // NaN-propagating like torch.relu
         }
     }
 }
