@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             // DMA mode: the PA + PB tile requests are spread between the MFMAs (one every STRIDE MFMAs). A
             // vector-memory issue that has to queue behind the other waves' requests then stalls this wave
             // while its previous MFMA is still executing, instead of delaying the whole MFMA burst.
-            constexpr int NMFMA = 16 * TM * TN, NREQ = PA + PB, STRIDE = NMFMA / NREQ;
+            constexpr int NMFMA = 16 * TM * TN, NREQ = PA + PB;
+            constexpr int STRIDE = NMFMA / NREQ > 0 ? NMFMA / NREQ : 1;   // spread evenly over the burst (measured best)
+            static_assert((NREQ - 1) * STRIDE + 1 < NMFMA, "every tile request must be issued inside the MFMA burst");
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
@@ -397,9 +399,9 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                             const float bv = e == 0 ? b[jj][j].x : e == 1 ? b[jj][j].y : e == 2 ? b[jj][j].z : b[jj][j].w;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                             const int idx = ((jj * 4 + e) * TM + i) * TN + j;
-                            if (DMA && idx % STRIDE == 1 && idx / STRIDE < NREQ) {
+                            if (DMA && idx >= 1 && (idx - 1) % STRIDE == 0 && (idx - 1) / STRIDE < NREQ) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (more) dma_one(idx / STRIDE, kt + 1, cur ^ 1);
+                                if (more) dma_one((idx - 1) / STRIDE, kt + 1, cur ^ 1);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
