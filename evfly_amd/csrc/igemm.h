@@ -56,6 +56,13 @@ inline int conv_k_index(int tap, int c, int C, int ntaps) {
 // Enqueue the GEMM on `st`. Returns 0 / negative (evfly_last_error).
 int igemm_launch(const ConvDesc &d, hipStream_t st);
 
+// >= 256 B of zeros in global memory on the current device (source of masked LDS-DMA rows)
+int igemm_zero_page(const float **out);
+
+// Halo-tiled 3x3 valid conv for wide shallow layers (conv3x3_halo.hip); same ConvDesc contract.
+bool conv3x3_halo_applicable(const ConvDesc &d);
+int conv3x3_halo_launch(const ConvDesc &d, hipStream_t st);
+
 // algorithmic work of one launch (for the profile / roofline accounting)
 inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }
 

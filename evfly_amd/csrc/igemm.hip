@@ -477,6 +477,46 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
         }
         const int act = d.act;
         const bool plain_res = d.res && d.res_rpi == 0;
+        // Fast path: transpose the tile through LDS so that every lane stores 16 B. The direct epilogue issues
+        // one global_store_dword per accumulator register (4 B per lane, two 128-B segments per instruction);
+        // on the wide shallow layers that store tail was ~20 % of the kernel (store-issue bound, not bandwidth).
+        const bool vec_store = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0 &&
+                               (!d.res || ((d.ldres & 3) == 0 && (((uintptr_t)d.res) & 15) == 0));
+        if (vec_store && NBUF == 2 && !BF16) {     // the fp32 double buffer is exactly BM x BN floats or larger
+            float *ot = reinterpret_cast<float *>(smem_raw);          // [BM][BN]; all waves passed the last barrier
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) ot[row * BN + wn * WN + j * 32 + frow] = acc[i][j][r] + bj[j];
+                }
+            __syncthreads();
+            constexpr int C4 = BN / 4;
+#pragma unroll 4
+            for (int idx = tid; idx < BM * C4; idx += 256) {
+                const int row = idx / C4, c4 = idx - row * C4;
+                const int64_t m = m0 + row;
+                const int n = n0 + c4 * 4;
+                if (m >= d.M || n >= d.Nc) continue;
+                float4 v = *reinterpret_cast<const float4 *>(ot + row * BN + c4 * 4);
+                if (d.res) {
+                    int64_t rrow = m;
+                    if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
+                    const float4 q = *reinterpret_cast<const float4 *>(d.res + rrow * d.ldres + n);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                if (act == ACT_RELU) {
+                    v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                } else if (act == ACT_LEAKY) {
+                    v.x = v.x < 0.f ? 0.01f * v.x : v.x; v.y = v.y < 0.f ? 0.01f * v.y : v.y;
+                    v.z = v.z < 0.f ? 0.01f * v.z : v.z; v.w = v.w < 0.f ? 0.01f * v.w : v.w;
+                }
+                *reinterpret_cast<float4 *>(d.y + m * d.ldy + n) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             // rows of this lane in tile i: m_base + {0,1,2,3, 8,..,11, 16,..,19, 24,..,27}: walk them with a
@@ -580,8 +620,7 @@ int launch_by_n(const ConvDesc &d, hipStream_t st) {
 
 }  // namespace
 
-namespace {
-int zero_page(const float **out) {
+int igemm_zero_page(const float **out) {
     static const float *pages[64] = {};
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
@@ -595,11 +634,10 @@ int zero_page(const float **out) {
     *out = pages[dev];
     return 0;
 }
-}  // namespace
 
 int igemm_launch(const ConvDesc &d_in, hipStream_t st) {
     ConvDesc d = d_in;
-    if (int rc = zero_page(&d.zeros)) return rc;
+    if (int rc = igemm_zero_page(&d.zeros)) return rc;
     EVFLY_REQUIRE(d.x && d.w && d.y && d.M > 0 && d.Nc > 0 && d.K > 0, "igemm: empty problem");
     EVFLY_REQUIRE(d.ldw % BK == 0 && d.ldw >= d.K, "igemm: weights must be zero padded to a multiple of 32 (ldw=%d K=%d)",
                   d.ldw, d.K);

@@ -354,7 +354,8 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", wname.c_str());
     const double bytes = 4.0 * ((double)n * H * W * C + (double)d.M * cout + (double)cout * d.K);
     const std::string pn = std::string(pname) + "/" + wname;   // family/layer: bench.py groups by family
-    RUN(m, pn.c_str(), igemm_flops(d), bytes, igemm_launch(d, m->st));
+    RUN(m, pn.c_str(), igemm_flops(d), bytes,
+        conv3x3_halo_applicable(d) ? conv3x3_halo_launch(d, m->st) : igemm_launch(d, m->st));
     return 0;
 }
 
@@ -800,5 +801,6 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
         d.w = static_cast<const float *>(scr);
     }
     d.ldw = d.K; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
+    if (conv3x3_halo_applicable(d)) return conv3x3_halo_launch(d, as_stream(stream));
     return igemm_launch(d, as_stream(stream));
 }
