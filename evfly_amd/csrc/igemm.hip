@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
         // on the wide shallow layers that store tail was ~20 % of the kernel (store-issue bound, not bandwidth).
         const bool vec_store = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0 &&
                                (!d.res || ((d.ldres & 3) == 0 && (((uintptr_t)d.res) & 15) == 0));
-        if (vec_store && NBUF == 2 && !BF16) {     // the fp32 double buffer is exactly BM x BN floats or larger
+        if (vec_store && NBUF == 2 && PREC != 1) {  // the fp32 / bf16x3 double buffer is BM x BN floats or larger
             float *ot = reinterpret_cast<float *>(smem_raw);          // [BM][BN]; all waves passed the last barrier
 #pragma unroll
             for (int i = 0; i < TM; ++i)
