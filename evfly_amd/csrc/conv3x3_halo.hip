@@ -141,6 +141,34 @@ __global__ __launch_bounds__(256) void k_conv3x3_halo(ConvDesc d, int tiles_x, i
         if (vec) *reinterpret_cast<float4 *>(dst) = v;
         else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
     }
+    if (d.y_pool) {
+        // fused nn.MaxPool2d(2, 2): the 8 x 32 patch starts at even coordinates, so every pooling window lies
+        // inside it. max commutes with the monotonic activation; NaN wins like in torch.
+        const int PH = d.OH / 2, PW = d.OW / 2;
+#pragma unroll 2
+        for (int idx = tid; idx < (TH / 2) * (TW / 2) * C4; idx += 256) {
+            const int pp = idx / C4, c4 = idx - pp * C4;
+            const int py = pp / (TW / 2), pxp = pp - py * (TW / 2);
+            const int gy = oy0 / 2 + py, gx = ox0 / 2 + pxp, n = n0 + c4 * 4;
+            if (gy >= PH || gx >= PW || n >= d.Nc) continue;
+            const float *s0 = ot + ((2 * py) * TW + 2 * pxp) * BN + c4 * 4;
+            const float4 a = *reinterpret_cast<const float4 *>(s0), b = *reinterpret_cast<const float4 *>(s0 + BN);
+            const float4 c = *reinterpret_cast<const float4 *>(s0 + TW * BN), e = *reinterpret_cast<const float4 *>(s0 + TW * BN + BN);
+#define MX(p, q) ((p) > (q) || (p) != (p) ? (p) : (q))
+            float4 v = make_float4(MX(MX(a.x, b.x), MX(c.x, e.x)), MX(MX(a.y, b.y), MX(c.y, e.y)),
+                                   MX(MX(a.z, b.z), MX(c.z, e.z)), MX(MX(a.w, b.w), MX(c.w, e.w)));
+#undef MX
+            if (d.act == ACT_RELU) {
+                v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+            } else if (d.act == ACT_LEAKY) {
+                v.x = v.x < 0.f ? 0.01f * v.x : v.x; v.y = v.y < 0.f ? 0.01f * v.y : v.y;
+                v.z = v.z < 0.f ? 0.01f * v.z : v.z; v.w = v.w < 0.f ? 0.01f * v.w : v.w;
+            }
+            float *dst = d.y_pool + (((int64_t)img * PH + gy) * PW + gx) * d.Nc + n;
+            if ((d.Nc & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
+            else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
+        }
+    }
 }
 
 template <int BN>

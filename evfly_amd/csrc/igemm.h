@@ -34,6 +34,9 @@ struct ConvDesc {
     int up_cout = 0;            // OUT_UPCONV2X2: n = (dy*2+dx)*up_cout + co, bias indexed by co
     int dtype = EVFLY_DTYPE_F32;
     const float *zeros = nullptr;   // >= 16 B of zeros in global memory (set by igemm_launch)
+    // optional second output of the halo-tiled 3x3 kernel: 2x2/stride-2 max pool (floor) of the activated
+    // output, NHWC [NI][OH/2][OW/2][Nc] contiguous (nn.MaxPool2d(2, 2) fused into the producer)
+    float *y_pool = nullptr;
 };
 
 // Fills OH/OW/M/K from the geometry (conv arithmetic of torch.nn.Conv2d).

@@ -343,7 +343,7 @@ struct Ctx {
 // y[N,OH,OW,Cout] = act(conv(x) + b (+res))
 int conv(evfly_model *m, const char *pname, const std::string &wname, const float *x, int n, int H, int W, int C,
          int64_t ldx, int cout, int kh, int kw, int stride, int pad, int act, const float *res, int64_t ldres, float *y,
-         int64_t ldy) {
+         int64_t ldy, float *y_pool = nullptr, bool *pool_fused = nullptr) {
     ConvDesc d;
     d.x = x; d.ldx = ldx; d.NI = n; d.H = H; d.W = W; d.C = C;
     d.w = m->W(wname + ".w"); d.ldw = m->planning ? round_up(kh * kw * C, 32) : m->wld[wname];
@@ -354,8 +354,10 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", wname.c_str());
     const double bytes = 4.0 * ((double)n * H * W * C + (double)d.M * cout + (double)cout * d.K);
     const std::string pn = std::string(pname) + "/" + wname;   // family/layer: bench.py groups by family
-    RUN(m, pn.c_str(), igemm_flops(d), bytes,
-        conv3x3_halo_applicable(d) ? conv3x3_halo_launch(d, m->st) : igemm_launch(d, m->st));
+    const bool halo = conv3x3_halo_applicable(d);
+    if (halo) d.y_pool = y_pool;                               // nn.MaxPool2d(2,2) fused into the producer
+    if (pool_fused) *pool_fused = halo && y_pool != nullptr;
+    RUN(m, pn.c_str(), igemm_flops(d), bytes, halo ? conv3x3_halo_launch(d, m->st) : igemm_launch(d, m->st));
     return 0;
 }
 
@@ -385,17 +387,22 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     int H = 258, W = 344, C = 32;
     const char *names[5][2] = {{nullptr, "e12"}, {"e21", "e22"}, {"e31", "e32"}, {"e41", "e42"}, {"e51", "e52"}};
     const int chans[5] = {32, 64, 128, 256, 512};
+    float *pooled = nullptr;         // pool of the previous level's output (already filled when the conv fused it)
+    bool pool_done = false;
     for (int l = 0; l < 5; ++l) {
         if (l > 0) {
-            float *p = m->alloc((int64_t)F * (H / 2) * (W / 2) * C);
-            RUN(m, "maxpool", 0, 4.0 * F * H * W * C * 1.25, launch_maxpool2x2(cur, F, H, W, C, p, st));
+            float *p = pooled;
+            if (!pool_done) RUN(m, "maxpool", 0, 4.0 * F * H * W * C * 1.25, launch_maxpool2x2(cur, F, H, W, C, p, st));
             cur = p; H /= 2; W /= 2;
             float *a = m->alloc((int64_t)F * (H - 2) * (W - 2) * chans[l]);
             if (int rc = conv(m, "conv3x3", names[l][0], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, chans[l])) return rc;
             cur = a; H -= 2; W -= 2; C = chans[l];
         }
         float *b = m->alloc((int64_t)F * (H - 2) * (W - 2) * chans[l]);
-        if (int rc = conv(m, "conv3x3", names[l][1], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, chans[l])) return rc;
+        pooled = l < 4 ? m->alloc((int64_t)F * ((H - 2) / 2) * ((W - 2) / 2) * chans[l]) : nullptr;
+        pool_done = false;
+        if (int rc = conv(m, "conv3x3", names[l][1], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, chans[l],
+                          pooled, &pool_done)) return rc;
         cur = b; H -= 2; W -= 2; C = chans[l];
         lv[l] = Lvl{H, W, C, b};
         static const char *tn[5] = {"e1", "e2", "e3", "e4", "e5"};
