@@ -451,6 +451,33 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             coloff[j] = ((int64_t)(q >> 1) * (2 * d.OW) + (q & 1)) * d.ldy + co;
         }
         const int hw = d.OH * d.OW;
+        if (NBUF == 2 && PREC != 1 && (d.ldy & 3) == 0 && (d.up_cout & 3) == 0 && (((uintptr_t)d.y) & 15) == 0) {
+            // same LDS transpose as the row epilogue: 16-B stores into the (2iy+dy, 2ix+dx) scatter
+            float *ot = reinterpret_cast<float *>(smem_raw);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) ot[row * BN + wn * WN + j * 32 + frow] = acc[i][j][r] + bj[j];
+                }
+            __syncthreads();
+            constexpr int C4 = BN / 4;
+#pragma unroll 2
+            for (int idx = tid; idx < BM * C4; idx += 256) {
+                const int row = idx / C4, c4 = idx - row * C4;
+                const int64_t m = m0 + row;
+                const int n = n0 + c4 * 4;
+                if (m >= d.M || n >= d.Nc) continue;
+                const int mi = (int)m, img = mi / hw, rem = mi - img * hw;
+                const int iy = rem / d.OW, ix = rem - iy * d.OW;
+                const int q = n / d.up_cout, co = n - q * d.up_cout;
+                float *dst = d.y + ((((int64_t)img * 2 * d.OH + 2 * iy + (q >> 1)) * (2 * d.OW)) + 2 * ix + (q & 1)) * d.ldy + co;
+                *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(ot + row * BN + c4 * 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
