@@ -69,6 +69,10 @@ def load_library():
             raise RuntimeError(
                 f"evfly_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch first: its wheel carries its own libamdhip64 / libhsa-runtime64. If this library (linked
+        # against /opt/rocm) were loaded before torch, the process would end up with two HIP runtimes in the
+        # wrong binding order and the first HIP call here fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

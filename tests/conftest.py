@@ -18,3 +18,12 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail("test is marked gpu but no GPU is visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_library_present():
+    """The HIP library is built in-tree by __graft_entry__.build(); build it if a fresh checkout lacks it."""
+    from evfly_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
