@@ -190,9 +190,19 @@ def main():
     }
     if rank == 0:
         tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["flops"] else 0.0
+        # HBM bytes per launch of the MFMA GEMM kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE, separate runs of this script at the C2 shape; FETCH doubled per the gfx950 calibration in
+        # profiles/README.md). PMC counters cannot be read inside this process, so the figure is null for other shapes.
+        traffic, tnote = None, "no PMC summary for this shape/dtype"
+        pmc = os.path.join(REPO, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(pmc) and a.dtype == "f32" and (B, T, a.events_per_window) == (64, 5, 60_000):
+            g = json.load(open(pmc))["kernels"]["mfma_gemm"]
+            traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
+            tnote = ("bytes per launch, mean over the %d MFMA GEMM launches of a step (17 conv3x3 + smaller GEMMs): "
+                     "(2 x FETCH_SIZE + WRITE_SIZE) from profiles/r1_pmc_traffic.json" % g["launches_per_step"])
         if dom["flops"]:
             out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(tfl, 2), "peak": PEAK[a.dtype],
-                               "unit": "TFLOP/s", "frac": round(tfl / PEAK[a.dtype], 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(tfl / PEAK[a.dtype], 4), "traffic": traffic, "traffic_note": tnote,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                                "flops_per_launch": dom["flops"] / dom["launches"]}
         else:
