@@ -28,7 +28,16 @@ class ModelConfig(C.Structure):
         ("vit_reduction", c_i * 2), ("vit_patch", c_i * 2), ("vit_stride", c_i * 2),
         ("vit_pad", c_i * 2), ("vit_expansion", c_i),
         ("compute_dtype", c_i),
+        ("velpred", c_i), ("enc_num_layers", c_i),
+        ("enc_kernel", c_i * 4), ("enc_stride", c_i * 4), ("enc_out_channels", c_i * 4), ("enc_act", c_i * 4),
+        ("enc_pool_type", c_i), ("enc_pool_kernel", c_i * 4), ("enc_pool_stride", c_i * 4),
+        ("enc_invert_pool_inputs", c_i),
+        ("fc_num_layers", c_i), ("fc_size", c_i * 8), ("fc_act", c_i * 8),
     ]
+
+
+ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
+POOL_CODES = {"none": 0, "max": 1, "avg": 2}
 
 
 # name -> (restype, argtypes); must list every symbol include/evfly_hip.h declares
@@ -46,7 +55,7 @@ SIGNATURES = {
     "evfly_model_load_tensor": (c_i, [c_p, C.c_char_p, c_p, C.POINTER(c_i64), c_i]),
     "evfly_model_finalize": (c_i, [c_p]),
     "evfly_model_destroy": (None, [c_p]),
-    "evfly_unet_forward": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "evfly_unet_forward": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "evfly_vit_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "evfly_vit_stage_forward": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "evfly_e2v_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -7,7 +7,16 @@
 
 namespace evfly {
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+
+// scalar activation shared by the GEMM epilogues (NaN-propagating ReLU like torch)
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return v < 0.f ? 0.f : v;
+    if (act == ACT_LEAKY) return v < 0.f ? 0.01f * v : v;
+    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
 enum OutMode { OUT_ROWS = 0, OUT_UPCONV2X2 = 1 };
 
 struct ConvDesc {

@@ -536,9 +536,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 }
                 if (act == ACT_RELU) {
                     v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
-                } else if (act == ACT_LEAKY) {
-                    v.x = v.x < 0.f ? 0.01f * v.x : v.x; v.y = v.y < 0.f ? 0.01f * v.y : v.y;
-                    v.z = v.z < 0.f ? 0.01f * v.z : v.z; v.w = v.w < 0.f ? 0.01f * v.w : v.w;
+                } else if (act != ACT_NONE) {
+                    v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
                 }
                 *reinterpret_cast<float4 *>(d.y + m * d.ldy + n) = v;
             }
@@ -565,8 +564,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                         if (!nok[j]) continue;
                         float v = acc[i][j][r] + bj[j];
                         if (rrow) v += rrow[j * 32];
-                        if (act == ACT_RELU) v = v < 0.f ? 0.f : v;             // NaN-propagating like torch.relu
-                        else if (act == ACT_LEAKY) v = v < 0.f ? 0.01f * v : v;
+                        v = apply_act(v, act);
                         yr[j * 32] = v;
                     }
                 }
@@ -592,9 +590,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvDesc d, int splits, c
             if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
             v += d.res[rrow * d.ldres + n];
         }
-        if (d.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-        else if (d.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-        d.y[m * d.ldy + n] = v;
+        d.y[m * d.ldy + n] = apply_act(v, d.act);
     }
 }
 

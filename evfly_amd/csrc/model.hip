@@ -266,6 +266,85 @@ int pack_unet(evfly_model *m) {
     return 0;
 }
 
+// velpred geometry: input of the DynamicConvNet and the (H, W, C) after every conv+pool pair
+struct VpGeom {
+    int H0, W0, C0;
+    int ch[4], cw[4];      // after the conv
+    int ph[4], pw[4];      // after the pool (== conv dims when pool_type is none)
+    int C[4];
+};
+
+int velpred_geometry(const evfly_model_config &c, VpGeom &g) {
+    if (c.velpred == 1) { g.H0 = c.input_h; g.W0 = c.input_w; g.C0 = 1; }
+    else if (c.velpred == 11) { g.H0 = 68; g.W0 = 148; g.C0 = 1; }
+    else { g.H0 = 8; g.W0 = 13; g.C0 = 512; }
+    int H = g.H0, W = g.W0;
+    for (int i = 0; i < c.enc_num_layers; ++i) {
+        const int k = c.enc_kernel[i], s = c.enc_stride[i];
+        EVFLY_REQUIRE(k >= 1 && s >= 1 && H >= k && W >= k, "velpred conv %d: kernel %d does not fit a %dx%d input", i, k, H, W);
+        H = (H - k) / s + 1; W = (W - k) / s + 1;
+        g.ch[i] = H; g.cw[i] = W; g.C[i] = c.enc_out_channels[i];
+        if (c.enc_pool_type != EVFLY_POOL_NONE) {
+            const int pk = c.enc_pool_kernel[i], ps = c.enc_pool_stride[i];
+            EVFLY_REQUIRE(pk >= 1 && ps >= 1 && H >= pk && W >= pk, "velpred pool %d: kernel %d does not fit %dx%d", i, pk, H, W);
+            H = (H - pk) / ps + 1; W = (W - pk) / ps + 1;
+        }
+        g.ph[i] = H; g.pw[i] = W;
+    }
+    return 0;
+}
+
+// DynamicConvNet / DynamicFCNet weights (learner_models.py:18-145). BatchNorm2d in eval mode is folded into the
+// bias-free conv: w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps)  (eps = 1e-5).
+int pack_velpred(evfly_model *m) {
+    const auto &c = m->cfg;
+    VpGeom g;
+    if (int rc = velpred_geometry(c, g)) return rc;
+    int cin = g.C0;
+    for (int i = 0; i < c.enc_num_layers; ++i) {
+        const std::string si = std::to_string(i), L = "convnet_velpred.layers.";
+        const HostTensor *w = m->find(L + "conv2d_" + si + ".weight", kUnetP);
+        const HostTensor *ga = m->find(L + "batchnorm_" + si + ".weight", kUnetP), *be = m->find(L + "batchnorm_" + si + ".bias", kUnetP);
+        const HostTensor *mu = m->find(L + "batchnorm_" + si + ".running_mean", kUnetP), *var = m->find(L + "batchnorm_" + si + ".running_var", kUnetP);
+        if (!w || !ga || !be || !mu || !var) return fail(-4, "missing DynamicConvNet tensors of layer %d (%sconv2d_%d / batchnorm_%d)", i, L.c_str(), i, i);
+        const int O = c.enc_out_channels[i], k = c.enc_kernel[i];
+        EVFLY_REQUIRE(w->shape.size() == 4 && w->shape[0] == O && w->shape[1] == cin && w->shape[2] == k && w->shape[3] == k,
+                      "convnet_velpred conv2d_%d.weight: expected (%d,%d,%d,%d)", i, O, cin, k, k);
+        EVFLY_REQUIRE((int)ga->v.size() == O && (int)be->v.size() == O && (int)mu->v.size() == O && (int)var->v.size() == O,
+                      "convnet_velpred batchnorm_%d: expected %d channels", i, O);
+        HostTensor fw = *w, fb;
+        fb.shape = {O}; fb.v.resize(O);
+        const size_t per = fw.v.size() / O;
+        for (int o = 0; o < O; ++o) {
+            const float sc = ga->v[o] / std::sqrt(var->v[o] + 1e-5f);
+            for (size_t j = 0; j < per; ++j) fw.v[o * per + j] *= sc;
+            fb.v[o] = be->v[o] - mu->v[o] * sc;
+        }
+        m->host["__vpconv" + si + ".weight"] = std::move(fw);
+        m->host["__vpconv" + si + ".bias"] = std::move(fb);
+        if (int rc = pack_conv(m, "", "__vpconv" + si, "vp.conv" + si)) return rc;
+        cin = O;
+    }
+    // fcnet consumes torch.flatten(x, 1) of a (C, H, W) tensor (:605); ours is HWC
+    const int L = c.enc_num_layers;
+    const int Cf = L ? g.C[L - 1] : g.C0, Hf = L ? g.ph[L - 1] : g.H0, Wf = L ? g.pw[L - 1] : g.W0;
+    std::vector<int> perm((size_t)Cf * Hf * Wf);
+    for (int ch = 0; ch < Cf; ++ch)
+        for (int p = 0; p < Hf * Wf; ++p) perm[(size_t)ch * Hf * Wf + p] = p * Cf + ch;
+    int fin = Cf * Hf * Wf;
+    for (int i = 0; i < c.fc_num_layers; ++i) {
+        const std::string key = "velpred_head.fcnet.layers.fc_" + std::to_string(i);
+        const HostTensor *w = m->find(key + ".weight", kUnetP);
+        if (!w) return fail(-4, "missing tensor %s.weight", key.c_str());
+        EVFLY_REQUIRE(w->shape.size() == 2 && w->shape[0] == c.fc_size[i] && w->shape[1] == fin,
+                      "%s.weight: expected (%d,%d), got (%lld,%lld)", key.c_str(), c.fc_size[i], fin,
+                      (long long)w->shape[0], (long long)(w->shape.size() > 1 ? w->shape[1] : 0));
+        if (int rc = pack_linear(m, kUnetP, key, "vp.fc" + std::to_string(i), true, i == 0 ? &perm : nullptr)) return rc;
+        fin = c.fc_size[i];
+    }
+    return 0;
+}
+
 int pack_vit(evfly_model *m) {
     const auto &c = m->cfg;
     for (int s = 0; s < 2; ++s) {
@@ -370,8 +449,10 @@ int linear(evfly_model *m, const char *pname, const std::string &wname, const fl
 }  // namespace
 
 // ============================================================================ U-Net forward (one chunk)
+static int velpred_chunk(evfly_model *m, const float *x, int F, float *yvel);
+
 static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *h_state, float *c_state,
-                      float *depth_out, float *upconv_out, float **depth_dev) {
+                      float *depth_out, float *upconv_out, float **depth_dev, float *yvel_out = nullptr) {
     const auto &c = m->cfg;
     const int F = S * T;
     const int cin = (c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels;
@@ -478,6 +559,45 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     float *dp = depth_out ? depth_out : m->alloc((int64_t)F * c.input_h * c.input_w);
     RUN(m, "depth_bilinear", 0, 4.0 * F * c.input_h * c.input_w * 2, launch_bilinear(up, F, 68, 148, 1, 1, dp, c.input_h, c.input_w, 1, 0, 0, st));
     if (depth_dev) *depth_dev = dp;
+    if (c.velpred > 0 && yvel_out)
+        return velpred_chunk(m, c.velpred == 1 ? dp : c.velpred == 11 ? up : y5, F, yvel_out);
+    return 0;
+}
+
+// ============================================================================ velpred head (OrigUNet, velpred > 0)
+// learner_models.py:593-614: convnet_velpred(y_interp | y_upconv | y_e5) -> flatten -> velpred_head
+static int velpred_chunk(evfly_model *m, const float *x, int F, float *yvel) {
+    const auto &c = m->cfg;
+    VpGeom g;
+    if (int rc = velpred_geometry(c, g)) return rc;
+    hipStream_t st = m->st;
+    const float *cur = x;
+    int H = g.H0, W = g.W0, C = g.C0;
+    for (int i = 0; i < c.enc_num_layers; ++i) {
+        const std::string wn = "vp.conv" + std::to_string(i);
+        float *a = m->alloc((int64_t)F * g.ch[i] * g.cw[i] * g.C[i]);
+        if (int rc = conv(m, "velpred_conv", wn, cur, F, H, W, C, C, g.C[i], c.enc_kernel[i], c.enc_kernel[i], c.enc_stride[i], 0,
+                          c.enc_act[i], nullptr, 0, a, g.C[i])) return rc;
+        cur = a; H = g.ch[i]; W = g.cw[i]; C = g.C[i];
+        // one InvertLayer survives, in front of the pool (both are registered as 'invert_i', :77-92)
+        const bool pool = c.enc_pool_type != EVFLY_POOL_NONE;
+        if (pool || c.enc_invert_pool_inputs) {
+            float *b = m->alloc((int64_t)F * g.ph[i] * g.pw[i] * C);
+            RUN(m, "velpred_pool", 0, 4.0 * F * H * W * C * 1.25,
+                launch_pool2d(cur, F, H, W, C, pool ? c.enc_pool_kernel[i] : 1, pool ? c.enc_pool_stride[i] : 1,
+                              pool ? c.enc_pool_type : EVFLY_POOL_MAX, c.enc_invert_pool_inputs, b, st));
+            cur = b; H = g.ph[i]; W = g.pw[i];
+        }
+    }
+    m->tap("velpred_enc", const_cast<float *>(cur), F, H, W, C);
+    int fin = H * W * C;
+    for (int i = 0; i < c.fc_num_layers; ++i) {
+        float *y = m->alloc((int64_t)F * c.fc_size[i]);
+        if (int rc = linear(m, "velpred_fc", "vp.fc" + std::to_string(i), cur, F, fin, fin, c.fc_size[i], c.fc_act[i], nullptr, 0, y,
+                            c.fc_size[i])) return rc;
+        cur = y; fin = c.fc_size[i];
+    }
+    RUN(m, "velpred_vec", 0, 16.0 * F, launch_velpred_vec(cur, F, fin, yvel, st));
     return 0;
 }
 
@@ -623,11 +743,12 @@ constexpr int kChunkFrames = 320;
 }  // namespace
 
 extern "C" int evfly_unet_forward(evfly_model *m, const float *frames, int n_streams, int T, float *h_state, float *c_state,
-                                  float *depth_out, float *upconv_out, void *stream) {
+                                  float *depth_out, float *upconv_out, float *yvel_out, void *stream) {
     if (int rc = check_model(m, stream)) return rc;
     EVFLY_REQUIRE(m->cfg.has_unet, "handle has no U-Net");
     EVFLY_REQUIRE(frames && n_streams > 0 && T > 0, "unet_forward: empty batch");
     EVFLY_REQUIRE((h_state == nullptr) == (c_state == nullptr), "unet_forward: h_state and c_state go together");
+    EVFLY_REQUIRE(m->cfg.velpred == 0 || yvel_out, "unet_forward: the handle has a velpred head, yvel_out is required");
     const int per = std::max(1, kChunkFrames / T);
     const int64_t fr = (int64_t)m->cfg.input_h * m->cfg.input_w;
     for (int s0 = 0; s0 < n_streams; s0 += per) {
@@ -636,7 +757,8 @@ extern "C" int evfly_unet_forward(evfly_model *m, const float *frames, int n_str
             return unet_chunk(m, frames + (int64_t)s0 * T * fr, S, T, h_state ? h_state + (int64_t)s0 * 104 * 512 : nullptr,
                               c_state ? c_state + (int64_t)s0 * 104 * 512 : nullptr,
                               depth_out ? depth_out + (int64_t)s0 * T * fr : nullptr,
-                              upconv_out ? upconv_out + (int64_t)s0 * T * 68 * 148 : nullptr, nullptr);
+                              upconv_out ? upconv_out + (int64_t)s0 * T * 68 * 148 : nullptr, nullptr,
+                              m->cfg.velpred > 0 ? yvel_out + (int64_t)s0 * T * 3 : nullptr);
         };
         if (int rc = with_arena(m, body)) return rc;
     }
@@ -713,6 +835,23 @@ extern "C" int evfly_model_create(const evfly_model_config *cfg, evfly_model **o
         EVFLY_REQUIRE(cfg->num_out_channels == 1, "num_out_channels != 1 is not built");
         EVFLY_REQUIRE(cfg->num_recurrent_unet == 0 || cfg->num_recurrent_unet == 1, "only 0 or 1 ConvLSTM layers are built");
     }
+    if (cfg->velpred != 0) {
+        EVFLY_REQUIRE(cfg->has_unet, "velpred needs the U-Net");
+        EVFLY_REQUIRE(cfg->velpred == 1 || cfg->velpred == 11 || cfg->velpred == 2, "velpred should be 0/1/11/2, but is %d", cfg->velpred);
+        EVFLY_REQUIRE(cfg->enc_num_layers >= 0 && cfg->enc_num_layers <= EVFLY_MAX_ENC_LAYERS, "enc_num_layers out of range");
+        EVFLY_REQUIRE(cfg->fc_num_layers >= 1 && cfg->fc_num_layers <= EVFLY_MAX_FC_LAYERS, "fc_num_layers out of range");
+        EVFLY_REQUIRE(cfg->fc_size[cfg->fc_num_layers - 1] == 1, "velpred_head is built with num_out=1 (learner_models.py:462): "
+                      "the last fc layer size must be 1");
+        EVFLY_REQUIRE(cfg->enc_pool_type >= EVFLY_POOL_NONE && cfg->enc_pool_type <= EVFLY_POOL_AVG, "bad enc_pool_type");
+        for (int i = 0; i < cfg->enc_num_layers; ++i)
+            EVFLY_REQUIRE(cfg->enc_act[i] >= EVFLY_ACT_NONE && cfg->enc_act[i] <= EVFLY_ACT_SIGMOID && cfg->enc_out_channels[i] > 0,
+                          "bad velpred encoder layer %d", i);
+        for (int i = 0; i < cfg->fc_num_layers; ++i)
+            EVFLY_REQUIRE(cfg->fc_act[i] >= EVFLY_ACT_RELU && cfg->fc_act[i] <= EVFLY_ACT_SIGMOID && cfg->fc_size[i] > 0,
+                          "bad velpred fc layer %d", i);
+        VpGeom g;
+        if (int rc = velpred_geometry(*cfg, g)) return rc;
+    }
     EVFLY_REQUIRE(cfg->compute_dtype >= EVFLY_DTYPE_F32 && cfg->compute_dtype <= EVFLY_DTYPE_BF16X3, "bad compute_dtype");
     auto *m = new evfly_model();
     m->cfg = *cfg;
@@ -735,6 +874,8 @@ extern "C" int evfly_model_finalize(evfly_model *m) {
     EVFLY_REQUIRE(m && !m->finalized, "finalize: bad handle");
     if (m->cfg.has_unet)
         if (int rc = pack_unet(m)) return rc;
+    if (m->cfg.velpred > 0)
+        if (int rc = pack_velpred(m)) return rc;
     bool any_vit = false;
     for (auto &kv : m->host) any_vit |= kv.first.find("encoder_blocks.") != std::string::npos;
     if (m->cfg.head != EVFLY_HEAD_NONE || any_vit)

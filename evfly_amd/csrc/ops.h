@@ -8,6 +8,11 @@ namespace evfly {
 int launch_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff,
                const float *w_packed /*[9*cin][32]*/, const float *bias, float *y, hipStream_t st);
 int launch_maxpool2x2(const float *x, int n, int H, int W, int C, float *y, hipStream_t st);
+// nn.MaxPool2d / nn.AvgPool2d (k, s, no padding, floor mode) of DynamicConvNet (learner_models.py:81-84); negate != 0
+// pools -x (the surviving InvertLayer of :77-92). type: 1 max (NaN-propagating), 2 avg
+int launch_pool2d(const float *x, int n, int H, int W, int C, int k, int s, int type, int negate, float *y, hipStream_t st);
+// VelPredictor tail for num_out == 1 (learner_models.py:326-336): vel = [sqrt(clip(1 - y*y, 0, 1)), y, 0]
+int launch_velpred_vec(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st);
 // bilinear resize (F.interpolate / nn.Upsample); y pixel stride ldy, written at channel offset 0 of y.
 // pre: 0 none, 1 clip(2*v, 0, 1) applied to every source sample (learner_models.py:634)
 int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, float *y, int Ho, int Wo, int64_t ldy,

@@ -96,6 +96,41 @@ __global__ __launch_bounds__(256) void k_maxpool2x2(const float4 *__restrict__ x
     }
 }
 
+// generic k x k / stride s pooling of the velpred encoder (tiny tensors: one thread per output element)
+__global__ __launch_bounds__(256) void k_pool2d(const float *__restrict__ x, int n, int H, int W, int C, int k, int s, int OH,
+                                                int OW, int type, int negate, float *__restrict__ y) {
+    const int64_t total = (int64_t)n * OH * OW * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int ox = (int)(p % OW); p /= OW;
+        const int oy = (int)(p % OH);
+        const int img = (int)(p / OH);
+        const float *src = x + (((int64_t)img * H + (int64_t)oy * s) * W + (int64_t)ox * s) * C + c;
+        float acc = type == 1 ? -INFINITY : 0.f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                float v = src[((int64_t)dy * W + dx) * C];
+                if (negate) v = -v;
+                if (type == 1) acc = (v > acc || v != v) ? v : acc;   // NaN-propagating like ATen max_pool2d
+                else acc += v;
+            }
+        y[i] = type == 1 ? acc : acc / (float)(k * k);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_velpred_vec(const float *__restrict__ y, int64_t rows, int64_t ldy,
+                                                     float *__restrict__ vel) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float v = y[r * ldy];
+    float rad = 1.0f - v * v;
+    rad = rad < 0.f ? 0.f : (rad > 1.f ? 1.f : rad);   // NaN stays NaN
+    vel[r * 3 + 0] = sqrtf(rad);
+    vel[r * 3 + 1] = v;
+    vel[r * 3 + 2] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------ bilinear
 // ATen upsample_bilinear2d (aten/src/ATen/native/UpSample.h area_pixel_compute_* + cpu/UpSampleKernel.cpp):
 // fp32 scale, source index, lambdas; result = wh0*(ww0*v00 + ww1*v01) + wh1*(ww0*v10 + ww1*v11).
@@ -496,6 +531,21 @@ int launch_maxpool2x2(const float *x, int n, int H, int W, int C, float *y, hipS
     const int64_t work = (int64_t)n * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(k_maxpool2x2, dim3(grid_for(work, 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(x), n, H, W,
                        C / 4, reinterpret_cast<float4 *>(y));
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pool2d(const float *x, int n, int H, int W, int C, int k, int s, int type, int negate, float *y, hipStream_t st) {
+    EVFLY_REQUIRE(k >= 1 && s >= 1 && H >= k && W >= k && (type == 1 || type == 2), "pool2d: bad geometry %dx%d k%d s%d", H, W, k, s);
+    const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
+    const int64_t work = (int64_t)n * OH * OW * C;
+    hipLaunchKernelGGL(k_pool2d, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, H, W, C, k, s, OH, OW, type, negate, y);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_velpred_vec(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st) {
+    hipLaunchKernelGGL(k_velpred_vec, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, y, rows, ldy, vel);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

@@ -18,6 +18,137 @@ from ._hipmodule import HipModule, to_gpu
 from .ConvLSTM_pytorch.convlstm import ConvLSTM
 
 _SKIP = {"crop": 0, "interp": 1, "none": 2}
+_ACTS = {'relu': nn.ReLU, 'sigmoid': nn.Sigmoid, 'tanh': nn.Tanh, 'leaky_relu': nn.LeakyReLU}
+
+
+def _never_run(name):
+    def forward(self, *a, **k):
+        raise NotImplementedError(f"{name} is a parameter container; it runs inside OrigUNet's native forward "
+                                  f"(evfly_unet_forward, include/evfly_hip.h). There is no CPU path.")
+    return forward
+
+
+class InvertLayer(nn.Module):
+    """learner/learner_models.py:14-16."""
+    forward = _never_run("InvertLayer")
+
+
+class DynamicConvNet(nn.Module):
+    """learner/learner_models.py:18-98: conv(bias=False) + BatchNorm2d + activation (+ invert) + pool per layer,
+    same child names (`layers.conv2d_i`, `layers.batchnorm_i`, ...) so checkpoints load by key. Like the
+    reference, both InvertLayers of a layer are registered as `invert_i`; the second registration replaces the
+    first in place, so one negation - in front of the pool - survives."""
+
+    def __init__(self, in_channels, num_layers, kernel_sizes, kernel_strides, out_channels, activations,
+                 pool_type='max', pool_kernels=None, pool_strides=None, conv_function='conv2d', device=None,
+                 logger=None, invert_pool_input=False):
+        super().__init__()
+        mylogger = logger if logger is not None else print
+        self.layers = nn.Sequential()
+        assert len(kernel_sizes) == num_layers, "The length of kernel_sizes should match num_layers"
+        assert len(kernel_strides) == num_layers, "The length of kernel_strides should match num_layers"
+        assert len(out_channels) == num_layers, "The length of out_channels should match num_layers"
+        assert len(activations) == num_layers, "The length of activations should match num_layers"
+        if pool_kernels is None:
+            pool_kernels = [2] * num_layers
+        if pool_strides is None:
+            pool_strides = [2] * num_layers
+        if conv_function == 'upconv2d':
+            raise NotImplementedError("conv_function upconv2d is not built (no shipped config uses it)")
+        if conv_function != 'conv2d':
+            raise NotImplementedError(f'conv_function {conv_function} not implemented. Either use conv2d or upconv2d.')
+        if pool_type not in _lib.POOL_CODES:
+            raise NotImplementedError(f'pool_type {pool_type} not implemented. Either use max or avg.')
+        cur = in_channels
+        for i in range(num_layers):
+            self.layers.add_module(f'{conv_function}_{i}', nn.Conv2d(cur, out_channels[i], kernel_size=kernel_sizes[i],
+                                                                     stride=kernel_strides[i], bias=False))
+            self.layers.add_module(f'batchnorm_{i}', nn.BatchNorm2d(out_channels[i]))
+            if activations[i] in _ACTS:
+                self.layers.add_module(f'activation_{i}', _ACTS[activations[i]]())
+            elif activations[i] != 'none':
+                raise NotImplementedError(f'activation {activations[i]} not implemented. Either use relu, sigmoid, '
+                                          f'tanh, or leaky_relu.')
+            if invert_pool_input:
+                self.layers.add_module(f'invert_{i}', InvertLayer())
+            if pool_type == 'max':
+                self.layers.add_module(f'pool_{i}', nn.MaxPool2d(kernel_size=pool_kernels[i], stride=pool_strides[i]))
+            elif pool_type == 'avg':
+                self.layers.add_module(f'pool_{i}', nn.AvgPool2d(kernel_size=pool_kernels[i], stride=pool_strides[i]))
+            if invert_pool_input:
+                self.layers.add_module(f'invert_{i}', InvertLayer())
+            cur = out_channels[i]
+        self.spec = dict(in_channels=in_channels, num_layers=num_layers, kernel_sizes=list(kernel_sizes),
+                         kernel_strides=list(kernel_strides), out_channels=list(out_channels),
+                         activations=list(activations), pool_type=pool_type, pool_kernels=list(pool_kernels),
+                         pool_strides=list(pool_strides), invert=bool(invert_pool_input))
+        mylogger(f'[DynamicConvNet] Initialized DynamicConvNet with in_channels={in_channels}, '
+                 f'num_layers={num_layers}, kernel_sizes={kernel_sizes}, kernel_strides={kernel_strides}, '
+                 f'out_channels={out_channels}, activations={activations}, pool_type={pool_type}, '
+                 f'pool_kernels={pool_kernels}, pool_strides={pool_strides}, conv_function={conv_function}')
+
+    def out_shape(self, h, w):
+        """(C, H, W) after the stack for an (h, w) input: the arithmetic of find_output_size (:8-12)."""
+        sp = self.spec
+        c = sp['in_channels']
+        for i in range(sp['num_layers']):
+            h = (h - sp['kernel_sizes'][i]) // sp['kernel_strides'][i] + 1
+            w = (w - sp['kernel_sizes'][i]) // sp['kernel_strides'][i] + 1
+            if sp['pool_type'] != 'none':
+                h = (h - sp['pool_kernels'][i]) // sp['pool_strides'][i] + 1
+                w = (w - sp['pool_kernels'][i]) // sp['pool_strides'][i] + 1
+            c = sp['out_channels'][i]
+            if h < 1 or w < 1:
+                raise ValueError(f'[DynamicConvNet] layer {i} shrinks the input to nothing')
+        return c, h, w
+
+    forward = _never_run("DynamicConvNet")
+
+
+class DynamicFCNet(nn.Module):
+    """learner/learner_models.py:100-145 (Dropout is the identity in eval; the containers keep its child name)."""
+
+    def __init__(self, input_features, num_layers, layer_sizes, activations, dropout_p=None, device=None, logger=None):
+        super().__init__()
+        mylogger = logger if logger is not None else print
+        self.layers = nn.Sequential()
+        assert len(layer_sizes) == num_layers, "The length of layer_sizes should match num_layers"
+        assert len(activations) == num_layers, "The length of activations should match num_layers"
+        cur = input_features
+        for i, layer_size in enumerate(layer_sizes):
+            self.layers.add_module(f'fc_{i}', nn.Linear(cur, layer_size))
+            if dropout_p is not None and dropout_p > 0:
+                self.layers.add_module(f'dropout_{i}', nn.Dropout(p=dropout_p))
+            if activations[i] not in _ACTS:
+                raise NotImplementedError(f'activation {activations[i]} not implemented. Either use relu, sigmoid, '
+                                          f'tanh, or leaky_relu.')
+            self.layers.add_module(f'activation_{i}', _ACTS[activations[i]]())
+            cur = layer_size
+        self.spec = dict(num_layers=num_layers, layer_sizes=list(layer_sizes), activations=list(activations))
+        mylogger(f'[DynamicFCNet] Initialized DynamicFCNet with input_features={input_features}, '
+                 f'num_layers={num_layers}, layer_sizes={layer_sizes}, activations={activations}, dropout_p={dropout_p}')
+
+    forward = _never_run("DynamicFCNet")
+
+
+class VelPredictor(nn.Module):
+    """learner/learner_models.py:272-336."""
+
+    def __init__(self, fc_params=None, input_size=512, num_out=3, device=None, logger=None):
+        super().__init__()
+        self.mylogger = logger if logger is not None else print
+        self.input_size = input_size
+        self.num_out = num_out
+        self.device = device
+        self.mylogger(f'[VelPredictor] Initializing VelPredictor with input_size={input_size} and num_out={num_out}')
+        if fc_params is None:
+            fc_params = {'num_layers': 3, 'layer_sizes': [128, 32, num_out],
+                         'activations': ['leaky_relu', 'leaky_relu', 'tanh'], 'dropout_p': 0.1}
+        self.fcnet = DynamicFCNet(input_features=input_size, num_layers=fc_params['num_layers'],
+                                  layer_sizes=fc_params['layer_sizes'], activations=fc_params['activations'],
+                                  dropout_p=fc_params['dropout_p'], logger=logger, device=device)
+
+    forward = _never_run("VelPredictor")
 
 
 class OrigUNet(HipModule):
@@ -94,9 +225,32 @@ class OrigUNet(HipModule):
                 raise NotImplementedError("only one ConvLSTM layer is built (every shipped config uses 1)")
             self.lstm = ConvLSTM(input_dim=512, hidden_dim=[512] * self._nrec[0], num_layers=self._nrec[0],
                                  kernel_size=(1, 1), bias=False, batch_first=True, return_all_layers=False)
-        if self.velpred > 0:
-            raise NotImplementedError("velpred heads (learner_models.py:426-472, sim config only) are a "
-                                      "'next' row of SURVEY.md §8f and not built yet")
+        if self.velpred > 0:                                                 # :426-472
+            if self.velpred not in (1, 11, 2):
+                raise ValueError(f'velpred should be 0/1/11/2, but is {self.velpred}')
+            mylogger(f'[OrigUNet] self.velpred == {self.velpred}; Using velocity predictor with a ConvNet encoder '
+                     f'and FC head.')
+            in_shape = {1: (1, self.input_h, self.input_w), 11: self.decoded_shape[1:], 2: self.middle_shape[1:]}
+            cin, vh, vw = in_shape[self.velpred]
+            self.convnet_velpred = DynamicConvNet(
+                in_channels=cin, num_layers=enc_params['num_layers'], kernel_sizes=enc_params['kernel_sizes'],
+                kernel_strides=enc_params['kernel_strides'], out_channels=enc_params['out_channels'],
+                activations=enc_params['activations'], pool_type=enc_params['pool_type'],
+                pool_kernels=enc_params['pool_kernels'], pool_strides=enc_params['pool_strides'],
+                conv_function=enc_params['conv_function'], invert_pool_input=enc_params['invert_pool_inputs'],
+                logger=mylogger, device=device)
+            mylogger(f'[OrigUNet] Input size to velpred: {[1, cin, vh, vw]}')
+            oc, oh, ow = self.convnet_velpred.out_shape(vh, vw)
+            self.convnet_velpred_outsize = torch.Size([1, oc, oh, ow])
+            mylogger(f'[OrigUNet] Calculated self.convnet_velpred_outsize = {self.convnet_velpred_outsize}')
+            if self._nrec[1] > 0:
+                raise NotImplementedError("lstm_velpred (num_recurrent[1] > 0, :457-459) is not built: every shipped "
+                                          "config sets num_recurrent = [1, 0]")
+            self.velpred_head = VelPredictor(fc_params=fc_params, input_size=oc * oh * ow, num_out=1, device=device,
+                                             logger=mylogger)
+            if self.velpred_head.fcnet.spec['layer_sizes'][-1] != 1:
+                raise NotImplementedError("velpred_head is constructed with num_out=1 (:462); a last fc layer size "
+                                          "other than 1 is not built")
 
     # ---- native handle
     def _hip_config(self, c=None):
@@ -110,6 +264,25 @@ class OrigUNet(HipModule):
         c.input_h, c.input_w = self.input_h, self.input_w
         c.evs_min_cutoff = float(self.evs_min_cutoff)
         c.compute_dtype = self.compute_dtype
+        c.velpred = self.velpred
+        if self.velpred > 0:
+            sp, fp = self.convnet_velpred.spec, self.velpred_head.fcnet.spec
+            if sp['num_layers'] > 4 or fp['num_layers'] > 8:
+                raise NotImplementedError("velpred: at most 4 encoder and 8 fc layers (include/evfly_hip.h)")
+            c.enc_num_layers = sp['num_layers']
+            for i in range(sp['num_layers']):
+                c.enc_kernel[i] = sp['kernel_sizes'][i]
+                c.enc_stride[i] = sp['kernel_strides'][i]
+                c.enc_out_channels[i] = sp['out_channels'][i]
+                c.enc_act[i] = _lib.ACT_CODES[sp['activations'][i]]
+                c.enc_pool_kernel[i] = sp['pool_kernels'][i]
+                c.enc_pool_stride[i] = sp['pool_strides'][i]
+            c.enc_pool_type = _lib.POOL_CODES[sp['pool_type']]
+            c.enc_invert_pool_inputs = int(sp['invert'])
+            c.fc_num_layers = fp['num_layers']
+            for i in range(fp['num_layers']):
+                c.fc_size[i] = fp['layer_sizes'][i]
+                c.fc_act[i] = _lib.ACT_CODES[fp['activations'][i]]
         return c
 
     @staticmethod
@@ -136,10 +309,12 @@ class OrigUNet(HipModule):
             h, c = self._state_in(state, n_streams, x.device)
         depth = torch.empty(n, 1, self.input_h, self.input_w, device=x.device)
         upconv = torch.empty(n, 1, 68, 148, device=x.device)
+        yvel = torch.empty(n, 3, device=x.device) if self.velpred > 0 else None
         L = _lib.lib()
         _lib.check(L.evfly_unet_forward(self.hip().h, _lib.ptr(x), n_streams, T, _lib.ptr(h), _lib.ptr(c),
-                                        _lib.ptr(depth), _lib.ptr(upconv), _lib.cur_stream()))
+                                        _lib.ptr(depth), _lib.ptr(upconv), _lib.ptr(yvel), _lib.cur_stream()))
         h_unet = self._state_out(h, c, dev) if h is not None else None
+        self.__dict__["_last_yvel"] = yvel.to(dev) if yvel is not None else None
         return depth.to(dev), upconv.to(dev), h_unet
 
     def forward(self, x):
@@ -152,11 +327,18 @@ class OrigUNet(HipModule):
             raise NotImplementedError("is_deployment=True skips the decoder (:553); evfly_ros/run.py passes False")
         y_interp, y_upconv, h_unet = self._run(frames, x[2][0], 1, frames.shape[0])
         y_vel = torch.Tensor([1., 0., 0.]).repeat(frames.shape[0], 1)               # :590-591
+        if self.velpred > 0:                                                        # :593-614
+            y_vel = self.__dict__["_last_yvel"]
         return y_vel, (y_interp, y_upconv, (h_unet, None))
 
     def forward_streams(self, frames, state, n_streams, T):
-        """Throughput entry: frames laid out [stream][t]; state [[h, c]] each (n_streams,512,8,13)."""
+        """Throughput entry: frames laid out [stream][t]; state [[h, c]] each (n_streams,512,8,13).
+        With velpred > 0 the (n_streams*T, 3) y_vel rows are left in `self.last_yvel`."""
         return self._run(frames, state, n_streams, T)
+
+    @property
+    def last_yvel(self):
+        return self.__dict__.get("_last_yvel")
 
 
 class OrigUNet_w_VITFLY_ViTLSTM(HipModule):

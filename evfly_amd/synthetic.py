@@ -72,6 +72,10 @@ def fill_tensor(name, shape):
     rs = np.random.RandomState(zlib.crc32(name.encode()) & 0xFFFFFFFF)
     shape = tuple(int(s) for s in shape)
     leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":          # BatchNorm2d bookkeeping buffer (int64 scalar, unused in eval)
+        return np.asarray(100, dtype=np.int64)
+    if leaf == "running_var":                  # BatchNorm2d running variance: strictly positive
+        return (0.5 + rs.random_sample(shape)).astype(np.float32)
     if leaf in ("weight_u", "weight_v"):
         v = rs.standard_normal(shape)
         return (v / np.linalg.norm(v)).astype(np.float32)
@@ -125,3 +129,28 @@ def make_u8_frames(seed, n, H=480, W=640, rate=0.35):
     rs = np.random.RandomState(seed)
     k = rs.poisson(rate, (n, H, W)).astype(np.int32) - rs.poisson(rate, (n, H, W)).astype(np.int32)
     return ((128 + k) & 0xFF).astype(np.uint8)
+
+
+# OrigUNet velpred-head configurations used by the G9 golden and its parity tests. "sim" is
+# learner/configs/eval_config_sim_joint.txt:41-73 verbatim; the other two exercise velpred 1 / 2, avg / no
+# pooling, every activation code and the no-invert path.
+VELPRED_CASES = {
+    "sim": dict(velpred=11,
+                enc_params=dict(num_layers=2, kernel_sizes=[5, 3], kernel_strides=[2, 2], out_channels=[8, 32],
+                                activations=["relu", "relu"], pool_type="max", pool_kernels=[2, 2],
+                                pool_strides=[2, 2], conv_function="conv2d", invert_pool_inputs=True),
+                fc_params=dict(num_layers=4, layer_sizes=[1024, 128, 16, 1],
+                               activations=["leaky_relu", "leaky_relu", "leaky_relu", "tanh"], dropout_p=0.1)),
+    "interp_avg": dict(velpred=1,
+                       enc_params=dict(num_layers=2, kernel_sizes=[7, 5], kernel_strides=[4, 2], out_channels=[4, 8],
+                                       activations=["tanh", "leaky_relu"], pool_type="avg", pool_kernels=[2, 3],
+                                       pool_strides=[2, 2], conv_function="conv2d", invert_pool_inputs=False),
+                       fc_params=dict(num_layers=2, layer_sizes=[32, 1], activations=["sigmoid", "tanh"],
+                                      dropout_p=0.0)),
+    "e5_nopool": dict(velpred=2,
+                      enc_params=dict(num_layers=1, kernel_sizes=[3], kernel_strides=[1], out_channels=[16],
+                                      activations=["none"], pool_type="none", pool_kernels=[2], pool_strides=[2],
+                                      conv_function="conv2d", invert_pool_inputs=True),
+                      fc_params=dict(num_layers=2, layer_sizes=[8, 1], activations=["relu", "tanh"],
+                                     dropout_p=0.1)),
+}

@@ -144,7 +144,31 @@ typedef struct evfly_model_config {
     int vit_patch[2], vit_stride[2], vit_pad[2]; /* {7,3} {4,2} {3,1} */
     int vit_expansion;     /* 8 */
     int compute_dtype;     /* EVFLY_DTYPE_* */
+    /* OrigUNet velocity-prediction head (velpred > 0, learner/learner_models.py:426-472, 589-616):
+     * DynamicConvNet (:18-98, conv(bias=False) + BatchNorm2d(eval) + activation + pool, with the
+     * enc_invert_pool_inputs quirk: both InvertLayers are registered under one name, so exactly one
+     * negation - before the pool - survives) -> flatten -> DynamicFCNet (:100-145) -> VelPredictor
+     * with num_out = 1 (:326-336): vel = [sqrt(clip(1 - y^2, 0, 1)), y, 0]. */
+    int velpred;           /* 0 none | 1 on y_interp | 11 on y_upconv | 2 on y_e5 (:593-603) */
+    int enc_num_layers;    /* <= EVFLY_MAX_ENC_LAYERS */
+    int enc_kernel[4], enc_stride[4], enc_out_channels[4], enc_act[4]; /* EVFLY_ACT_* */
+    int enc_pool_type;     /* EVFLY_POOL_* */
+    int enc_pool_kernel[4], enc_pool_stride[4];
+    int enc_invert_pool_inputs;
+    int fc_num_layers;     /* <= EVFLY_MAX_FC_LAYERS; the last layer size must be 1 */
+    int fc_size[8], fc_act[8];
 } evfly_model_config;
+
+#define EVFLY_MAX_ENC_LAYERS 4
+#define EVFLY_MAX_FC_LAYERS 8
+#define EVFLY_ACT_NONE 0
+#define EVFLY_ACT_RELU 1
+#define EVFLY_ACT_LEAKY 2   /* nn.LeakyReLU() default slope 0.01 */
+#define EVFLY_ACT_TANH 3
+#define EVFLY_ACT_SIGMOID 4
+#define EVFLY_POOL_NONE 0
+#define EVFLY_POOL_MAX 1
+#define EVFLY_POOL_AVG 2
 
 /* Replaces the module constructors + load_state_dict + .eval() (evfly_ros/run.py:106-171).
  * Tensors are handed over by their reference state-dict key (SURVEY.md §8b "State-dict keys"),
@@ -166,10 +190,13 @@ void evfly_model_destroy(evfly_model *m);
  * h_state / c_state: (n_streams, 8, 13, 512) NHWC ConvLSTM state, read and updated in place; NULL =
  * start from zeros and discard. depth_out (n_streams*T, input_h, input_w) = y_interp,
  * upconv_out (n_streams*T, 68, 148) = y_upconv; either may be NULL. Does not modify `frames`
- * (the reference mutates its input in place, learner_models.py:477). */
+ * (the reference mutates its input in place, learner_models.py:477).
+ * yvel_out (n_streams*T, 3) = y_vel of the velpred head (:589-616); required when the handle was
+ * created with velpred > 0, ignored (may be NULL) otherwise - the constant [1,0,0] rows of :590-591
+ * are the host mirror's business. */
 int evfly_unet_forward(evfly_model *m, const float *frames, int n_streams, int T,
                        float *h_state, float *c_state, float *depth_out, float *upconv_out,
-                       void *stream);
+                       float *yvel_out, void *stream);
 
 /* Replaces LSTMNetVIT.forward learner/vitfly_models.py:132-150 / ViT.forward :170-186, including
  * refine_inputs :18-31. img: (n_streams*T, img_h, img_w) depth images (bilinearly resized to 60x90

@@ -86,10 +86,54 @@ def _skip(y, big, small, skip_type):
     raise ValueError(skip_type)
 
 
+_ACT = {"relu": F.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "leaky_relu": F.leaky_relu, "none": None}
+
+
+def dynamic_convnet_forward(sd, stem, x, enc):
+    """learner/learner_models.py:18-98 in eval mode. Per layer: conv(bias=False) -> BatchNorm2d(running stats)
+    -> activation -> [InvertLayer] -> pool. The reference registers both of a layer's InvertLayers under the
+    same name `invert_i` (:77, :92); nn.Module.add_module keeps the FIRST position for a re-used name, so exactly
+    one negation, in front of the pool, is executed."""
+    for i in range(enc["num_layers"]):
+        x = F.conv2d(x, _p(sd, f"{stem}layers.conv2d_{i}.weight"), None, stride=enc["kernel_strides"][i])
+        bn = f"{stem}layers.batchnorm_{i}."
+        x = F.batch_norm(x, _p(sd, bn + "running_mean"), _p(sd, bn + "running_var"), _p(sd, bn + "weight"),
+                         _p(sd, bn + "bias"), training=False, eps=1e-5)
+        act = _ACT[enc["activations"][i]]
+        if act is not None:
+            x = act(x)
+        if enc["invert_pool_inputs"]:
+            x = -x
+        pk = (enc.get("pool_kernels") or [2] * enc["num_layers"])[i]
+        ps = (enc.get("pool_strides") or [2] * enc["num_layers"])[i]
+        if enc["pool_type"] == "max":
+            x = F.max_pool2d(x, pk, ps)
+        elif enc["pool_type"] == "avg":
+            x = F.avg_pool2d(x, pk, ps)
+    return x
+
+
+def dynamic_fcnet_forward(sd, stem, x, fc):
+    """learner/learner_models.py:100-145 in eval mode (Dropout = identity)."""
+    for i in range(fc["num_layers"]):
+        x = _ACT[fc["activations"][i]](F.linear(x, _p(sd, f"{stem}layers.fc_{i}.weight"),
+                                                _p(sd, f"{stem}layers.fc_{i}.bias")))
+    return x
+
+
+def velpredictor_forward(sd, stem, x, fc):
+    """learner/learner_models.py:303-336 with num_out == 1 (how OrigUNet builds it, :462)."""
+    y = dynamic_fcnet_forward(sd, stem + "fcnet.", torch.flatten(x, 1), fc)
+    rad = 1.0 - y ** 2
+    if (rad < 0).any():
+        rad = torch.clip(rad, 0.0, 1.0)
+    return torch.cat((torch.sqrt(rad), y, torch.zeros(y.shape[0], 1)), dim=1)
+
+
 def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff=0.15,
                      skip_type="interp", num_recurrent=(1, 0), input_hw=(260, 346), num_in_channels=2,
-                     return_taps=False):
-    """learner/learner_models.py:521-616 with velpred=0, is_deployment=False.
+                     return_taps=False, velpred=0, enc_params=None, fc_params=None):
+    """learner/learner_models.py:521-616 with is_deployment=False (velpred 0 / 1 / 11 / 2, no lstm_velpred).
     x: (T,1,260,346) float32 conditioned frames = consecutive steps of one stream.
     Returns y_vel, (y_interp, y_upconv, (h_unet, None))."""
     from .conditioning import form_input
@@ -122,6 +166,11 @@ def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff
     y_upconv = _conv(sd, P + "unet_out.", y)                                        # :583
     y_interp = F.interpolate(y_upconv, size=input_hw, mode="bilinear", align_corners=False)  # :497
     y_vel = torch.tensor([1., 0., 0.]).repeat(x.shape[0], 1)                        # :590-591
+    if velpred > 0:                                                                 # :593-614
+        src = {1: y_interp, 11: y_upconv, 2: y_e5}[velpred]
+        enc = dynamic_convnet_forward(sd, P + "convnet_velpred.", src, enc_params)
+        taps["velpred_enc"] = enc
+        y_vel = velpredictor_forward(sd, P + "velpred_head.", enc, fc_params)
     out = (y_vel, (y_interp, y_upconv, (h_unet, None)))
     return (out, taps) if return_taps else out
 

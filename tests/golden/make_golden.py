@@ -264,6 +264,27 @@ def g8():
          vel_batch=v3.numpy(), depth_last=d.numpy(), lstm_h=h_vit[0].numpy(), lstm_c=h_vit[1].numpy())
 
 
+# ------------------------------------------------------------------ G9: OrigUNet velpred heads (A13 / N4)
+def g9():
+    from evfly_amd.synthetic import VELPRED_CASES
+    out = {}
+    x = cond_frames(90, 2)
+    for tag, case in VELPRED_CASES.items():
+        net = ref_lm.OrigUNet(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346],
+                              velpred=case["velpred"], enc_params=case["enc_params"], fc_params=case["fc_params"],
+                              evs_min_cutoff=0.15, skip_type="interp", form_BEV=2, logger=lambda *a: None).eval()
+        net.load_state_dict(syn.fill_state_dict(net, "origunet."))
+        feats = {}
+        net.convnet_velpred.register_forward_hook(lambda m, i, o: feats.__setitem__("enc", o.detach().clone()))
+        with torch.no_grad():
+            y_vel, (y_interp, y_upconv, _) = net([x.clone(), None, None])
+        out[f"{tag}_vel"] = y_vel.numpy()
+        out[f"{tag}_enc"] = feats["enc"].numpy()
+        out[f"{tag}_upconv_sum"] = np.float64(y_upconv.double().sum().item())
+        out[f"{tag}_keys"] = np.array(sorted(k for k in net.state_dict() if "velpred" in k))
+    save("g9_velpred", **out)
+
+
 # ------------------------------------------------------------------ G0: state-dict key inventory
 def g0():
     import json
@@ -283,7 +304,7 @@ def g0():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     with torch.no_grad():
         for g in which:
             globals()[g]()

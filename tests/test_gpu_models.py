@@ -168,6 +168,49 @@ def test_origunet_norec_and_statefulness(gpu_device):
     assert rel_err(st1[0][1].cpu(), st01[0][1].cpu()) < 1e-5
 
 
+# ------------------------------------------------------------------ G9 velpred heads (A13)
+@pytest.mark.parametrize("tag", list(syn.VELPRED_CASES))
+def test_origunet_velpred_vs_golden(gpu_device, tag):
+    g = golden("g9_velpred")
+    case = syn.VELPRED_CASES[tag]
+    net, sd = _unet(gpu_device, **case)
+    x = cond_frames(90, 2)
+    y_vel, (y_interp, y_upconv, (h_unet, h_vp)) = net([x.clone().to(gpu_device), None, None])
+    assert y_vel.shape == (2, 3) and h_vp is None
+    got = net.hip().tap("velpred_enc").permute(0, 3, 1, 2)
+    assert rel_err(got, g[f"{tag}_enc"]) < TOL
+    assert rel_err(y_vel.cpu(), g[f"{tag}_vel"]) < TOL
+    assert torch.all(y_vel[:, 2] == 0)
+    # oracle on the same inputs (also pins the FC flatten-order permutation)
+    (o_vel, _), taps = om.origunet_forward(sd, x, None, return_taps=True, **case)
+    assert rel_err(y_vel.cpu(), o_vel) < TOL
+    # stream-batched entry: 2 streams x 1 step == the two frames run as independent streams
+    net.forward_streams(x.clone().to(gpu_device), None, 2, 1)
+    v2 = net.last_yvel
+    for i in range(2):
+        o_i, _ = om.origunet_forward(sd, x[i:i + 1], None, **case)
+        assert rel_err(v2[i:i + 1].cpu(), o_i) < TOL
+
+
+def test_velpred_errors(gpu_device):
+    from evfly_amd import _lib
+    case = syn.VELPRED_CASES["sim"]
+    net, sd = _unet(gpu_device, **case)
+    x = cond_frames(90, 1).to(gpu_device).reshape(1, 260, 346).contiguous()
+    L = _lib.lib()
+    depth = torch.empty(1, 260, 346, device=gpu_device)
+    h = torch.zeros(1, 8, 13, 512, device=gpu_device); c = torch.zeros_like(h)
+    rc = L.evfly_unet_forward(net.hip().h, _lib.ptr(x), 1, 1, _lib.ptr(h), _lib.ptr(c), _lib.ptr(depth), None, None,
+                              _lib.cur_stream())
+    assert rc < 0 and b"yvel_out" in L.evfly_last_error()
+    # a checkpoint without the BatchNorm statistics is refused at finalize, by key
+    sd2 = {k: v for k, v in sd.items() if "running_var" not in k}
+    net.load_state_dict(sd2, strict=False)
+    from evfly_amd._hipmodule import HipHandle
+    with pytest.raises(RuntimeError, match="DynamicConvNet"):
+        HipHandle(net._hip_config(), sd2)
+
+
 # ------------------------------------------------------------------ G8 composite, run.py pattern
 def _composite(dev, dtype="f32"):
     import evfly_amd.learner_models as lm

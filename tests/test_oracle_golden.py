@@ -201,6 +201,41 @@ def test_origunet_norec():
     assert h is None and rel_err(y_upconv, g["norec_upconv"]) < TOL
 
 
+# ------------------------------------------------------------------ G9 velpred heads (A13)
+@pytest.mark.parametrize("tag", list(syn.VELPRED_CASES))
+def test_origunet_velpred(tag):
+    g = golden("g9_velpred")
+    case = syn.VELPRED_CASES[tag]
+    import evfly_amd.learner_models as lm
+    m = lm.OrigUNet(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346],
+                    evs_min_cutoff=0.15, skip_type="interp", form_BEV=2, logger=lambda *a: None, **case)
+    # the shell registers the reference's velpred state-dict keys (BatchNorm buffers included)
+    assert sorted(k for k in m.state_dict() if "velpred" in k) == list(g[f"{tag}_keys"])
+    sd = syn.fill_state_dict(m.state_dict(), "origunet.")
+    x = cond_frames(90, 2)
+    (y_vel, (_, y_upconv, _)), taps = om.origunet_forward(sd, x, None, return_taps=True, **case)
+    assert abs(y_upconv.double().sum().item() - float(g[f"{tag}_upconv_sum"])) < 1e-4 * abs(float(g[f"{tag}_upconv_sum"]))
+    assert rel_err(taps["velpred_enc"], g[f"{tag}_enc"]) < TOL
+    assert rel_err(y_vel, g[f"{tag}_vel"]) < TOL
+    if tag == "sim":    # the invert quirk: features are max-pooled NEGATED relu outputs, never positive
+        assert float(taps["velpred_enc"].max()) <= 0.0
+
+
+def test_velpred_shell_errors():
+    import evfly_amd.learner_models as lm
+    case = syn.VELPRED_CASES["sim"]
+    base = dict(num_in_channels=2, num_out_channels=1, input_shape=[1, 1, 260, 346], logger=lambda *a: None)
+    with pytest.raises(NotImplementedError):       # lstm_velpred
+        lm.OrigUNet(num_recurrent=[1, 1], **base, **case)
+    with pytest.raises(ValueError):
+        lm.OrigUNet(num_recurrent=[1, 0], **base, **{**case, "velpred": 3})
+    bad = {**case, "enc_params": {**case["enc_params"], "conv_function": "upconv2d"}}
+    with pytest.raises(NotImplementedError):
+        lm.OrigUNet(num_recurrent=[1, 0], **base, **bad)
+    with pytest.raises(NotImplementedError):       # the containers never compute on the CPU
+        lm.DynamicFCNet(4, 1, [1], ["tanh"], logger=lambda *a: None)(torch.zeros(1, 4))
+
+
 # ------------------------------------------------------------------ G8 composite (run.py pattern)
 def test_composite_stateful():
     g = golden("g8_composite")
