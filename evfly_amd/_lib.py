@@ -51,6 +51,8 @@ SIGNATURES = {
     "evfly_accumulate_u8": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "evfly_accumulate_reset": (c_i, [c_p, c_i64, c_p]),
     "evfly_condition_frames": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "evfly_difflog_events": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p]),
+    "evfly_resize_bilinear": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "evfly_model_create": (c_i, [C.POINTER(ModelConfig), C.POINTER(c_p)]),
     "evfly_model_load_tensor": (c_i, [c_p, C.c_char_p, c_p, C.POINTER(c_i64), c_i]),
     "evfly_model_finalize": (c_i, [c_p]),

@@ -5,6 +5,7 @@
 // Replaces evfly_ros/run.py:334-336,345-350,247-253 (twins envtest/ros/run_competition.py:485-495,
 // learner/dataloading.py:512-523).
 #include "common.h"
+#include <algorithm>
 
 namespace evfly {
 namespace {
@@ -123,7 +124,85 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
 }  // namespace
 }  // namespace evfly
 
+// ------------------------------------------------------------------------------------------ difflog events
+// envtest/ros/run_competition.py:603-635 on float32 images (im_callback :984-985 makes them float32 / 255):
+//   difflog = log(im + 1e-5) - log(prev + 1e-5)                     float32 arithmetic
+//   all zeros when max|difflog| < max(pos, neg)                      (:626-627)
+//   d > 0: (d // pos) * pos ;  d < 0: (d // -neg) * -neg ;  else 0   (:630-633, numpy floor_divide)
+namespace {
+
+// float32 log, correctly rounded for all practical purposes (f64 log rounded once); numpy's own float32 log is a SIMD
+// polynomial within a few ulp of this and differs between CPUs.
+__device__ __forceinline__ float log_f32(float v) { return (float)log((double)v); }
+
+// numpy npy_floor_divide for float32 (numpy/core/src/npymath/npy_math_internal.h.src)
+__device__ __forceinline__ float np_floor_divide(float a, float b) {
+    if (b == 0.f) return a / b;
+    float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.f && ((b < 0.f) != (mod < 0.f))) div -= 1.0f;
+    if (div != 0.f) {
+        float fl = floorf(div);
+        if (div - fl > 0.5f) fl += 1.0f;
+        return fl;
+    }
+    return copysignf(0.f, a / b);
+}
+
+__global__ __launch_bounds__(256) void k_difflog(const float *__restrict__ im, const float *__restrict__ prev, int64_t npix,
+                                                 float *__restrict__ d_out, unsigned *__restrict__ maxbits) {
+    const int img = blockIdx.y;
+    const float eps = 1e-5f;
+    unsigned mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        const int64_t o = (int64_t)img * npix + i;
+        const float d = log_f32(im[o] + eps) - log_f32(prev[o] + eps);
+        d_out[o] = d;
+        const unsigned b = __float_as_uint(d) & 0x7fffffffu;      // |d| bits: monotone for finite values, NaN above all
+        mx = b > mx ? b : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) { unsigned o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxbits + img, mx);
+}
+
+__global__ __launch_bounds__(256) void k_difflog_quantize(float *__restrict__ ev, int64_t npix, float pos, float neg,
+                                                          const unsigned *__restrict__ maxbits) {
+    const int img = blockIdx.y;
+    const float mx = __uint_as_float(maxbits[img]);
+    const bool skip = mx < fmaxf(pos, neg);                        // NaN max: comparison false, like numpy
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        const int64_t o = (int64_t)img * npix + i;
+        const float d = ev[o];
+        float v = 0.f;
+        if (!skip) {
+            if (d > 0.f) v = np_floor_divide(d, pos) * pos;
+            else if (d < 0.f) v = np_floor_divide(d, -neg) * -neg;
+        }
+        ev[o] = v;
+    }
+}
+
+}  // namespace
+
 using namespace evfly;
+
+extern "C" int evfly_difflog_events(const float *im, const float *prev_im, int n, int height, int width, float pos_thresh,
+                                    float neg_thresh, float *events, void *stream) {
+    EVFLY_REQUIRE(im && prev_im && events && n > 0 && height > 0 && width > 0, "difflog_events: null or empty argument");
+    EVFLY_REQUIRE(pos_thresh > 0.f && neg_thresh > 0.f, "difflog_events: thresholds must be positive");
+    hipStream_t st = as_stream(stream);
+    void *mb = nullptr;
+    if (int rc = scratch_get((size_t)n * 4, &mb, 0)) return rc;
+    EVFLY_HIP(hipMemsetAsync(mb, 0, (size_t)n * 4, st));
+    const int64_t npix = (int64_t)height * width;
+    const unsigned gx = (unsigned)std::min<int64_t>((npix + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_difflog, dim3(gx, n), dim3(256), 0, st, im, prev_im, npix, events, static_cast<unsigned *>(mb));
+    EVFLY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_difflog_quantize, dim3(gx, n), dim3(256), 0, st, events, npix, pos_thresh, neg_thresh,
+                       static_cast<const unsigned *>(mb));
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int evfly_condition_frames(const uint8_t *src_u8, const float *src_f32, int n, int in_h, int in_w, int out_h,
                                       int out_w, float quantile, float *dst, float *q_out, void *stream) {

@@ -653,3 +653,10 @@ int launch_lstm(const float *xg0, int n_streams, int T, LstmWeights w, float *h_
 }
 
 }  // namespace evfly
+
+// ------------------------------------------------------------------------------------------ C ABI: standalone resize
+extern "C" int evfly_resize_bilinear(const float *src, int n, int in_h, int in_w, float *dst, int out_h, int out_w, void *stream) {
+    using namespace evfly;
+    EVFLY_REQUIRE(src && dst && n > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "resize_bilinear: null or empty argument");
+    return launch_bilinear(src, n, in_h, in_w, 1, 1, dst, out_h, out_w, 1, 0, 0, as_stream(stream));
+}

@@ -154,3 +154,17 @@ VELPRED_CASES = {
                       fc_params=dict(num_layers=2, layer_sizes=[8, 1], activations=["relu", "tanh"],
                                      dropout_p=0.1)),
 }
+
+
+def make_gray_pair(seed, H=120, W=160, change=0.25, identical=False, shift=True):
+    """Two consecutive uint8 gray images (smooth texture + a shifted copy with brightness change) as the simulator
+    camera would deliver them; the sim pilot converts them to float32 / 255 (run_competition.py:984-985)."""
+    rs = np.random.RandomState(seed)
+    base = rs.rand(H // 8 + 2, W // 8 + 2)
+    big = np.kron(base, np.ones((8, 8)))[:H + 8, :W + 8]
+    big = 0.1 + 0.45 * big + 0.45 * rs.rand(H + 8, W + 8)
+    a = big[:H, :W]
+    moved = big[2:H + 2, 3:W + 3] if shift else a
+    b = a if identical else moved * (1.0 + change * (rs.rand(H, W) - 0.5))
+    to8 = lambda v: np.clip(np.rint(v * 255), 0, 255).astype(np.uint8)
+    return to8(a), to8(b)

@@ -101,3 +101,31 @@ class EventAccumulator:
         out = self.img.clone()
         _lib.check(L.evfly_accumulate_reset(_lib.ptr(self.img), self.img.numel(), _lib.cur_stream()))
         return out
+
+
+def difflog_events(im, prev_im, pos_thresh=0.2, neg_thresh=0.2):
+    """Simulator event estimate from consecutive gray images (envtest/ros/run_competition.py:603-635):
+    im, prev_im (n, H, W) or (H, W) float32 in [0, 1] -> (n, H, W) float32 event frames on the device."""
+    L = _lib.lib()
+    a = torch.as_tensor(im).to("cuda", torch.float32)
+    b = torch.as_tensor(prev_im).to("cuda", torch.float32)
+    if a.shape != b.shape:
+        raise ValueError(f"difflog_events: image shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+    a = a.reshape(-1, a.shape[-2], a.shape[-1]).contiguous()
+    b = b.reshape(a.shape).contiguous()
+    out = torch.empty_like(a)
+    _lib.check(L.evfly_difflog_events(_lib.ptr(a), _lib.ptr(b), a.shape[0], a.shape[1], a.shape[2], float(pos_thresh),
+                                      float(neg_thresh), _lib.ptr(out), _lib.cur_stream()))
+    return out
+
+
+def resize_bilinear(frames, out_hw):
+    """F.interpolate(frames, size=out_hw, mode='bilinear', align_corners=False) for one-channel frames
+    (run_competition.py:487-488): (n, H, W) / (H, W) float32 -> (n, h, w) on the device."""
+    L = _lib.lib()
+    a = torch.as_tensor(frames).to("cuda", torch.float32)
+    a = a.reshape(-1, a.shape[-2], a.shape[-1]).contiguous()
+    out = torch.empty(a.shape[0], out_hw[0], out_hw[1], device=a.device)
+    _lib.check(L.evfly_resize_bilinear(_lib.ptr(a), a.shape[0], a.shape[1], a.shape[2], _lib.ptr(out), out_hw[0],
+                                       out_hw[1], _lib.cur_stream()))
+    return out

@@ -106,6 +106,23 @@ int evfly_condition_frames(const uint8_t *src_u8, const float *src_f32, int n, i
                            int out_h, int out_w, float quantile, float *dst, float *q_out,
                            void *stream);
 
+/* Replaces AgilePilotNode.compute_events envtest/ros/run_competition.py:603-635 (the simulator's event
+ * estimate from two consecutive gray images, float32 / 255 as im_callback :984-985 stores them), for n image
+ * pairs at once: difflog = log(im + 1e-5) - log(prev_im + 1e-5) in float32; a pair whose max |difflog| is below
+ * max(pos_thresh, neg_thresh) gives an all-zero frame (:626-627); otherwise positive pixels become
+ * (d // pos_thresh) * pos_thresh and negative ones (d // -neg_thresh) * -neg_thresh with numpy's float32
+ * floor_divide (:630-633). events (n, height, width) f32. The logarithm is the correctly rounded float32 one;
+ * numpy's SIMD float32 log is within a few ulp of it, so a pixel whose |difflog| sits within that distance of a
+ * multiple of the threshold can land one level away (tests/test_gpu_sim.py states the bar). */
+int evfly_difflog_events(const float *im, const float *prev_im, int n, int height, int width,
+                         float pos_thresh, float neg_thresh, float *events, void *stream);
+
+/* Replaces the F.interpolate(..., mode='bilinear', align_corners=False) calls that resize a one-channel
+ * frame to the model's input size (envtest/ros/run_competition.py:487-488, learner/vitfly_models.py:28-29):
+ * src (n, in_h, in_w) -> dst (n, out_h, out_w), ATen upsample_bilinear2d arithmetic in fp32. */
+int evfly_resize_bilinear(const float *src, int n, int in_h, int in_w, float *dst, int out_h, int out_w,
+                          void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Models
  * ---------------------------------------------------------------------------------------- */

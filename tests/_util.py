@@ -58,3 +58,34 @@ def filled_sd(kind):
 def rel_err(a, b):
     a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def difflog_cases():
+    """(tag, seed, thresholds, image-pair kwargs) of golden G10 (tests/golden/make_golden.py::g10)."""
+    return (("sym", 100, {}, {}),
+            ("asym", 101, dict(neg_thresh=0.3, pos_thresh=0.1), {}),
+            ("asym_quiet", 102, dict(neg_thresh=0.5, pos_thresh=0.01), dict(change=0.1, shift=False)),
+            ("identical", 103, {}, dict(identical=True)))
+
+
+def gray_pair_f32(seed, **kw):
+    a8, b8 = syn.make_gray_pair(seed, **kw)
+    return a8.astype(np.float32) / 255.0, b8.astype(np.float32) / 255.0     # prev_im, im
+
+
+def assert_difflog_parity(got, want, d, pos_thresh=0.2, neg_thresh=0.2, max_frac=1e-3, exact=True):
+    """The parity bar of evfly_difflog_events (include/evfly_hip.h): identical event levels, except that a pixel
+    whose |difflog| / threshold lies within 2e-5 of an integer may land on the neighbouring level (float32 log
+    implementations differ by a few ulp: numpy's SIMD log vs the correctly rounded one)."""
+    got = np.asarray(got, dtype=np.float64); want = np.asarray(want, dtype=np.float64); d = np.asarray(d, np.float64)
+    if exact:
+        bad = np.flatnonzero(got.reshape(-1) != want.reshape(-1))
+    else:   # float32 result vs the float64 arithmetic of the very first frame: same level, value to 1 ulp of float32
+        bad = np.flatnonzero(np.abs(got - want).reshape(-1) > 2.5e-7 * np.maximum(1.0, np.abs(want).reshape(-1)))
+    assert bad.size <= max_frac * got.size, f"{bad.size} of {got.size} pixels differ"
+    for i in bad:
+        di = d.reshape(-1)[i]
+        th = pos_thresh if di > 0 else neg_thresh
+        q = abs(di) / th
+        assert abs(q - round(q)) < 2e-5, f"pixel {i}: difflog {di} is not on a level boundary (q={q})"
+        assert abs(got.reshape(-1)[i] - want.reshape(-1)[i]) <= th * 1.0001, f"pixel {i}: off by more than one level"

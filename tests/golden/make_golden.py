@@ -285,6 +285,50 @@ def g9():
     save("g9_velpred", **out)
 
 
+# ------------------------------------------------------------------ G10: simulator difflog events (N4)
+def _reference_compute_events():
+    """run_competition.py imports rospy / cv_bridge at module level, so the module cannot be imported here. The
+    function under test is pure numpy: take its FunctionDef (and the SMALL_EPS assignment) out of the file with
+    `ast` and execute THAT code object -- the reference's own statements, from where they lie."""
+    import ast
+    path = os.path.join(REF, "envtest", "ros", "run_competition.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    eps = [n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "SMALL_EPS"]
+    fn = [n for c in tree.body if isinstance(c, ast.ClassDef) for n in c.body
+          if isinstance(n, ast.FunctionDef) and n.name == "compute_events"]
+    assert len(eps) == 1 and len(fn) == 1
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[eps[0], fn[0]], type_ignores=[]), path, "exec"), ns)
+    return ns["compute_events"]
+
+
+def g10():
+    from types import SimpleNamespace
+    ref_fn = _reference_compute_events()
+
+    def run(im, prev, **kw):
+        node = SimpleNamespace(im=im, prev_im=prev, image_h=im.shape[0], image_w=im.shape[1], events=None)
+        ref_fn(node, **kw)
+        return node.events
+
+    out = {}
+    for tag, seed, kw, pair_kw in (("sym", 100, {}, {}),
+                                   ("asym", 101, dict(neg_thresh=0.3, pos_thresh=0.1), {}),
+                                   ("asym_quiet", 102, dict(neg_thresh=0.5, pos_thresh=0.01), dict(change=0.1, shift=False)),
+                                   ("identical", 103, {}, dict(identical=True))):
+        a8, b8 = syn.make_gray_pair(seed, **pair_kw)
+        prev, im = a8.astype(np.float32) / 255.0, b8.astype(np.float32) / 255.0
+        ev = run(im, prev, **kw)
+        assert ev.dtype == np.float32
+        out[tag] = ev
+    # first frame of a run: prev_im is still the float64 zeros of :341 -> float64 arithmetic
+    a8, _ = syn.make_gray_pair(104)
+    ev = run(a8.astype(np.float32) / 255.0, np.zeros(a8.shape))
+    assert ev.dtype == np.float64
+    out["first"] = ev
+    save("g10_difflog", **out)
+
+
 # ------------------------------------------------------------------ G0: state-dict key inventory
 def g0():
     import json
@@ -304,7 +348,7 @@ def g0():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     with torch.no_grad():
         for g in which:
             globals()[g]()

@@ -236,6 +236,25 @@ def test_velpred_shell_errors():
         lm.DynamicFCNet(4, 1, [1], ["tanh"], logger=lambda *a: None)(torch.zeros(1, 4))
 
 
+# ------------------------------------------------------------------ G10 simulator difflog events (N4)
+def test_difflog_events_oracle():
+    from oracle import sim as osim
+    from _util import assert_difflog_parity, difflog_cases, gray_pair_f32
+    g = golden("g10_difflog")
+    for tag, seed, kw, pkw in difflog_cases():
+        prev, im = gray_pair_f32(seed, **pkw)
+        ev = osim.compute_events(im, prev, **kw)
+        assert ev.dtype == np.float32
+        assert_difflog_parity(ev, g[tag], osim.difflog(im, prev), kw.get("pos_thresh", 0.2), kw.get("neg_thresh", 0.2))
+    assert not g["asym_quiet"].any() and not g["identical"].any()      # the early return of :626-627
+    prev, im = gray_pair_f32(104)
+    first = osim.compute_events(prev, np.zeros(prev.shape))            # float64 zeros of :341
+    assert first.dtype == np.float64
+    assert_difflog_parity(first, g["first"], osim.difflog(prev, np.zeros(prev.shape)))
+    v = osim.command_velocity([0.9, -0.4, 0.0], 4.0, 1.0)
+    assert np.allclose(v, [2.0, -1.6, 0.0]) and np.allclose(osim.command_velocity([0.9, 0.1, 0], 4.0, 0.1)[0], 1.0)
+
+
 # ------------------------------------------------------------------ G8 composite (run.py pattern)
 def test_composite_stateful():
     g = golden("g8_composite")
