@@ -75,6 +75,15 @@ int igemm_zero_page(const float **out);
 bool conv3x3_halo_applicable(const ConvDesc &d);
 int conv3x3_halo_launch(const ConvDesc &d, hipStream_t st);
 
+// Winograd F(2x2,3x3) kernel (wino.hip): same ConvDesc contract plus the pre-transformed weights U = G g G^T in the
+// streamed layout of wino_u_index (wino_u_floats(cout, cin) floats). Supports d.y_pool.
+size_t wino_u_floats(int cout, int cin);
+void wino_pack_host(const float *w_oihw, int cout, int cin, float *U);
+int wino_pack_device(const float *w, int cout, int cin, int64_t sn, int64_t sc, int64_t st, float *U, hipStream_t stream);
+bool wino_applicable(const ConvDesc &d);
+double wino_efficiency(const ConvDesc &d);      // useful tile slots / launched tile slots of the chosen plan
+int wino_launch(const ConvDesc &d, const float *U, hipStream_t st);
+
 // algorithmic work of one launch (for the profile / roofline accounting)
 inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }
 

@@ -231,8 +231,15 @@ int pack_unet(evfly_model *m) {
     }
     const char *convs[] = {"e12", "e21", "e22", "e31", "e32", "e41", "e42", "e51", "e52",
                            "d11", "d12", "d21", "d22", "d31", "d32", "d41", "d42"};
-    for (const char *n : convs)
+    for (const char *n : convs) {
         if (int rc = pack_conv(m, kUnetP, std::string("unet_") + n, n)) return rc;
+        // Winograd F(2x2,3x3) weights U = G g G^T in the streamed layout of wino.hip (exact-fp32 path only)
+        const HostTensor *t = m->find(std::string("unet_") + n + ".weight", kUnetP);
+        if (c.compute_dtype == EVFLY_DTYPE_F32 && t && t->shape[1] % 32 == 0) {
+            const int O = (int)t->shape[0], I = (int)t->shape[1];
+            wino_pack_host(t->v.data(), O, I, m->stage(std::string(n) + ".u", wino_u_floats(O, I)));
+        }
+    }
     for (int l = 1; l <= 4; ++l) {   // ConvTranspose2d (Cin, Cout, 2, 2) -> [(dy*2+dx)*Cout + co][ci]
         const std::string key = "unet_upconv" + std::to_string(l);
         const HostTensor *t = m->find(key + ".weight", kUnetP);
@@ -433,6 +440,12 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", wname.c_str());
     const double bytes = 4.0 * ((double)n * H * W * C + (double)d.M * cout + (double)cout * d.K);
     const std::string pn = std::string(pname) + "/" + wname;   // family/layer: bench.py groups by family
+    if (wino_applicable(d) && m->has(wname + ".u")) {          // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
+        d.y_pool = y_pool;                                     // nn.MaxPool2d(2,2): one window per Winograd tile
+        if (pool_fused) *pool_fused = y_pool != nullptr;
+        RUN(m, pn.c_str(), igemm_flops(d), bytes, wino_launch(d, m->W(wname + ".u"), m->st));
+        return 0;
+    }
     const bool halo = conv3x3_halo_applicable(d);
     if (halo) d.y_pool = y_pool;                               // nn.MaxPool2d(2,2) fused into the producer
     if (pool_fused) *pool_fused = halo && y_pool != nullptr;
@@ -949,6 +962,12 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
         d.w = static_cast<const float *>(scr);
     }
     d.ldw = d.K; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
+    if (wino_applicable(d) && !(getenv("EVFLY_WINO_OP") && atoi(getenv("EVFLY_WINO_OP")) == 0)) {
+        void *u = nullptr;
+        if (int rc = scratch_get(wino_u_floats(cout, cin) * 4, &u, 2)) return rc;
+        if (int rc = wino_pack_device(w_packed, cout, cin, (int64_t)9 * cin, 1, cin, static_cast<float *>(u), as_stream(stream))) return rc;
+        return wino_launch(d, static_cast<const float *>(u), as_stream(stream));
+    }
     if (conv3x3_halo_applicable(d)) return conv3x3_halo_launch(d, as_stream(stream));
     return igemm_launch(d, as_stream(stream));
 }
