@@ -4,8 +4,11 @@
 // i.e. 2.25x fewer MFMA flops than the direct implicit GEMM, all in fp32 (the transforms use only +-1 and +-1/2).
 //
 // Mapping. A block owns up to 64 Winograd tiles (IMGS images x TY x TX tiles of 2x2 outputs) and 32 output
-// channels. The raw (2TY+2) x (2TX+2) input patch of one 32-channel chunk is DMA'd into LDS once (16-B chunk swizzle
-// keyed on the patch pixel, as in conv3x3_halo.hip). For each of the 16 Winograd positions (a, b) the MFMA computes
+// channels. The raw (2TY+2) x (2TX+2) input patch of one 32-channel chunk is DMA'd into LDS once. LDS layout: pixel
+// PAIRS of 256 B (the CDNA4 LDS is 64 banks wide and serves ds_read_b128 in four 16-lane groups); the sixteen 16-B
+// slots of a pair are XOR-swizzled with key = (px/2 + (py/2)*TX + im*TY*TX) & 15, which for any fixed patch offset
+// equals (tile index + const) & 15 -- the 16 lanes of every ds_read_b128 group hold 16 raster-consecutive tiles
+// (mod 16), so every fragment read is bank-conflict free for every plan (TY, TX, IMGS). For each of the 16 Winograd positions (a, b) the MFMA computes
 // M_ab[tile, n] += V_ab[tile, c] * U_ab[n, c]:
 //   * V = B^T d B is formed IN REGISTERS from twelve ds_read_b128 of the raw patch (2 v_add per MFMA operand);
 //   * U = G g G^T is precomputed at weight-pack time and streamed from L2 straight into the B-operand registers,
@@ -33,31 +36,34 @@ struct WinoGeom {
     int ntiles;                 // IMGS * TY * TX  (<= 64)
     int bx, by, bi;             // blocks along x, y, image groups
     int n_nt, cpx, n_btiles;
-    int mPW, mPP, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
-    int dbg;                    // ablation switches (EVFLY_WINO_ABL): 1 no patch DMA, 2 no U loads, 4 no stores
+    int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
+    int dbg;                    // ablation switches (EVFLY_WINO_ABL): 1 no patch DMA, 4 no stores
 };
 
-__device__ __forceinline__ int swz(int q, int chunk) { return q * 32 + ((chunk ^ ((q >> 1) & 7)) << 2); }
+// Opaque identity: stops hipcc from hoisting the per-step address XORs out of the chunk loop (LICM would turn six
+// offsets into 48 loop-invariant registers and spill).
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
 // one 32-channel chunk of the K loop for a wave with position rows {2*AH, 2*AH+1}.
 // off0[r][c/2]: byte offset of patch pixel (row r, column c & ~1) of this lane's tile, chunk slot of k-half fh at j = 0;
-// the slot of step j is that XOR (2j) (the swizzle is an XOR on the same bits), i.e. byte offset XOR 32*j.
+// slot = ((c & 1) * 8 + 2j + fh) ^ key, so step j is a byte-offset XOR of 32*j and the odd column one of 128.
+constexpr bool DMA_EARLY = true;    // true: issue the next chunk's DMA after the last fragment reads (more overlap, more registers)
+
 template <int AH, typename Dma>
 __device__ __forceinline__ void wino_chunk(const char *__restrict__ patch, const int (&off0)[3][2],
-                                           const float2 *__restrict__ &ub, float2 (&bcur)[8], f32x16 (&acc)[8], bool last, bool nob,
-                                           Dma &&dma_next) {
+                                           const float2 *__restrict__ &ub, float2 (&bcur)[8], f32x16 (&acc)[8], Dma &&dma_next) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // row transform right after the loads: t0 / t1 = the wave's two rows of B^T d, four k-values per float4
         float4 t0[4], t1[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            // columns 0,1 share a swizzle key, columns 2,3 the next one (the patch width is even): two offsets per row
-            const float4 r0 = *reinterpret_cast<const float4 *>(patch + (off0[0][c >> 1] ^ (j << 5)) + (c & 1) * 128);
-            const float4 r1 = *reinterpret_cast<const float4 *>(patch + (off0[1][c >> 1] ^ (j << 5)) + (c & 1) * 128);
-            const float4 r2 = *reinterpret_cast<const float4 *>(patch + (off0[2][c >> 1] ^ (j << 5)) + (c & 1) * 128);
+            // columns 0,1 are one pixel pair, columns 2,3 the next: two offsets per row; j and the odd column are XORs
+            const float4 r0 = *reinterpret_cast<const float4 *>(patch + (opaque(off0[0][c >> 1]) ^ ((j << 5) | ((c & 1) << 7))));
+            const float4 r1 = *reinterpret_cast<const float4 *>(patch + (opaque(off0[1][c >> 1]) ^ ((j << 5) | ((c & 1) << 7))));
+            const float4 r2 = *reinterpret_cast<const float4 *>(patch + (opaque(off0[2][c >> 1]) ^ ((j << 5) | ((c & 1) << 7))));
             if (AH == 0) {   // a = 0: d0 - d2 ; a = 1: d1 + d2   (patch rows 0,1,2)
                 t0[c] = make_float4(r0.x - r2.x, r0.y - r2.y, r0.z - r2.z, r0.w - r2.w);
                 t1[c] = make_float4(r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w);
@@ -68,12 +74,12 @@ __device__ __forceinline__ void wino_chunk(const char *__restrict__ patch, const
         }
         // the last fragment reads of this chunk are issued: start the DMA of the next chunk into the other buffer
         // (hipcc orders every later ds_read behind outstanding LDS-DMA, so it must not come earlier)
-        if (j == 3) dma_next();
+        if (j == 3 && DMA_EARLY) dma_next();
 #pragma unroll
         for (int hg = 0; hg < 2; ++hg) {
             // position-outer: both k-values of U_p are consumed back to back, then the same registers are refilled
-            // for the next half-group: one set of B registers, ~15 MFMAs (1 us) of prefetch distance
-            const bool more = !(last && j == 3 && hg == 1) && !nob;
+            // for the next half-group: one set of B registers, ~15 MFMAs (1 us) of prefetch distance. The refill is
+            // unconditional (straight-line code): the U buffer carries one half-group of slack behind its last step.
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const float4 *t = p < 4 ? t0 : t1;
@@ -85,11 +91,12 @@ __device__ __forceinline__ void wino_chunk(const char *__restrict__ patch, const
                 else             { va = f4e(t[1], e) - f4e(t[3], e); vb = f4e(t[1], e + 1) - f4e(t[3], e + 1); }
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, bcur[p].x, acc[p], 0, 0, 0);
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, bcur[p].y, acc[p], 0, 0, 0);
-                if (more) bcur[p] = ub[p * 64];
+                bcur[p] = ub[p * 64];
             }
-            if (more) ub += 16 * 64;
+            ub += 16 * 64;
         }
     }
+    if (!DMA_EARLY) dma_next();
 }
 
 __global__ __launch_bounds__(256, 2) void k_wino(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
@@ -105,7 +112,6 @@ __global__ __launch_bounds__(256, 2) void k_wino(ConvDesc d, const float *__rest
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int mt = wv & 1, ah = wv >> 1;
-    const int sub = lane >> 3, c8 = lane & 7;
     const int fm = lane & 31, fh = lane >> 5;
 
     // this lane's tile as MFMA row fm of M-tile mt
@@ -115,13 +121,14 @@ __global__ __launch_bounds__(256, 2) void k_wino(ConvDesc d, const float *__rest
         if (t >= g.ntiles) t = 0;
         const int per = g.TY * g.TX;
         const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-        const int q0 = (im * g.PH + 2 * ty + ah) * g.PW + 2 * tx;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int q = q0 + r * g.PW + 2 * c;          // q0 and PW are even: q and q + 1 share (q >> 1)
-                off0[r][c] = q * 128 + ((fh ^ ((q >> 1) & 7)) << 4);
+                const int py = 2 * ty + ah + r, pxh = tx + c;
+                const int pp = (im * g.PH + py) * (g.PW >> 1) + pxh;
+                const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
+                off0[r][c] = pp * 256 + ((fh ^ key) << 4);
             }
     }
 
@@ -143,13 +150,16 @@ __global__ __launch_bounds__(256, 2) void k_wino(ConvDesc d, const float *__rest
     const int buf_floats = g.ngroups * 8 * 32;
     auto dma = [&](int cc, float *dst) {
         if (g.dbg & 1) return;
+        const int pl = lane >> 4, sp = lane & 15;      // DMA lane role: pixel pair within the group of 4, 16-B slot
         for (int gi = wv; gi < g.ngroups; gi += 4) {
-            const int q = gi * 8 + sub;
-            const int im = (q * g.mPP) >> 20, rem = q - im * (g.PH * g.PW), py = (rem * g.mPW) >> 20, px = rem - py * g.PW;
+            const int pp = gi * 4 + pl;
+            const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
+            const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
+            const int sl = sp ^ ((pxh + (py >> 1) * g.TX + im * (g.TY * g.TX)) & 15);   // content of this LDS slot
+            const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
             const int iy = iy0 + py, ix = ix0 + px, img = img0 + im;
-            const bool ok = q < g.npix && img < d.NI && iy < d.H && ix < d.W;
-            const float *src = ok ? d.x + (((int64_t)img * d.H + iy) * d.W + ix) * d.ldx + cc * 32 + ((c8 ^ ((q >> 1) & 7)) << 2)
-                                  : d.zeros;
+            const bool ok = 2 * pp < g.npix && img < d.NI && iy < d.H && ix < d.W;
+            const float *src = ok ? d.x + (((int64_t)img * d.H + iy) * d.W + ix) * d.ldx + cc * 32 + ch * 4 : d.zeros;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + gi * 8 * 32), 16, 0, 0);
         }
     };
@@ -160,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void k_wino(ConvDesc d, const float *__rest
         float *nxt = patch + ((cc + 1) & 1) * buf_floats;
         const bool last = cc == nchunks - 1;
         auto next = [&]() { if (!last) dma(cc + 1, nxt); };
-        if (ah == 0) wino_chunk<0>(cur, off0, ub, bcur, acc, last, (g.dbg & 2) != 0, next);
-        else wino_chunk<1>(cur, off0, ub, bcur, acc, last, (g.dbg & 2) != 0, next);
+        if (ah == 0) wino_chunk<0>(cur, off0, ub, bcur, acc, next);
+        else wino_chunk<1>(cur, off0, ub, bcur, acc, next);
     }
 
     // ---- output transform. Along b (lane-local): s_a0 = M_a0 + M_a1 + M_a2, s_a1 = M_a1 - M_a2 - M_a3.
@@ -218,6 +228,174 @@ __global__ __launch_bounds__(256, 2) void k_wino(ConvDesc d, const float *__rest
                 const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx;
                 const float o = xch[(mt * 16 + r) * 64 + lane];
                 const float v = (rowmax[r] > o || rowmax[r] != rowmax[r]) ? rowmax[r] : o;
+                if (nok && t < g.ntiles && img < d.NI && gy < PHo && gx < PWo)
+                    d.y_pool[(((int64_t)img * PHo + gy) * PWo + gx) * d.Nc + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- 8-wave variant
+// Same block tile (<= 64 Winograd tiles x 32 output channels) split over EIGHT waves: wave = (M-tile mt, position row
+// a in 0..3), four accumulator tiles (64 registers) instead of eight. Everything fits in 128 VGPRs, so four waves
+// per SIMD (two 512-thread blocks per CU) hide the LDS, L2 and barrier latencies that the 4-wave kernel exposes.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino8(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;
+
+    const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
+    const int bt = xcd * g.cpx + slot / g.n_nt, nt = slot % g.n_nt;
+    if (bt >= g.n_btiles) return;
+    const int bxi = bt % g.bx, byi = (bt / g.bx) % g.by, big = bt / (g.bx * g.by);
+    const int img0 = big * g.IMGS, ty0 = byi * g.TY, tx0 = bxi * g.TX;
+    const int n0 = nt * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs
+    const int mt = wv & 1, a = wv >> 1;
+    const int fm = lane & 31, fh = lane >> 5;
+    const int per = g.TY * g.TX;
+
+    // B^T row a: t = d[rA] + sg * d[rB]   (a = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
+    const int rA = a == 0 ? 0 : a == 2 ? 2 : 1, rB = a == 3 ? 3 : a == 2 ? 1 : 2;
+    const float sg = a == 1 ? 1.f : -1.f;
+    int off0[2][2];
+    {
+        int t = mt * 32 + fm;
+        if (t >= g.ntiles) t = 0;
+        const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int py = 2 * ty + (r == 0 ? rA : rB), pxh = tx + c;
+                const int pp = (im * g.PH + py) * (g.PW >> 1) + pxh;
+                const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
+                off0[r][c] = pp * 256 + ((fh ^ key) << 4);
+            }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const int nchunks = d.C / 32;
+    // U stream: [nt][cc][j][hg][pos 16][lane 64][2]; this wave reads pos 4a .. 4a+3
+    const float2 *ub = reinterpret_cast<const float2 *>(U) + ((int64_t)nt * nchunks * 8 * 16 + 4 * a) * 64 + lane;
+    float2 bcur[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) bcur[p] = ub[p * 64];
+    ub += 16 * 64;
+
+    const int iy0 = 2 * ty0, ix0 = 2 * tx0;
+    const int buf_floats = g.ngroups * 8 * 32;
+    auto dma = [&](int cc, float *dst) {
+        if (g.dbg & 1) return;
+        const int pl = lane >> 4, sp = lane & 15;
+        for (int gi = wv; gi < g.ngroups; gi += 8) {
+            const int pp = gi * 4 + pl;
+            const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
+            const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
+            const int sl = sp ^ ((pxh + (py >> 1) * g.TX + im * per) & 15);
+            const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
+            const int iy = iy0 + py, ix = ix0 + px, img = img0 + im;
+            const bool ok = 2 * pp < g.npix && img < d.NI && iy < d.H && ix < d.W;
+            const float *src = ok ? d.x + (((int64_t)img * d.H + iy) * d.W + ix) * d.ldx + cc * 32 + ch * 4 : d.zeros;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + gi * 8 * 32), 16, 0, 0);
+        }
+    };
+    dma(0, patch);
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();            // chunk cc has landed; everyone is done reading the other buffer
+        const char *cur = reinterpret_cast<const char *>(patch + (cc & 1) * buf_floats);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int x = (j << 5) | ((c & 1) << 7);
+                float4 u, v;
+                if (g.dbg & 8) { u = make_float4(1.f, 2.f, 3.f, (float)lane); v = u; }
+                else {
+                    u = *reinterpret_cast<const float4 *>(cur + (opaque(off0[0][c >> 1]) ^ x));
+                    v = *reinterpret_cast<const float4 *>(cur + (opaque(off0[1][c >> 1]) ^ x));
+                }
+                t[c] = make_float4(fmaf(sg, v.x, u.x), fmaf(sg, v.y, u.y), fmaf(sg, v.z, u.z), fmaf(sg, v.w, u.w));
+            }
+            // last fragment reads of the chunk are issued: the next chunk's DMA may start (see wino_chunk)
+            if (j == 3 && cc + 1 < nchunks) dma(cc + 1, patch + ((cc + 1) & 1) * buf_floats);
+#pragma unroll
+            for (int hg = 0; hg < 2; ++hg) {
+                // position-outer, refill after use (slack behind the last step: unconditional loads)
+                const int e = 2 * hg;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float va, vb;
+                    if (p == 0)      { va = f4e(t[0], e) - f4e(t[2], e); vb = f4e(t[0], e + 1) - f4e(t[2], e + 1); }
+                    else if (p == 1) { va = f4e(t[1], e) + f4e(t[2], e); vb = f4e(t[1], e + 1) + f4e(t[2], e + 1); }
+                    else if (p == 2) { va = f4e(t[2], e) - f4e(t[1], e); vb = f4e(t[2], e + 1) - f4e(t[1], e + 1); }
+                    else             { va = f4e(t[1], e) - f4e(t[3], e); vb = f4e(t[1], e + 1) - f4e(t[3], e + 1); }
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, bcur[p].x, acc[p], 0, 0, 0);
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, bcur[p].y, acc[p], 0, 0, 0);
+                    if (!(g.dbg & 16)) bcur[p] = ub[p * 64];
+                }
+                ub += 16 * 64;
+            }
+        }
+    }
+
+    // ---- output transform. Lane-local along b: s0 = M_a0 + M_a1 + M_a2, s1 = M_a1 - M_a2 - M_a3. Along a the four
+    // waves of an M-tile trade through LDS; wave a owns output pixel (i, x) = (a >> 1, a & 1) of every tile:
+    //   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
+    // sets in LDS: k0 = s_01, k1 = s_10, k2 = s_11, k3 = s_20, k4 = s_21, k5 = s_30
+    __syncthreads();
+    float *xch = smem;                                 // [mt 2][set 6][r 16][lane 64]  = 48 KB
+    auto at = [&](int k, int r) -> float & { return xch[((mt * 6 + k) * 16 + r) * 64 + lane]; };
+    float own[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s0 = acc[0][r] + acc[1][r] + acc[2][r], s1 = acc[1][r] - acc[2][r] - acc[3][r];
+        if (a == 0) { at(0, r) = s1; own[r] = s0; }
+        else if (a == 1) { at(1, r) = s0; at(2, r) = s1; own[r] = s1; }
+        else if (a == 2) { at(3, r) = s0; at(4, r) = s1; own[r] = -s0; }
+        else { at(5, r) = s0; own[r] = -s1; }
+    }
+    __syncthreads();
+    const int kA = a == 0 ? 1 : a == 1 ? 0 : a == 2 ? 1 : 2, kB = a == 0 ? 3 : a == 1 ? 4 : a == 2 ? 5 : 4;
+    const float sB = a < 2 ? 1.f : -1.f;
+    const int n = n0 + fm;
+    const bool nok = n < d.Nc;
+    const float bias = (d.bias && nok) ? d.bias[n] : 0.f;
+    const int oi = a >> 1, ox_ = a & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+        const int img = img0 + im, oy = 2 * (ty0 + ty) + oi, ox = 2 * (tx0 + tx) + ox_;
+        float y = own[r] + at(kA, r) + sB * at(kB, r) + bias;
+        y = apply_act(y, d.act);
+        own[r] = y;
+        if (nok && t < g.ntiles && img < d.NI && oy < d.OH && ox < d.OW && !(g.dbg & 4))
+            d.y[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy + n] = y;
+    }
+    if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): the window is the Winograd tile, one pixel per wave of the M-tile
+        __syncthreads();
+        if (a > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) at(a - 1, r) = own[r];
+        }
+        __syncthreads();
+        if (a == 0) {
+            const int PHo = d.OH / 2, PWo = d.OW / 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+                const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx;
+                float v = own[r];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const float o = at(k, r); v = (v > o || v != v) ? v : o; }
                 if (nok && t < g.ntiles && img < d.NI && gy < PHo && gx < PWo)
                     d.y_pool[(((int64_t)img * PHo + gy) * PWo + gx) * d.Nc + n] = v;
             }
@@ -287,14 +465,15 @@ bool plan(const ConvDesc &d, WinoGeom &g) {
     g.n_nt = cdiv(d.Nc, 32);
     g.n_btiles = g.bx * g.by * g.bi;
     g.cpx = cdiv(g.n_btiles, kNumXCD);
-    g.mPW = 1048576 / g.PW + 1; g.mPP = 1048576 / (g.PH * g.PW) + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
+    g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
     g.dbg = getenv("EVFLY_WINO_ABL") ? atoi(getenv("EVFLY_WINO_ABL")) : 0;
     return true;
 }
 
 }  // namespace
 
-size_t wino_u_floats(int cout, int cin) { return (size_t)((cout + 31) / 32 * 32) * cin * 16; }
+// + one half-group (16 positions x 64 lanes x 2 floats) of slack: the kernel's prefetch runs one step past the end
+size_t wino_u_floats(int cout, int cin) { return (size_t)((cout + 31) / 32 * 32) * cin * 16 + 16 * 64 * 2; }
 
 void wino_pack_host(const float *w_oihw, int cout, int cin, float *U) {
     const int cout_pad = (cout + 31) / 32 * 32;
@@ -333,16 +512,19 @@ int wino_launch(const ConvDesc &d_in, const float *U, hipStream_t st) {
     EVFLY_REQUIRE(plan(d, g), "wino: no tile plan");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
     if (int rc = igemm_zero_page(&d.zeros)) return rc;
-    const int lds = std::max(2 * g.ngroups * 8 * 32 * 4, 4 * 2 * 16 * 64 * 4);
-    static int lds_set = 0;
-    if (lds > lds_set) {
+    static const int variant = getenv("EVFLY_WINO_WAVES") ? atoi(getenv("EVFLY_WINO_WAVES")) : 8;
+    const int lds = std::max(2 * g.ngroups * 8 * 32 * 4, variant == 8 ? 2 * 6 * 16 * 64 * 4 : 4 * 2 * 16 * 64 * 4);
+    static bool lds_set = false;
+    if (!lds_set) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        lds_set = 80 * 1024;
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino8), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        lds_set = true;
     }
     if (getenv("EVFLY_WINO_DBG"))
         fprintf(stderr, "wino: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, eff %.2f\n", d.NI, d.OH, d.OW,
                 d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, wino_efficiency(d));
-    hipLaunchKernelGGL(k_wino, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256), lds, st, d, U, g);
+    if (variant == 8) hipLaunchKernelGGL(k_wino8, dim3(kNumXCD * g.cpx * g.n_nt), dim3(512), lds, st, d, U, g);
+    else hipLaunchKernelGGL(k_wino, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256), lds, st, d, U, g);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
