@@ -364,41 +364,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     const int kA = a == 0 ? 1 : a == 1 ? 0 : a == 2 ? 1 : 2, kB = a == 0 ? 3 : a == 1 ? 4 : a == 2 ? 5 : 4;
     const float sB = a < 2 ? 1.f : -1.f;
-    const int n = n0 + fm;
-    const bool nok = n < d.Nc;
-    const float bias = (d.bias && nok) ? d.bias[n] : 0.f;
-    const int oi = a >> 1, ox_ = a & 1;
+    const bool nokl = n0 + fm < d.Nc;
+    const float bias = (d.bias && nokl) ? d.bias[n0 + fm] : 0.f;
+    // finished pixels go to LDS as [tile 64][pixel 4][channel 32] so that the global stores are 16-B vectors and the
+    // index arithmetic runs once per four channels instead of once per value
+    float *ot = smem + 2 * 6 * 16 * 64;                // 32 KB behind the exchange sets
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-        const int img = img0 + im, oy = 2 * (ty0 + ty) + oi, ox = 2 * (tx0 + tx) + ox_;
+        const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         float y = own[r] + at(kA, r) + sB * at(kB, r) + bias;
-        y = apply_act(y, d.act);
-        own[r] = y;
-        if (nok && t < g.ntiles && img < d.NI && oy < d.OH && ox < d.OW && !(g.dbg & 4))
-            d.y[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy + n] = y;
+        ot[(tl * 4 + a) * 32 + fm] = apply_act(y, d.act);
     }
-    if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): the window is the Winograd tile, one pixel per wave of the M-tile
-        __syncthreads();
-        if (a > 0) {
+    __syncthreads();
+    const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) at(a - 1, r) = own[r];
-        }
-        __syncthreads();
-        if (a == 0) {
-            const int PHo = d.OH / 2, PWo = d.OW / 2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-                const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx;
-                float v = own[r];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { const float o = at(k, r); v = (v > o || v != v) ? v : o; }
-                if (nok && t < g.ntiles && img < d.NI && gy < PHo && gx < PWo)
-                    d.y_pool[(((int64_t)img * PHo + gy) * PWo + gx) * d.Nc + n] = v;
-            }
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + q * 512, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
+        const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+        const int img = img0 + im, oy = 2 * (ty0 + ty) + (pix >> 1), ox = 2 * (tx0 + tx) + (pix & 1), n = n0 + c4 * 4;
+        if (tl >= g.ntiles || img >= d.NI || oy >= d.OH || ox >= d.OW || n >= d.Nc || (g.dbg & 4)) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(ot + pl * 32 + c4 * 4);
+        float *dst = d.y + (((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy + n;
+        if (vec) *reinterpret_cast<float4 *>(dst) = v;
+        else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
+    }
+    if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): the window is the Winograd tile; NaN wins like in torch
+        const int c4 = tid & 7, tl = tid >> 3;
+        const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+        const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx, n = n0 + c4 * 4;
+        const int PHo = d.OH / 2, PWo = d.OW / 2;
+        if (tl < g.ntiles && img < d.NI && gy < PHo && gx < PWo && n < d.Nc && !(g.dbg & 4)) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 0) * 32 + c4 * 4);
+            const float4 p1 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 1) * 32 + c4 * 4);
+            const float4 p2 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 2) * 32 + c4 * 4);
+            const float4 p3 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 3) * 32 + c4 * 4);
+#define MX(p, q) ((p) > (q) || (p) != (p) ? (p) : (q))
+            const float4 v = make_float4(MX(MX(p0.x, p1.x), MX(p2.x, p3.x)), MX(MX(p0.y, p1.y), MX(p2.y, p3.y)),
+                                         MX(MX(p0.z, p1.z), MX(p2.z, p3.z)), MX(MX(p0.w, p1.w), MX(p2.w, p3.w)));
+#undef MX
+            float *dst = d.y_pool + (((int64_t)img * PHo + gy) * PWo + gx) * d.Nc + n;
+            if ((d.Nc & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
+            else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
         }
     }
 }
@@ -513,7 +519,7 @@ int wino_launch(const ConvDesc &d_in, const float *U, hipStream_t st) {
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
     if (int rc = igemm_zero_page(&d.zeros)) return rc;
     static const int variant = getenv("EVFLY_WINO_WAVES") ? atoi(getenv("EVFLY_WINO_WAVES")) : 8;
-    const int lds = std::max(2 * g.ngroups * 8 * 32 * 4, variant == 8 ? 2 * 6 * 16 * 64 * 4 : 4 * 2 * 16 * 64 * 4);
+    const int lds = std::max(2 * g.ngroups * 8 * 32 * 4, variant == 8 ? (2 * 6 * 16 * 64 + 64 * 4 * 32) * 4 : 4 * 2 * 16 * 64 * 4);
     static bool lds_set = false;
     if (!lds_set) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
