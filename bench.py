@@ -172,8 +172,8 @@ def main():
     fam = {}
     for p in layers:
         f = fam.setdefault(p["name"].split("/")[0],
-                           dict(name=p["name"].split("/")[0], ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        for k in ("ms", "flops", "bytes", "launches"):
+                           dict(name=p["name"].split("/")[0], ms=0.0, flops=0.0, bytes=0.0, launches=0, exec_flops=0.0))
+        for k in ("ms", "flops", "bytes", "launches", "exec_flops"):
             f[k] += p[k]
     prof = list(fam.values())
     dom = max(prof, key=lambda p: p["ms"])
@@ -194,17 +194,28 @@ def main():
         # --pmc WRITE_SIZE, separate runs of this script at the C2 shape; FETCH doubled per the gfx950 calibration in
         # profiles/README.md). PMC counters cannot be read inside this process, so the figure is null for other shapes.
         traffic, tnote = None, "no PMC summary for this shape/dtype"
-        pmc = os.path.join(REPO, "profiles", "r1_pmc_traffic.json")
+        pmc = os.path.join(REPO, "profiles", "r1f_pmc_traffic.json")
         if os.path.exists(pmc) and a.dtype == "f32" and (B, T, a.events_per_window) == (64, 5, 60_000):
-            g = json.load(open(pmc))["kernels"]["mfma_gemm"]
+            g = json.load(open(pmc))["kernels"]["wino_conv3x3"]
             traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
-            tnote = ("bytes per launch, mean over the %d MFMA GEMM launches of a step (17 conv3x3 + smaller GEMMs): "
-                     "(2 x FETCH_SIZE + WRITE_SIZE) from profiles/r1_pmc_traffic.json" % g["launches_per_step"])
+            tnote = ("HBM bytes per launch, mean over the %d conv3x3 (k_wino8) launches of a step: (2 x FETCH_SIZE + "
+                     "WRITE_SIZE) from profiles/r1f_pmc_traffic.json; algorithmic = bytes_per_launch"
+                     % g["launches_per_step"])
         if dom["flops"]:
             out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(tfl, 2), "peak": PEAK[a.dtype],
                                "unit": "TFLOP/s", "frac": round(tfl / PEAK[a.dtype], 4), "traffic": traffic, "traffic_note": tnote,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                               "flops_per_launch": dom["flops"] / dom["launches"]}
+                               "flops_per_launch": dom["flops"] / dom["launches"],
+                               "bytes_per_launch": dom["bytes"] / dom["launches"]}
+            if dom["exec_flops"] and abs(dom["exec_flops"] - dom["flops"]) > 1e-6 * dom["flops"]:
+                # `achieved` is ALGORITHMIC work (direct 3x3 convolution flops) over time. The fp32 path runs Winograd
+                # F(2x2,3x3): the matrix cores issue 16/36 of that count (plus tile padding), so `frac` can approach or
+                # pass 1 while the MFMA pipe itself is at `mfma_issued.frac` of its peak.
+                ex = dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12
+                out["roofline"]["mfma_issued"] = {"tflops": round(ex, 2), "frac": round(ex / PEAK[a.dtype], 4),
+                                                  "flops_per_launch": dom["exec_flops"] / dom["launches"]}
+                out["roofline"]["note"] = ("achieved = algorithmic direct-conv flops / time; kernel = Winograd F(2x2,3x3) on "
+                                           "v_mfma_f32_32x32x2_f32, which issues 2.25x fewer multiplies: see mfma_issued")
         else:
             gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,

@@ -52,8 +52,10 @@ class HipHandle:
         ms, fl, by, ln = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         for i in range(L.evfly_model_profile_count(self.h)):
             L.evfly_model_profile_get(self.h, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by), C.byref(ln))
+            ex = C.c_double()
+            L.evfly_model_profile_exec_flops(self.h, i, C.byref(ex))
             out.append(dict(name=name.value.decode(), ms=ms.value, flops=fl.value, bytes=by.value,
-                            launches=ln.value))
+                            launches=ln.value, exec_flops=ex.value))
         return out
 
 

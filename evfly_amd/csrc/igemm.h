@@ -83,6 +83,7 @@ int wino_pack_device(const float *w, int cout, int cin, int64_t sn, int64_t sc, 
 bool wino_applicable(const ConvDesc &d);
 double wino_efficiency(const ConvDesc &d);      // useful tile slots / launched tile slots of the chosen plan
 int wino_launch(const ConvDesc &d, const float *U, hipStream_t st);
+double wino_exec_flops(const ConvDesc &d);     // MFMA flops one launch issues (its algorithmic count is igemm_flops)
 
 // algorithmic work of one launch (for the profile / roofline accounting)
 inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }

@@ -33,12 +33,12 @@ struct Tap {
 
 struct ProfRec {
     std::string name;
-    double flops, bytes;
+    double flops, bytes, exec;
     hipEvent_t e0, e1;
 };
 struct ProfAgg {
     std::string name;
-    double ms = 0, flops = 0, bytes = 0;
+    double ms = 0, flops = 0, bytes = 0, exec = 0;   // exec: matrix-core flops actually issued (Winograd: < flops)
     int launches = 0;
 };
 
@@ -108,14 +108,17 @@ struct evfly_model {
     }
 
     // ------------------------------------------------------------------ profiling
+    double next_exec = 0;   // set by conv() before RUN when the kernel issues fewer flops than the algorithmic count
     int prof_begin(const char *name, double flops, double bytes) {
+        const double ex = next_exec > 0 ? next_exec : flops;
+        next_exec = 0;
         if (!profiling || planning) return 0;
         while (ev_pool.size() < ev_used + 2) {
             hipEvent_t e;
             EVFLY_HIP(hipEventCreate(&e));
             ev_pool.push_back(e);
         }
-        ProfRec r{name, flops, bytes, ev_pool[ev_used], ev_pool[ev_used + 1]};
+        ProfRec r{name, flops, bytes, ex, ev_pool[ev_used], ev_pool[ev_used + 1]};
         ev_used += 2;
         EVFLY_HIP(hipEventRecord(r.e0, st));
         prof.push_back(r);
@@ -135,7 +138,7 @@ struct evfly_model {
             ProfAgg *a = nullptr;
             for (auto &x : agg) if (x.name == r.name) a = &x;
             if (!a) { agg.push_back(ProfAgg{r.name}); a = &agg.back(); }
-            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->launches += 1;
+            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->exec += r.exec; a->launches += 1;
         }
         prof.clear();
         ev_used = 0;
@@ -443,6 +446,7 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     if (wino_applicable(d) && m->has(wname + ".u")) {          // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
         d.y_pool = y_pool;                                     // nn.MaxPool2d(2,2): one window per Winograd tile
         if (pool_fused) *pool_fused = y_pool != nullptr;
+        m->next_exec = wino_exec_flops(d);
         RUN(m, pn.c_str(), igemm_flops(d), bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;
     }
@@ -938,6 +942,12 @@ extern "C" int evfly_model_profile_get(evfly_model *m, int i, char *name_out, in
     if (launches_out) *launches_out = a.launches;
     return 0;
 }
+extern "C" int evfly_model_profile_exec_flops(evfly_model *m, int i, double *exec_flops_out) {
+    EVFLY_REQUIRE(m && exec_flops_out && i >= 0 && i < (int)m->agg.size(), "profile_exec_flops: index out of range");
+    *exec_flops_out = m->agg[i].exec;
+    return 0;
+}
+
 extern "C" int evfly_model_profile_reset(evfly_model *m) {
     EVFLY_REQUIRE(m, "null handle");
     if (int rc = m->prof_collect()) return rc;

@@ -512,6 +512,13 @@ double wino_efficiency(const ConvDesc &d) {
     return (double)d.NI * cdiv(d.OH, 2) * cdiv(d.OW, 2) / (64.0 * g.n_btiles);
 }
 
+// matrix-core flops the launch issues: 16 positions x 64 tile slots x 32-channel slices x C_in, times 2
+double wino_exec_flops(const ConvDesc &d) {
+    WinoGeom g;
+    if (!plan(d, g)) return 0;
+    return 2.0 * 16.0 * ((double)g.n_btiles * 64.0) * ((double)g.n_nt * 32.0) * d.C;
+}
+
 int wino_launch(const ConvDesc &d_in, const float *U, hipStream_t st) {
     ConvDesc d = d_in;
     WinoGeom g;

@@ -249,6 +249,9 @@ int evfly_model_set_profiling(evfly_model *m, int enable);
 int evfly_model_profile_count(evfly_model *m);
 int evfly_model_profile_get(evfly_model *m, int i, char *name_out, int name_cap, double *ms_out,
                             double *flops_out, double *bytes_out, int *launches_out);
+/* Matrix-core flops actually ISSUED by record i (equals flops_out of evfly_model_profile_get for direct GEMMs; the
+ * Winograd F(2x2,3x3) kernel issues 16/36 of the algorithmic count, plus its tile padding). */
+int evfly_model_profile_exec_flops(evfly_model *m, int i, double *exec_flops_out);
 int evfly_model_profile_reset(evfly_model *m);
 
 /* ------------------------------------------------------------------------------------------
