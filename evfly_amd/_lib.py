@@ -63,6 +63,7 @@ SIGNATURES = {
     "evfly_e2v_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "evfly_model_tap": (c_i64, [c_p, C.c_char_p, c_p, c_i64, C.POINTER(c_i64), c_p]),
     "evfly_model_set_profiling": (c_i, [c_p, c_i]),
+    "evfly_model_set_profile_filter": (c_i, [c_p, C.c_char_p]),
     "evfly_model_profile_count": (c_i, [c_p]),
     "evfly_model_profile_get": (c_i, [c_p, c_i, C.c_char_p, c_i, C.POINTER(c_d), C.POINTER(c_d),
                                       C.POINTER(c_d), C.POINTER(c_i)]),

@@ -108,11 +108,15 @@ struct evfly_model {
     }
 
     // ------------------------------------------------------------------ profiling
+    std::string prof_filter;   // non-empty: only launch sites whose name starts with it are bracketed by events
+    bool prof_skipped = false;
     double next_exec = 0;   // set by conv() before RUN when the kernel issues fewer flops than the algorithmic count
     int prof_begin(const char *name, double flops, double bytes) {
         const double ex = next_exec > 0 ? next_exec : flops;
         next_exec = 0;
+        prof_skipped = false;
         if (!profiling || planning) return 0;
+        if (!prof_filter.empty() && std::strncmp(name, prof_filter.c_str(), prof_filter.size()) != 0) { prof_skipped = true; return 0; }
         while (ev_pool.size() < ev_used + 2) {
             hipEvent_t e;
             EVFLY_HIP(hipEventCreate(&e));
@@ -125,7 +129,7 @@ struct evfly_model {
         return 0;
     }
     int prof_end() {
-        if (!profiling || planning) return 0;
+        if (!profiling || planning || prof_skipped) return 0;
         EVFLY_HIP(hipEventRecord(prof.back().e1, st));
         return 0;
     }
@@ -924,6 +928,11 @@ extern "C" int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_
 extern "C" int evfly_model_set_profiling(evfly_model *m, int enable) {
     EVFLY_REQUIRE(m, "null handle");
     m->profiling = enable != 0;
+    return 0;
+}
+extern "C" int evfly_model_set_profile_filter(evfly_model *m, const char *prefix) {
+    EVFLY_REQUIRE(m, "null handle");
+    m->prof_filter = prefix ? prefix : "";
     return 0;
 }
 extern "C" int evfly_model_profile_count(evfly_model *m) {

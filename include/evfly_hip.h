@@ -246,6 +246,10 @@ int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_host, int64
 /* Names + average device time (ms, HIP events on `stream`) of the kernels of the last profiled
  * forward; enabled by evfly_model_set_profiling(m, 1). Used by bench.py for the roofline object. */
 int evfly_model_set_profiling(evfly_model *m, int enable);
+/* Restrict the event bracketing to launch sites whose "family/layer" name starts with `prefix` (NULL or "" = all).
+ * Every bracket costs two hipEventRecord on the stream (~3.5 us of serialisation per launch on MI355X): a
+ * throughput run brackets only the kernel family it reports. */
+int evfly_model_set_profile_filter(evfly_model *m, const char *prefix);
 int evfly_model_profile_count(evfly_model *m);
 int evfly_model_profile_get(evfly_model *m, int i, char *name_out, int name_cap, double *ms_out,
                             double *flops_out, double *bytes_out, int *launches_out);
