@@ -107,7 +107,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("EVFLY_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL over xGMI
 
