@@ -51,6 +51,7 @@ SIGNATURES = {
     "evfly_accumulate_u8": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "evfly_accumulate_reset": (c_i, [c_p, c_i64, c_p]),
     "evfly_condition_frames": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "evfly_remap_cubic": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "evfly_difflog_events": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p]),
     "evfly_resize_bilinear": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "evfly_model_create": (c_i, [C.POINTER(ModelConfig), C.POINTER(c_p)]),

@@ -13,13 +13,15 @@ from . import voxelizer
 
 class EventDepthVelocityNode:
     def __init__(self, model, evcam_hw=(480, 640), model_hw=(260, 346), des_fwd_vel=1.0, dodge_scaler=2.0,
-                 des_z=0.8, desvel=4.0, device="cuda"):
+                 des_z=0.8, desvel=4.0, device="cuda", aligner=None):
         self.model = model.to(device).float().eval()
         self.device = device
         self.evcam_height, self.evcam_width = evcam_hw                 # run.py:41
         self.model_hw = model_hw
         self.des_fwd_vel, self.dodge_scaler, self.des_z = des_fwd_vel, dodge_scaler, des_z   # run.py:36-39
         self.desvel = desvel                                           # run.py:255 (hard-coded 4.0)
+        self.align_evframe = aligner is not None                       # run.py:67-71
+        self.aligner = aligner
         self.proc_evs = None
         self.origunet_hidden_state = None                              # run.py:173-174
         self.velpred_hidden_state = None
@@ -31,7 +33,15 @@ class EventDepthVelocityNode:
 
     def run_model(self, frame_u8):
         """run.py:334-350 + 245-268 for one accumulator image (decode, centre crop, q97, forward)."""
-        x = voxelizer.condition_frames(torch.from_numpy(np.ascontiguousarray(frame_u8))[None], out_hw=self.model_hw)
+        src = torch.from_numpy(np.ascontiguousarray(frame_u8))[None]
+        if self.align_evframe:
+            # run.py:338-340 then :345-350: rectify (decode fused into the gather), producing only the centre-crop
+            # window the model consumes
+            H, W = self.evcam_height, self.evcam_width
+            h, w = self.model_hw
+            win = (H // 2 - h // 2, W // 2 - w // 2, h, w) if (H, W) != (h, w) else None
+            src = self.aligner.align(davis=src, window=win)['davis']
+        x = voxelizer.condition_frames(src, out_hw=self.model_hw)
         desvel = torch.tensor([[self.desvel]], device=x.device)
         full_input = [x, desvel, [self.origunet_hidden_state, None], self.velpred_hidden_state]
         with torch.no_grad():

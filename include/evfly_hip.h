@@ -106,6 +106,21 @@ int evfly_condition_frames(const uint8_t *src_u8, const float *src_f32, int n, i
                            int out_h, int out_w, float quantile, float *dst, float *q_out,
                            void *stream);
 
+/* Replaces Aligner.align -> remap_img -> cv2.remap(img, mapx, mapy, cv2.INTER_CUBIC), the rectification between
+ * decode and centre crop when align_evframe is set (utils/calibration_tools/rectify_bag.py:91-98,117-138;
+ * evfly_ros/run.py:338-340; every shipped config sets it, learner/configs/*.txt:10). OpenCV is a third-party
+ * dependency that is not in the reference tree (environment.yaml: opencv 4.5.x): the kernel restates the published
+ * remap algorithm for CV_32FC1 maps / CV_32FC1 image / INTER_CUBIC / BORDER_CONSTANT(0) -- coordinates rounded to
+ * 1/32 pixel (cvRound(map * 32)), 4x4 window at (ix-1, iy-1), separable float weights cubic(fy)[r] * cubic(fx)[c]
+ * with A = -0.75, zero outside the source, row-wise accumulation order of remapBicubic.
+ * src: n images (src_h, src_w), either uint8 accumulator images decoded on the fly as (u8 - 128) * 0.2f
+ * (run.py:334-336) or float32. mapx / mapy (map_h, map_w) float32 DEVICE arrays as cv2.initUndistortRectifyMap
+ * returns them. Only the window [top, top+out_h) x [left, left+out_w) of the map is produced (the centre crop of
+ * run.py:345-350 fused in): dst (n, out_h, out_w) f32. Parity is unpinned (no cv2, no calibration file here). */
+int evfly_remap_cubic(const uint8_t *src_u8, const float *src_f32, int n, int src_h, int src_w,
+                      const float *mapx, const float *mapy, int map_h, int map_w,
+                      int top, int left, int out_h, int out_w, float *dst, void *stream);
+
 /* Replaces AgilePilotNode.compute_events envtest/ros/run_competition.py:603-635 (the simulator's event
  * estimate from two consecutive gray images, float32 / 255 as im_callback :984-985 stores them), for n image
  * pairs at once: difflog = log(im + 1e-5) - log(prev_im + 1e-5) in float32; a pair whose max |difflog| is below

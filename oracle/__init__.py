@@ -14,5 +14,8 @@ with its outputs `tests/golden/*.npz`). `tests/test_oracle_golden.py` checks eve
 oracle function against those fixtures. The two ROS C++ accumulator nodes cannot be
 compiled here (ROS headers absent), so their 10-line loop bodies are restated in
 `oracle/accum.c` and pinned only by hand-derived known answers ("parity unpinned"
-for A3/A4 beyond those).
+for A3/A4 beyond those). `oracle/rectify.py` (Aligner.align, N3) restates two OpenCV
+calls; OpenCV is absent from the reference tree and from this container: "parity
+unpinned" for it as well. `oracle/sim.py` is pinned by running the reference's own
+function body (G10).
 """

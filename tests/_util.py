@@ -89,3 +89,22 @@ def assert_difflog_parity(got, want, d, pos_thresh=0.2, neg_thresh=0.2, max_frac
         q = abs(di) / th
         assert abs(q - round(q)) < 2e-5, f"pixel {i}: difflog {di} is not on a level boundary (q={q})"
         assert abs(got.reshape(-1)[i] - want.reshape(-1)[i]) <= th * 1.0001, f"pixel {i}: off by more than one level"
+
+
+def write_camchain_yaml(path):
+    """A synthetic Kalibr camchain (the layout utils/calibration_tools/rectify_bag.py:7-55 reads): cam0 = 848x480
+    frame camera, cam1 = 640x480 event camera with a small rotation + baseline; radtan distortion on both."""
+    import yaml
+    c, s = float(np.cos(0.02)), float(np.sin(0.02))
+    data = {
+        "cam0": {"camera_model": "pinhole", "intrinsics": [425.3, 424.1, 421.7, 238.9],
+                 "distortion_model": "radtan", "distortion_coeffs": [-0.051, 0.042, 0.0007, -0.0011],
+                 "resolution": [848, 480]},
+        "cam1": {"camera_model": "pinhole", "intrinsics": [548.2, 547.5, 322.4, 243.6],
+                 "distortion_model": "radtan", "distortion_coeffs": [-0.362, 0.171, 0.0013, -0.0008],
+                 "resolution": [640, 480],
+                 "T_cn_cnm1": [[c, 0.0, s, 0.049], [0.0, 1.0, 0.0, 0.001], [-s, 0.0, c, -0.002], [0.0, 0.0, 0.0, 1.0]]},
+    }
+    with open(path, "w") as fh:
+        yaml.safe_dump(data, fh)
+    return data

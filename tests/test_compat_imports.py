@@ -16,11 +16,12 @@ def test_run_py_import_surface():
         from learner_models import *
         import vitfly_models
         from ConvLSTM_pytorch.convlstm import ConvLSTM
+        from calibration_tools.rectify_bag import Aligner                   # run.py:25
         m = OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
                                       input_shape=[1, 1, 260, 346], velpred=0, enc_params={{}}, dec_params={{}}, fc_params={{}},
                                       form_BEV=2, evs_min_cutoff=0.15, skip_type='interp', is_deployment=False)
         assert sum(p.numel() for p in m.parameters()) == 13420336          # BASELINE.md: composite parameter count
-        assert isinstance(m.vitfly_vitlstm, vitfly_models.LSTMNetVIT) and callable(form_eventframe) and callable(argparsing)
+        assert isinstance(m.vitfly_vitlstm, vitfly_models.LSTMNetVIT) and callable(form_eventframe) and callable(argparsing) and callable(Aligner)
         print('ok')
     """)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)

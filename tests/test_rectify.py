@@ -1,0 +1,53 @@
+"""N3 (CPU part): the rectification maps of evfly_amd.calibration_tools.rectify_bag against the independent oracle
+restatement, and known answers of the oracle's cubic remap. OpenCV parity itself is unpinned (see oracle/rectify.py)."""
+import numpy as np
+
+from _util import write_camchain_yaml
+from oracle import rectify as orect
+
+
+def test_cubic_table_and_remap_known_answers():
+    tab = orect.cubic_table()
+    assert np.array_equal(tab[0], np.array([0, 1, 0, 0], np.float32))            # zero fraction: the pixel itself
+    assert np.allclose(tab.sum(1), 1.0, atol=1e-7)                                 # partition of unity
+    assert np.allclose(tab[16], [-0.09375, 0.59375, 0.59375, -0.09375])           # A = -0.75 at x = 1/2
+    rs = np.random.RandomState(0)
+    img = rs.rand(20, 30).astype(np.float32)
+    mx, my = np.meshgrid(np.arange(30, dtype=np.float32), np.arange(20, dtype=np.float32))
+    assert np.array_equal(orect.remap_cubic(img, mx, my), img)                    # identity map
+    out = orect.remap_cubic(img, mx + 2, my - 1)                                  # integer shift, zero border
+    assert np.array_equal(out[1:, :28], img[:-1, 2:]) and not out[0].any() and not out[:, 28:].any()
+    # half-pixel shift along x: the 1-D cubic kernel, rows untouched
+    out = orect.remap_cubic(img, mx + 0.5, my)
+    want = -0.09375 * img[:, 0:27] + 0.59375 * img[:, 1:28] + 0.59375 * img[:, 2:29] - 0.09375 * img[:, 3:30]
+    assert np.allclose(out[:, 1:28], want, atol=1e-6)
+    # 1/32-pixel quantisation of the coordinates (INTER_BITS = 5): 0.51 and 0.5 select the same table row
+    assert np.array_equal(orect.remap_cubic(img, mx + 0.51, my), out)
+
+
+def test_maps_match_oracle(tmp_path):
+    import yaml
+    from evfly_amd.calibration_tools import rectify_bag as rb
+    data = write_camchain_yaml(tmp_path / "K.yaml")
+    camsys = rb.CameraSystem(yaml.load(open(tmp_path / "K.yaml"), Loader=yaml.SafeLoader), fix_rotation=True)
+    assert camsys.event_cam.resolution == [640, 480] and camsys.cam.resolution == [848, 480]
+    maps = camsys.getRemapping()
+    assert maps["ev_mapx"].shape == (480, 640) and maps["ev_mapx"].dtype == np.float32
+    # undistorted pinhole with P = K: the map is the pixel grid
+    K = camsys.event_cam.K
+    mx, my = rb.init_undistort_rectify_map(K, np.zeros(4), None, K, (64, 48))
+    gx, gy = np.meshgrid(np.arange(64), np.arange(48))
+    assert np.abs(mx - gx).max() < 1e-4 and np.abs(my - gy).max() < 1e-4
+    # the vectorised product code against the per-pixel oracle on a sub-window of both maps
+    sub = (40, 24)
+    for cam, P in ((camsys.cam, camsys.newK @ camsys.newR @ camsys.cam.R.T),
+                   (camsys.event_cam, camsys.newK @ camsys.newR @ camsys.event_cam.R.T)):
+        a = rb.init_undistort_rectify_map(cam.K, cam.distortion_coeffs, None, P, sub)
+        b = orect.init_undistort_rectify_map(cam.K, cam.distortion_coeffs, None, P, sub)
+        for u, v in zip(a, b):
+            assert np.abs(u.astype(np.float64) - v).max() <= 1e-4      # float32 rounding of ~1e2-sized coordinates
+    # fix_rotation=True views the event camera through the frame camera's orientation (R^T, 0.02 rad about y): the
+    # principal point moves by about fx * tan(0.02) = 11 px along x and stays put along y; distortion moves the corners
+    u0, v0 = int(round(K[0, 2])), int(round(K[1, 2]))
+    assert abs(maps["ev_mapx"][v0, u0] - u0 - K[0, 0] * np.tan(0.02)) < 1.0 and abs(maps["ev_mapy"][v0, u0] - v0) < 1.0
+    assert abs(maps["ev_mapx"][0, 0] - 0.0) > 2.0
