@@ -168,3 +168,22 @@ def make_gray_pair(seed, H=120, W=160, change=0.25, identical=False, shift=True)
     b = a if identical else moved * (1.0 + change * (rs.rand(H, W) - 0.5))
     to8 = lambda v: np.clip(np.rint(v * 255), 0, 255).astype(np.uint8)
     return to8(a), to8(b)
+
+
+def make_time_sliced_case(seed, n_frames=4, H=60, W=80, n_events=40_000, t0_s=3.0):
+    """One trajectory for the dataset-side slicer (utils/to_events.py --acc_scheme time): int64-ns events, metadata
+    times in seconds starting at `t0_s` (so that the relative edges are ~1e7..1e9 ns and float32 rounding of the
+    comparison matters), a handful of events planted exactly on and next to the edges, and some coordinates on /
+    beyond the frame border."""
+    rs = np.random.RandomState(seed)
+    meta = t0_s + np.cumsum(np.r_[0.0, 0.03 + 0.01 * rs.rand(n_frames)])       # n_frames + 1 sample times [s]
+    edges = 1e9 * (meta - meta[0])
+    t = rs.randint(0, int(edges[-1]) + 5_000_000, n_events).astype(np.int64)
+    plant = np.concatenate([np.round(edges[1:]).astype(np.int64) + d for d in (-40, -33, -32, -1, 0, 1, 31, 32, 40)])
+    t[:plant.size] = plant
+    order = np.argsort(t, kind="stable")
+    x = rs.randint(0, W, n_events).astype(np.int64); y = rs.randint(0, H, n_events).astype(np.int64)
+    x[:8] = [W, W, W + 1, -1, 0, W - 1, 5, 5]; y[:8] = [3, H, 3, 3, H, H + 2, -2, H - 1]
+    p = (2 * rs.randint(0, 2, n_events) - 1).astype(np.int64)
+    p[8:12] = 0
+    return dict(x=x[order], y=y[order], t=t[order], p=p[order]), meta

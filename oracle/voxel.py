@@ -122,3 +122,23 @@ def batch_window_counts(batch, H, W, mode="timed"):
         out.append(window_counts(batch["x"][s], batch["y"][s], batch["t"][s], batch["p"][s],
                                  edges[b], H, W, mode))
     return np.stack(out)
+
+
+def to_events_time_frames(events, meta_times, traj_start, n_frames, H, W, pos_thresh=0.2, neg_thresh=0.2):
+    """utils/to_events.py:396-413 for one trajectory: events = dict of torch tensors x, y, t (int64 ns), p.
+    The comparisons are written exactly as there (`int64 tensor >= python float`, which torch evaluates in float32).
+    Returns float64 (n_frames, H, W)."""
+    import torch
+    ts = events["t"]
+    frames = np.zeros((n_frames, H, W))
+    for i in range(n_frames):
+        t_start = 1e9 * (meta_times[traj_start + i] - meta_times[traj_start])          # :404
+        t_end = 1e9 * (meta_times[traj_start + i + 1] - meta_times[traj_start])        # :405
+        win = torch.bitwise_and(ts >= t_start, ts < t_end)
+        pos = torch.bitwise_and(win, events["p"] > 0).cpu()                            # :407
+        neg = torch.bitwise_and(win, events["p"] < 0).cpu()                            # :408
+        rng = [[0, W], [0, H]]
+        hp = np.histogram2d(events["x"][pos].cpu().numpy(), events["y"][pos].cpu().numpy(), bins=(W, H), range=rng)[0]
+        hn = np.histogram2d(events["x"][neg].cpu().numpy(), events["y"][neg].cpu().numpy(), bins=(W, H), range=rng)[0]
+        frames[i] = (pos_thresh * hp - neg_thresh * hn).T                              # :411-413
+    return frames

@@ -329,6 +329,30 @@ def g10():
     save("g10_difflog", **out)
 
 
+# ------------------------------------------------------------------ G11: dataset-side time slicing (N2)
+def g11():
+    """utils/to_events.py is a script (argparse + esim at import time). Its time-slicing loop (:399-413) is lifted
+    out of the file with `ast` and executed here on synthetic events -- the reference's own statements."""
+    import ast
+    path = os.path.join(REF, "utils", "to_events.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    loops = [n for n in ast.walk(tree) if isinstance(n, ast.For) and isinstance(n.target, ast.Name) and n.target.id == "i"
+             and ast.unparse(n.iter) == "range(frames.shape[0])"]
+    assert len(loops) == 1, len(loops)
+    code = compile(ast.Module(body=[loops[0]], type_ignores=[]), path, "exec")
+    out = {}
+    for tag, seed, thr in (("a", 110, 0.2), ("b", 111, 0.35)):
+        ev, meta = syn.make_time_sliced_case(seed)
+        H, W, n = 60, 80, len(meta) - 1
+        ns = dict(np=np, torch=torch, events=[{k: torch.from_numpy(v) for k, v in ev.items()}], traj_idx=0,
+                  frames=np.zeros((n, H, W)), train_meta=np.stack([np.zeros_like(meta), meta], axis=1),
+                  train_trajstarts=[0], pos_thresh=thr, neg_thresh=thr)
+        ns["ts"] = ns["events"][0]["t"]                      # to_events.py:390
+        exec(code, ns)
+        out[tag] = ns["frames"]
+    save("g11_time_slices", **out)
+
+
 # ------------------------------------------------------------------ G0: state-dict key inventory
 def g0():
     import json
@@ -348,7 +372,7 @@ def g0():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     with torch.no_grad():
         for g in which:
             globals()[g]()

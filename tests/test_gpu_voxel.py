@@ -182,3 +182,20 @@ def test_conditioning_vs_golden_and_oracle(gpu_device):
     # all-zero frame: q = 0 -> 0/0 = NaN exactly like the reference expression
     z = voxelizer.condition_frames(np.zeros((1, 260, 346), np.float32))
     assert torch.isnan(z).all()
+
+
+def test_to_events_time_slicing_vs_golden(gpu_device):
+    """N2: utils/to_events.py --acc_scheme time (float64 frames, torch's float32 edge comparison) bit for bit."""
+    from _util import golden
+    from evfly_amd import to_events as te
+    g = golden("g11_time_slices")
+    for tag, seed, thr in (("a", 110, 0.2), ("b", 111, 0.35)):
+        ev, meta = syn.make_time_sliced_case(seed)
+        edges = te.frame_window_edges_ns(meta, 0, len(meta) - 1)
+        fr = te.slice_trajectory(ev, edges, 60, 80, thr, thr)
+        assert fr.dtype == np.float64 and fr.shape == g[tag].shape
+        assert np.array_equal(fr, g[tag])
+        # unsorted input (the reference masks, it never sorts) gives the same frames
+        perm = np.random.RandomState(1).permutation(len(ev["t"]))
+        fr2 = te.slice_trajectory({k: v[perm] for k, v in ev.items()}, edges, 60, 80, thr, thr)
+        assert np.array_equal(fr2, g[tag])

@@ -236,6 +236,39 @@ def test_velpred_shell_errors():
         lm.DynamicFCNet(4, 1, [1], ["tanh"], logger=lambda *a: None)(torch.zeros(1, 4))
 
 
+# ------------------------------------------------------------------ G11 dataset-side time slicing (N2)
+def test_to_events_time_frames_oracle(tmp_path):
+    from evfly_amd import to_events as te
+    from oracle import voxel as ov
+    g = golden("g11_time_slices")
+    for tag, seed, thr in (("a", 110, 0.2), ("b", 111, 0.35)):
+        ev, meta = syn.make_time_sliced_case(seed)
+        evt = {k: torch.from_numpy(v) for k, v in ev.items()}
+        fr = ov.to_events_time_frames(evt, meta, 0, len(meta) - 1, 60, 80, thr, thr)
+        assert fr.dtype == np.float64 and np.array_equal(fr, g[tag])
+        # host logic of the product: the int64 thresholds reproduce torch's float32 comparison for every event
+        edges = te.frame_window_edges_ns(meta, 0, len(meta) - 1)
+        ei = te.float32_compare_edges(edges)
+        for k, e in enumerate(edges):
+            assert np.array_equal((evt["t"] >= float(e)).numpy(), ev["t"] >= ei[k])
+    # brute force around float32 rounding boundaries, incl. timestamps of minutes (spacing up to 16384 ns)
+    rs = np.random.RandomState(0)
+    es = np.concatenate([rs.rand(50) * 1e9, rs.rand(50) * 3e11, [0.0, 1.0, 16777216.0, 16777217.0, 2.0 ** 31 + 3]])
+    ei = te.float32_compare_edges(es)
+    for e, t0 in zip(es, ei):
+        probe = torch.arange(int(t0) - 3, int(t0) + 4, dtype=torch.int64)
+        assert (probe >= float(e)).tolist() == [False] * 3 + [True] * 4, (e, t0)
+    # evs_frames.npy container rule (to_events.py:441-456) and the loader of dataloading.py:164
+    one = [np.ones((3, 4, 5))]
+    te.save_evs_frames(tmp_path / "one.npy", one)
+    a = te.load_evs_frames(tmp_path / "one.npy")
+    assert a.dtype == np.float64 and a.shape == (1, 3, 4, 5)
+    two = [np.ones((3, 4, 5)), np.zeros((2, 4, 5))]
+    te.save_evs_frames(tmp_path / "two.npy", two)
+    b = te.load_evs_frames(tmp_path / "two.npy")
+    assert b.dtype == object and b.shape == (2,) and b[1].shape == (2, 4, 5) and np.array_equal(b[0], two[0])
+
+
 # ------------------------------------------------------------------ G10 simulator difflog events (N4)
 def test_difflog_events_oracle():
     from oracle import sim as osim
