@@ -18,7 +18,7 @@ def _worker(rank, world, port, n_streams, T, q):
     # velocity rows of this rank's streams: row value encodes (stream, t) so order is checkable
     vel = torch.tensor([[s, t, s * 100 + t] for s in range(s0, s1) for t in range(T)], dtype=torch.float32).reshape(-1, 3)
     out = gather_velocities(vel, dist)
-    q.put((rank, out))
+    q.put((rank, out.tolist()))          # plain lists: no shared-memory handle that dies with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -38,7 +38,7 @@ def test_shard_and_gather(n_streams):
         assert p.exitcode == 0
     want = torch.tensor([[s, t, s * 100 + t] for s in range(n_streams) for t in range(T)], dtype=torch.float32)
     for r in range(world):
-        assert torch.equal(outs[r], want)
+        assert torch.equal(torch.tensor(outs[r]), want)
 
 
 def test_shard_covers_all_streams():
