@@ -43,8 +43,8 @@ struct ConvDesc {
     int up_cout = 0;            // OUT_UPCONV2X2: n = (dy*2+dx)*up_cout + co, bias indexed by co
     int dtype = EVFLY_DTYPE_F32;
     const float *zeros = nullptr;   // >= 16 B of zeros in global memory (set by igemm_launch)
-    // optional second output of the halo-tiled 3x3 kernel: 2x2/stride-2 max pool (floor) of the activated
-    // output, NHWC [NI][OH/2][OW/2][Nc] contiguous (nn.MaxPool2d(2, 2) fused into the producer)
+    // optional second output of the Winograd 3x3 kernel: 2x2/stride-2 max pool (floor) of the activated output,
+    // NHWC [NI][OH/2][OW/2][Nc] contiguous (nn.MaxPool2d(2, 2) fused into the producer)
     float *y_pool = nullptr;
 };
 
@@ -70,10 +70,6 @@ int igemm_launch(const ConvDesc &d, hipStream_t st);
 
 // >= 256 B of zeros in global memory on the current device (source of masked LDS-DMA rows)
 int igemm_zero_page(const float **out);
-
-// Halo-tiled 3x3 valid conv for wide shallow layers (conv3x3_halo.hip); same ConvDesc contract.
-bool conv3x3_halo_applicable(const ConvDesc &d);
-int conv3x3_halo_launch(const ConvDesc &d, hipStream_t st);
 
 // Winograd F(2x2,3x3) kernel (wino.hip): same ConvDesc contract plus the pre-transformed weights U = G g G^T in the
 // streamed layout of wino_u_index (wino_u_floats(cout, cin) floats). Supports d.y_pool.

@@ -454,10 +454,8 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
         RUN(m, pn.c_str(), igemm_flops(d), bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;
     }
-    const bool halo = conv3x3_halo_applicable(d);
-    if (halo) d.y_pool = y_pool;                               // nn.MaxPool2d(2,2) fused into the producer
-    if (pool_fused) *pool_fused = halo && y_pool != nullptr;
-    RUN(m, pn.c_str(), igemm_flops(d), bytes, halo ? conv3x3_halo_launch(d, m->st) : igemm_launch(d, m->st));
+    if (pool_fused) *pool_fused = false;
+    RUN(m, pn.c_str(), igemm_flops(d), bytes, igemm_launch(d, m->st));
     return 0;
 }
 
@@ -987,6 +985,5 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
         if (int rc = wino_pack_device(w_packed, cout, cin, (int64_t)9 * cin, 1, cin, static_cast<float *>(u), as_stream(stream))) return rc;
         return wino_launch(d, static_cast<const float *>(u), as_stream(stream));
     }
-    if (conv3x3_halo_applicable(d)) return conv3x3_halo_launch(d, as_stream(stream));
     return igemm_launch(d, as_stream(stream));
 }

@@ -10,11 +10,12 @@
 // equals (tile index + const) & 15 -- the 16 lanes of every ds_read_b128 group hold 16 raster-consecutive tiles
 // (mod 16), so every fragment read is bank-conflict free for every plan (TY, TX, IMGS). For each of the 16 Winograd positions (a, b) the MFMA computes
 // M_ab[tile, n] += V_ab[tile, c] * U_ab[n, c]:
-//   * V = B^T d B is formed IN REGISTERS from twelve ds_read_b128 of the raw patch (2 v_add per MFMA operand);
+//   * V = B^T d B is formed IN REGISTERS from eight ds_read_b128 of the raw patch (one v_fma for the row
+//     combination, one v_add / v_sub per MFMA operand for the column combination);
 //   * U = G g G^T is precomputed at weight-pack time and streamed from L2 straight into the B-operand registers,
 //     8 B per lane, in exactly the order the waves consume it (one linear pointer, prefetched one step ahead).
-// Wave w = (mt, ah): M-tile mt (32 of the 64 tiles) x position rows a in {2ah, 2ah+1} x all four b: 8 accumulator
-// tiles = 128 registers. The output transform is lane-local along b; along a the two waves of a pair swap halves
+// Wave w = (mt, a): M-tile mt (32 of the 64 tiles) x position row a x all four b: 4 accumulator tiles = 64
+// registers. The output transform is lane-local along b; along a the four waves of an M-tile trade partial sums
 // through LDS. nn.MaxPool2d(2, 2) fuses trivially: a Winograd tile IS one pooling window.
 #include "igemm.h"
 
@@ -46,199 +47,10 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
-// one 32-channel chunk of the K loop for a wave with position rows {2*AH, 2*AH+1}.
-// off0[r][c/2]: byte offset of patch pixel (row r, column c & ~1) of this lane's tile, chunk slot of k-half fh at j = 0;
-// slot = ((c & 1) * 8 + 2j + fh) ^ key, so step j is a byte-offset XOR of 32*j and the odd column one of 128.
-constexpr bool DMA_EARLY = true;    // true: issue the next chunk's DMA after the last fragment reads (more overlap, more registers)
-
-template <int AH, typename Dma>
-__device__ __forceinline__ void wino_chunk(const char *__restrict__ patch, const int (&off0)[3][2],
-                                           const float2 *__restrict__ &ub, float2 (&bcur)[8], f32x16 (&acc)[8], Dma &&dma_next) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // row transform right after the loads: t0 / t1 = the wave's two rows of B^T d, four k-values per float4
-        float4 t0[4], t1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            // columns 0,1 are one pixel pair, columns 2,3 the next: two offsets per row; j and the odd column are XORs
-            const float4 r0 = *reinterpret_cast<const float4 *>(patch + (opaque(off0[0][c >> 1]) ^ ((j << 5) | ((c & 1) << 7))));
-            const float4 r1 = *reinterpret_cast<const float4 *>(patch + (opaque(off0[1][c >> 1]) ^ ((j << 5) | ((c & 1) << 7))));
-            const float4 r2 = *reinterpret_cast<const float4 *>(patch + (opaque(off0[2][c >> 1]) ^ ((j << 5) | ((c & 1) << 7))));
-            if (AH == 0) {   // a = 0: d0 - d2 ; a = 1: d1 + d2   (patch rows 0,1,2)
-                t0[c] = make_float4(r0.x - r2.x, r0.y - r2.y, r0.z - r2.z, r0.w - r2.w);
-                t1[c] = make_float4(r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w);
-            } else {         // a = 2: d2 - d1 ; a = 3: d1 - d3   (patch rows 1,2,3)
-                t0[c] = make_float4(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z, r1.w - r0.w);
-                t1[c] = make_float4(r0.x - r2.x, r0.y - r2.y, r0.z - r2.z, r0.w - r2.w);
-            }
-        }
-        // the last fragment reads of this chunk are issued: start the DMA of the next chunk into the other buffer
-        // (hipcc orders every later ds_read behind outstanding LDS-DMA, so it must not come earlier)
-        if (j == 3 && DMA_EARLY) dma_next();
-#pragma unroll
-        for (int hg = 0; hg < 2; ++hg) {
-            // position-outer: both k-values of U_p are consumed back to back, then the same registers are refilled
-            // for the next half-group: one set of B registers, ~15 MFMAs (1 us) of prefetch distance. The refill is
-            // unconditional (straight-line code): the U buffer carries one half-group of slack behind its last step.
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const float4 *t = p < 4 ? t0 : t1;
-                float va, vb;
-                const int e = 2 * hg, b = p & 3;
-                if (b == 0)      { va = f4e(t[0], e) - f4e(t[2], e); vb = f4e(t[0], e + 1) - f4e(t[2], e + 1); }
-                else if (b == 1) { va = f4e(t[1], e) + f4e(t[2], e); vb = f4e(t[1], e + 1) + f4e(t[2], e + 1); }
-                else if (b == 2) { va = f4e(t[2], e) - f4e(t[1], e); vb = f4e(t[2], e + 1) - f4e(t[1], e + 1); }
-                else             { va = f4e(t[1], e) - f4e(t[3], e); vb = f4e(t[1], e + 1) - f4e(t[3], e + 1); }
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, bcur[p].x, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, bcur[p].y, acc[p], 0, 0, 0);
-                bcur[p] = ub[p * 64];
-            }
-            ub += 16 * 64;
-        }
-    }
-    if (!DMA_EARLY) dma_next();
-}
-
-__global__ __launch_bounds__(256, 2) void k_wino(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;
-
-    const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
-    const int bt = xcd * g.cpx + slot / g.n_nt, nt = slot % g.n_nt;
-    if (bt >= g.n_btiles) return;
-    const int bxi = bt % g.bx, byi = (bt / g.bx) % g.by, big = bt / (g.bx * g.by);
-    const int img0 = big * g.IMGS, ty0 = byi * g.TY, tx0 = bxi * g.TX;        // first image / tile row / tile col
-    const int n0 = nt * 32;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int mt = wv & 1, ah = wv >> 1;
-    const int fm = lane & 31, fh = lane >> 5;
-
-    // this lane's tile as MFMA row fm of M-tile mt
-    int off0[3][2];
-    {
-        int t = mt * 32 + fm;
-        if (t >= g.ntiles) t = 0;
-        const int per = g.TY * g.TX;
-        const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int py = 2 * ty + ah + r, pxh = tx + c;
-                const int pp = (im * g.PH + py) * (g.PW >> 1) + pxh;
-                const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
-                off0[r][c] = pp * 256 + ((fh ^ key) << 4);
-            }
-    }
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-
-    const int nchunks = d.C / 32;
-    // U stream of this wave: [nt][cc][j][hg][pos 16][lane 64][2]; the wave reads pos 8*ah .. 8*ah+7
-    const float2 *ub = reinterpret_cast<const float2 *>(U) + ((int64_t)nt * nchunks * 8 * 16 + 8 * ah) * 64 + lane;
-    float2 bcur[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) bcur[p] = ub[p * 64];
-    ub += 16 * 64;
-
-    const int iy0 = 2 * ty0, ix0 = 2 * tx0;
-    const int buf_floats = g.ngroups * 8 * 32;
-    auto dma = [&](int cc, float *dst) {
-        if (g.dbg & 1) return;
-        const int pl = lane >> 4, sp = lane & 15;      // DMA lane role: pixel pair within the group of 4, 16-B slot
-        for (int gi = wv; gi < g.ngroups; gi += 4) {
-            const int pp = gi * 4 + pl;
-            const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
-            const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
-            const int sl = sp ^ ((pxh + (py >> 1) * g.TX + im * (g.TY * g.TX)) & 15);   // content of this LDS slot
-            const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
-            const int iy = iy0 + py, ix = ix0 + px, img = img0 + im;
-            const bool ok = 2 * pp < g.npix && img < d.NI && iy < d.H && ix < d.W;
-            const float *src = ok ? d.x + (((int64_t)img * d.H + iy) * d.W + ix) * d.ldx + cc * 32 + ch * 4 : d.zeros;
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + gi * 8 * 32), 16, 0, 0);
-        }
-    };
-    dma(0, patch);
-    for (int cc = 0; cc < nchunks; ++cc) {
-        __syncthreads();            // chunk cc has landed (vmcnt(0) + barrier); everyone is done reading the other buffer
-        const char *cur = reinterpret_cast<const char *>(patch + (cc & 1) * buf_floats);
-        float *nxt = patch + ((cc + 1) & 1) * buf_floats;
-        const bool last = cc == nchunks - 1;
-        auto next = [&]() { if (!last) dma(cc + 1, nxt); };
-        if (ah == 0) wino_chunk<0>(cur, off0, ub, bcur, acc, next);
-        else wino_chunk<1>(cur, off0, ub, bcur, acc, next);
-    }
-
-    // ---- output transform. Along b (lane-local): s_a0 = M_a0 + M_a1 + M_a2, s_a1 = M_a1 - M_a2 - M_a3.
-    // Along a: Y_0x = s_0x + s_1x + s_2x, Y_1x = s_1x - s_2x - s_3x. Wave ah = 0 owns output row i = 0, ah = 1 row 1;
-    // each sends the other its contribution through LDS.
-    __syncthreads();                                   // all waves are done with the patch
-    float *xch = smem;                                 // [wave 4][x 2][r 16][lane 64]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float sA0 = acc[0][r] + acc[1][r] + acc[2][r], sA1 = acc[1][r] - acc[2][r] - acc[3][r];   // a = 2ah
-        const float sB0 = acc[4][r] + acc[5][r] + acc[6][r], sB1 = acc[5][r] - acc[6][r] - acc[7][r];   // a = 2ah + 1
-        // ah = 0: Y0 += s0 + s1, sends s1 to row 1;  ah = 1: Y1 += -s2 - s3, sends s2 to row 0
-        xch[((wv * 2 + 0) * 16 + r) * 64 + lane] = ah == 0 ? sB0 : sA0;
-        xch[((wv * 2 + 1) * 16 + r) * 64 + lane] = ah == 0 ? sB1 : sA1;
-        acc[0][r] = ah == 0 ? sA0 + sB0 : -sA0 - sB0;
-        acc[1][r] = ah == 0 ? sA1 + sB1 : -sA1 - sB1;
-    }
-    __syncthreads();
-    const int partner = wv ^ 2;
-    const int n = n0 + fm;
-    const bool nok = n < d.Nc;
-    const float bias = (d.bias && nok) ? d.bias[n] : 0.f;
-    const int per = g.TY * g.TX;
-    float rowmax[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-        const int img = img0 + im, oy = 2 * (ty0 + ty) + ah, ox = 2 * (tx0 + tx);
-        const bool ok = nok && t < g.ntiles && img < d.NI && oy < d.OH;
-        float y0 = acc[0][r] + xch[((partner * 2 + 0) * 16 + r) * 64 + lane] + bias;
-        float y1 = acc[1][r] + xch[((partner * 2 + 1) * 16 + r) * 64 + lane] + bias;
-        y0 = apply_act(y0, d.act); y1 = apply_act(y1, d.act);
-        rowmax[r] = (y0 > y1 || y0 != y0) ? y0 : y1;
-        if (ok && !(g.dbg & 4)) {
-            float *dst = d.y + (((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy + n;
-            if (ox < d.OW) dst[0] = y0;
-            if (ox + 1 < d.OW) dst[d.ldy] = y1;
-        }
-    }
-    if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): window == Winograd tile; rows i = 0 / 1 live in the two waves of a pair
-        __syncthreads();
-        if (ah == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xch[(mt * 16 + r) * 64 + lane] = rowmax[r];
-        }
-        __syncthreads();
-        if (ah == 0) {
-            const int PHo = d.OH / 2, PWo = d.OW / 2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-                const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx;
-                const float o = xch[(mt * 16 + r) * 64 + lane];
-                const float v = (rowmax[r] > o || rowmax[r] != rowmax[r]) ? rowmax[r] : o;
-                if (nok && t < g.ntiles && img < d.NI && gy < PHo && gx < PWo)
-                    d.y_pool[(((int64_t)img * PHo + gy) * PWo + gx) * d.Nc + n] = v;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------- 8-wave variant
-// Same block tile (<= 64 Winograd tiles x 32 output channels) split over EIGHT waves: wave = (M-tile mt, position row
-// a in 0..3), four accumulator tiles (64 registers) instead of eight. Everything fits in 128 VGPRs, so four waves
-// per SIMD (two 512-thread blocks per CU) hide the LDS, L2 and barrier latencies that the 4-wave kernel exposes.
+// ---------------------------------------------------------------------------------------------------- kernel
+// Block tile (<= 64 Winograd tiles x 32 output channels) over EIGHT waves: wave = (M-tile mt, position row a in
+// 0..3), four accumulator tiles (64 registers). Everything fits in 128 VGPRs: four waves per SIMD, two 512-thread
+// blocks per CU. (A 4-wave variant with 8 positions per wave measured the same speed at twice the registers.)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino8(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;
@@ -323,7 +135,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 t[c] = make_float4(fmaf(sg, v.x, u.x), fmaf(sg, v.y, u.y), fmaf(sg, v.z, u.z), fmaf(sg, v.w, u.w));
             }
-            // last fragment reads of the chunk are issued: the next chunk's DMA may start (see wino_chunk)
+            // last fragment reads of the chunk are issued: the next chunk's DMA may start (hipcc orders every
+            // later ds_read behind an outstanding LDS-DMA with vmcnt(0), so it must not be issued earlier)
             if (j == 3 && cc + 1 < nchunks) dma(cc + 1, patch + ((cc + 1) & 1) * buf_floats);
 #pragma unroll
             for (int hg = 0; hg < 2; ++hg) {
@@ -525,19 +338,17 @@ int wino_launch(const ConvDesc &d_in, const float *U, hipStream_t st) {
     EVFLY_REQUIRE(plan(d, g), "wino: no tile plan");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
     if (int rc = igemm_zero_page(&d.zeros)) return rc;
-    static const int variant = getenv("EVFLY_WINO_WAVES") ? atoi(getenv("EVFLY_WINO_WAVES")) : 8;
-    const int lds = std::max(2 * g.ngroups * 8 * 32 * 4, variant == 8 ? (2 * 6 * 16 * 64 + 64 * 4 * 32) * 4 : 4 * 2 * 16 * 64 * 4);
+    // two patch buffers; the epilogue reuses them for the exchange sets (48 KB) + the transposed output tile (32 KB)
+    const int lds = std::max(2 * g.ngroups * 8 * 32 * 4, (2 * 6 * 16 * 64 + 64 * 4 * 32) * 4);
     static bool lds_set = false;
     if (!lds_set) {
-        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino8), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         lds_set = true;
     }
     if (getenv("EVFLY_WINO_DBG"))
         fprintf(stderr, "wino: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, eff %.2f\n", d.NI, d.OH, d.OW,
                 d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, wino_efficiency(d));
-    if (variant == 8) hipLaunchKernelGGL(k_wino8, dim3(kNumXCD * g.cpx * g.n_nt), dim3(512), lds, st, d, U, g);
-    else hipLaunchKernelGGL(k_wino, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256), lds, st, d, U, g);
+    hipLaunchKernelGGL(k_wino8, dim3(kNumXCD * g.cpx * g.n_nt), dim3(512), lds, st, d, U, g);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
