@@ -38,7 +38,8 @@ struct WinoGeom {
     int bx, by, bi;             // blocks along x, y, image groups
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
-    int dbg;                    // ablation switches (EVFLY_WINO_ABL): 1 no patch DMA, 4 no stores
+    double cost;                // plan cost (launched tile slots + weighted patch pixels)
+    int dbg;                    // ablation switches (EVFLY_WINO_ABL): 1 no patch DMA, 4 no stores, 8 no LDS reads, 16 no U loads, 32 K loop twice
 };
 
 // Opaque identity: stops hipcc from hoisting the per-step address XORs out of the chunk loop (LICM would turn six
@@ -48,10 +49,14 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
 // ---------------------------------------------------------------------------------------------------- kernel
-// Block tile (<= 64 Winograd tiles x 32 output channels) over EIGHT waves: wave = (M-tile mt, position row a in
-// 0..3), four accumulator tiles (64 registers). Everything fits in 128 VGPRs: four waves per SIMD, two 512-thread
-// blocks per CU. (A 4-wave variant with 8 positions per wave measured the same speed at twice the registers.)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino8(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
+// Block tile = MT M-tiles of 32 Winograd tiles x 32 output channels over 4*MT waves: wave = (M-tile mt, position row
+// a in 0..3), four accumulator tiles (64 registers). Everything fits in 128 VGPRs: four waves per SIMD. MT = 2
+// (512 threads, 80 KB LDS, two blocks per CU) halves the halo and U traffic per MFMA; MT = 1 (256 threads, <= 40 KB
+// LDS, four blocks per CU) keeps four independent blocks in flight, which matters for the one- and two-chunk layers
+// whose load / MFMA / store phases are of similar length (e12: 64 MFMAs per wave between a cold DMA and the stores).
+template <int MT>
+__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino8(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
+    constexpr int NW = 4 * MT, NTHR = 256 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;
 
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int n0 = nt * 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs
-    const int mt = wv & 1, a = wv >> 1;
+    const int mt = MT == 2 ? (wv & 1) : 0, a = MT == 2 ? (wv >> 1) : wv;
     const int fm = lane & 31, fh = lane >> 5;
     const int per = g.TY * g.TX;
 
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     auto dma = [&](int cc, float *dst) {
         if (g.dbg & 1) return;
         const int pl = lane >> 4, sp = lane & 15;
-        for (int gi = wv; gi < g.ngroups; gi += 8) {
+        for (int gi = wv; gi < g.ngroups; gi += NW) {
             const int pp = gi * 4 + pl;
             const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
             const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
@@ -118,6 +123,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     };
     dma(0, patch);
+    const int reps = (g.dbg & 32) ? 2 : 1;      // timing experiment: walk the K loop twice (results are garbage)
+    for (int rep = 0; rep < reps; ++rep)
     for (int cc = 0; cc < nchunks; ++cc) {
         __syncthreads();            // chunk cc has landed; everyone is done reading the other buffer
         const char *cur = reinterpret_cast<const char *>(patch + (cc & 1) * buf_floats);
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     //   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
     // sets in LDS: k0 = s_01, k1 = s_10, k2 = s_11, k3 = s_20, k4 = s_21, k5 = s_30
     __syncthreads();
-    float *xch = smem;                                 // [mt 2][set 6][r 16][lane 64]  = 48 KB
+    float *xch = smem;                                 // [mt MT][set 6][r 16][lane 64]  = MT x 24 KB
     auto at = [&](int k, int r) -> float & { return xch[((mt * 6 + k) * 16 + r) * 64 + lane]; };
     float own[16];
 #pragma unroll
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float bias = (d.bias && nokl) ? d.bias[n0 + fm] : 0.f;
     // finished pixels go to LDS as [tile 64][pixel 4][channel 32] so that the global stores are 16-B vectors and the
     // index arithmetic runs once per four channels instead of once per value
-    float *ot = smem + 2 * 6 * 16 * 64;                // 32 KB behind the exchange sets
+    float *ot = smem + MT * 6 * 16 * 64;               // MT x 16 KB behind the exchange sets
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int idx = tid + q * 512, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
+        const int idx = tid + q * NTHR, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
         const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
         const int img = img0 + im, oy = 2 * (ty0 + ty) + (pix >> 1), ox = 2 * (tx0 + tx) + (pix & 1), n = n0 + c4 * 4;
         if (tl >= g.ntiles || img >= d.NI || oy >= d.OH || ox >= d.OW || n >= d.Nc || (g.dbg & 4)) continue;
@@ -258,24 +265,25 @@ __global__ void k_wino_weights(const float *__restrict__ w, int cout, int cin, i
     for (int p = 0; p < 16; ++p) U[wino_u_index(n, c, p, cin / 32)] = u[p];
 }
 
-bool plan(const ConvDesc &d, WinoGeom &g) {
+// MT: M-tiles per block; max_px: patch budget (pixels) of one LDS buffer
+bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
+    const int slots = 32 * MT;
     const int tiles_y = cdiv(d.OH, 2), tiles_x = cdiv(d.OW, 2);
-    double best = 0;
-    int best_np = 1 << 30;
+    // cost of a plan ~ launched work: every block pays its tile slots (MFMA time, used or not) and its patch pixels
+    // (DMA + LDS traffic; ~5 px per tile for a square arrangement, far more for thin ones)
+    double best = -1;
     for (int IM = 1; IM <= 4; ++IM)
         for (int TY = 1; TY <= std::min(tiles_y, 32); ++TY)
             for (int TX = 1; TX <= std::min(tiles_x, 32); ++TX) {
-                if (IM * TY * TX > 64) break;
+                if (IM * TY * TX > slots) break;
                 const int np = IM * (2 * TY + 2) * (2 * TX + 2);
-                if (np > 320) continue;      // two buffers of 320 px x 128 B = 80 KB: two blocks per CU
+                if (np > max_px) continue;
                 const int64_t blocks = (int64_t)cdiv(tiles_y, TY) * cdiv(tiles_x, TX) * cdiv(d.NI, IM);
-                const double eff = (double)d.NI * tiles_y * tiles_x / (64.0 * blocks);
-                if (eff > best + 1e-9 || (eff > best - 1e-9 && np < best_np)) {
-                    best = eff; best_np = np;
-                    g.IMGS = IM; g.TY = TY; g.TX = TX;
-                }
+                const double cost = (double)blocks * (slots + 0.1 * np);
+                if (best < 0 || cost < best) { best = cost; g.IMGS = IM; g.TY = TY; g.TX = TX; }
             }
-    if (best <= 0) return false;
+    if (best < 0) return false;
+    g.cost = best;
     g.PH = 2 * g.TY + 2; g.PW = 2 * g.TX + 2;
     g.npix = g.IMGS * g.PH * g.PW;
     g.ngroups = cdiv(g.npix, 8);
@@ -319,38 +327,74 @@ bool wino_applicable(const ConvDesc &d) {
            d.out_mode == OUT_ROWS && !d.res && d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0 && d.OH >= 1 && d.OW >= 1;
 }
 
-double wino_efficiency(const ConvDesc &d) {
-    WinoGeom g;
-    if (!plan(d, g)) return 0;
-    return (double)d.NI * cdiv(d.OH, 2) * cdiv(d.OW, 2) / (64.0 * g.n_btiles);
+namespace {
+
+struct WinoCfg { int MT, nbuf, max_px; };
+
+// One-chunk layers (C_in = 32: e12, e21, d42) run 256-thread blocks with a single patch buffer, four per CU; the
+// others 512-thread blocks with two 40 KB buffers, two per CU, unless the small block fills its tile slots much
+// better (MT = 1 on a multi-chunk layer: two 26 KB buffers, three blocks per CU). EVFLY_WINO_MT = 1 / 2 forces one.
+WinoCfg choose(const ConvDesc &d) {
+    static const int force = getenv("EVFLY_WINO_MT") ? atoi(getenv("EVFLY_WINO_MT")) : 0;
+    const int nchunks = d.C / 32;
+    const WinoCfg c2{2, nchunks > 1 ? 2 : 1, 320};
+    const WinoCfg c1 = nchunks == 1 ? WinoCfg{1, 1, 320} : WinoCfg{1, 2, 208};
+    if (force) return force == 2 ? c2 : c1;
+    if (nchunks == 1) return c1;
+    // multi-chunk layers: the small block is 5-15 % slower at equal tile efficiency (handicap 1.08) (measured on e32 / e42 / d11), but
+    // wins when 64-tile blocks fill badly (e51: 40 tiles per image)
+    WinoGeom g1, g2;
+    const bool ok1 = plan(d, g1, c1.MT, c1.max_px), ok2 = plan(d, g2, c2.MT, c2.max_px);
+    if (ok1 && ok2) return 1.08 * g1.cost < g2.cost ? c1 : c2;
+    return ok2 ? c2 : c1;
 }
 
-// matrix-core flops the launch issues: 16 positions x 64 tile slots x 32-channel slices x C_in, times 2
+template <int MT>
+int launch(const ConvDesc &d, const float *U, const WinoGeom &g, const WinoCfg &c, hipStream_t st) {
+    // patch buffer(s); the epilogue reuses them for the exchange sets (MT x 24 KB) + the transposed tile (MT x 16 KB)
+    const int lds = std::max(c.nbuf * g.ngroups * 8 * 32 * 4, MT * 40 * 1024);
+    auto kern = k_wino8<MT>;
+    static bool lds_set = false;
+    if (!lds_set) {
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        lds_set = true;
+    }
+    if (getenv("EVFLY_WINO_DBG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256 * MT, lds);
+        fprintf(stderr, "wino<%d>: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, %d B LDS, %d blocks/CU\n", MT, d.NI,
+                d.OH, d.OW, d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, lds, nb);
+    }
+    hipLaunchKernelGGL(kern, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256 * MT), lds, st, d, U, g);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+double wino_efficiency(const ConvDesc &d) {
+    WinoGeom g;
+    const WinoCfg c = choose(d);
+    if (!plan(d, g, c.MT, c.max_px)) return 0;
+    return (double)d.NI * cdiv(d.OH, 2) * cdiv(d.OW, 2) / (32.0 * c.MT * g.n_btiles);
+}
+
+// matrix-core flops the launch issues: 16 positions x tile slots x 32-channel slices x C_in, times 2
 double wino_exec_flops(const ConvDesc &d) {
     WinoGeom g;
-    if (!plan(d, g)) return 0;
-    return 2.0 * 16.0 * ((double)g.n_btiles * 64.0) * ((double)g.n_nt * 32.0) * d.C;
+    const WinoCfg c = choose(d);
+    if (!plan(d, g, c.MT, c.max_px)) return 0;
+    return 2.0 * 16.0 * ((double)g.n_btiles * 32.0 * c.MT) * ((double)g.n_nt * 32.0) * d.C;
 }
 
 int wino_launch(const ConvDesc &d_in, const float *U, hipStream_t st) {
     ConvDesc d = d_in;
     WinoGeom g;
-    EVFLY_REQUIRE(plan(d, g), "wino: no tile plan");
+    const WinoCfg c = choose(d);
+    EVFLY_REQUIRE(plan(d, g, c.MT, c.max_px), "wino: no tile plan");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
     if (int rc = igemm_zero_page(&d.zeros)) return rc;
-    // two patch buffers; the epilogue reuses them for the exchange sets (48 KB) + the transposed output tile (32 KB)
-    const int lds = std::max(2 * g.ngroups * 8 * 32 * 4, (2 * 6 * 16 * 64 + 64 * 4 * 32) * 4);
-    static bool lds_set = false;
-    if (!lds_set) {
-        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino8), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        lds_set = true;
-    }
-    if (getenv("EVFLY_WINO_DBG"))
-        fprintf(stderr, "wino: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, eff %.2f\n", d.NI, d.OH, d.OW,
-                d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, wino_efficiency(d));
-    hipLaunchKernelGGL(k_wino8, dim3(kNumXCD * g.cpx * g.n_nt), dim3(512), lds, st, d, U, g);
-    EVFLY_LAUNCH_CHECK();
-    return 0;
+    return c.MT == 2 ? launch<2>(d, U, g, c, st) : launch<1>(d, U, g, c, st);
 }
 
 }  // namespace evfly
