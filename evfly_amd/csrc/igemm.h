@@ -46,6 +46,13 @@ struct ConvDesc {
     // optional second output of the Winograd 3x3 kernel: 2x2/stride-2 max pool (floor) of the activated output,
     // NHWC [NI][OH/2][OW/2][Nc] contiguous (nn.MaxPool2d(2, 2) fused into the producer)
     float *y_pool = nullptr;
+    // optional fused producer (Winograd kernel, C == 32 only): x is not read; input pixel (iy, ix) is
+    // relu(conv3x3(form(pre_frames))[iy][ix]) of the FIRST U-Net conv (learner_models.py:476-494,533), computed on
+    // the fly while the patch is staged. pre_frames (NI, H + 2, W + 2) raw conditioned frames, pre_w [9 * cin][32],
+    // pre_b [32] (the packing of launch_e11), same fmaf order as k_e11.
+    const float *pre_frames = nullptr, *pre_w = nullptr, *pre_b = nullptr;
+    int pre_cin = 0, pre_form_bev = 0, pre_apply_form = 0;
+    float pre_cutoff = 0.f;
 };
 
 // Fills OH/OW/M/K from the geometry (conv arithmetic of torch.nn.Conv2d).

@@ -110,6 +110,8 @@ struct evfly_model {
     // ------------------------------------------------------------------ profiling
     std::string prof_filter;   // non-empty: only launch sites whose name starts with it are bracketed by events
     bool prof_skipped = false;
+    // fused first-conv producer for the next conv() call (consumed and cleared there; Winograd path only)
+    struct { const float *frames = nullptr, *w = nullptr, *b = nullptr; int cin = 0, form_bev = 0, apply_form = 0; float cutoff = 0.f; } pre;
     double next_exec = 0;   // set by conv() before RUN when the kernel issues fewer flops than the algorithmic count
     int prof_begin(const char *name, double flops, double bytes) {
         const double ex = next_exec > 0 ? next_exec : flops;
@@ -447,13 +449,21 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", wname.c_str());
     const double bytes = 4.0 * ((double)n * H * W * C + (double)d.M * cout + (double)cout * d.K);
     const std::string pn = std::string(pname) + "/" + wname;   // family/layer: bench.py groups by family
+    double extra_flops = 0;
+    if (m->pre.frames) {                                       // first U-Net conv computed on the fly by the consumer
+        d.pre_frames = m->pre.frames; d.pre_w = m->pre.w; d.pre_b = m->pre.b; d.pre_cin = m->pre.cin;
+        d.pre_form_bev = m->pre.form_bev; d.pre_apply_form = m->pre.apply_form; d.pre_cutoff = m->pre.cutoff;
+        extra_flops = 2.0 * n * H * W * C * 9 * m->pre.cin;
+        m->pre.frames = nullptr;
+    }
     if (wino_applicable(d) && m->has(wname + ".u")) {          // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
         d.y_pool = y_pool;                                     // nn.MaxPool2d(2,2): one window per Winograd tile
         if (pool_fused) *pool_fused = y_pool != nullptr;
         m->next_exec = wino_exec_flops(d);
-        RUN(m, pn.c_str(), igemm_flops(d), bytes, wino_launch(d, m->W(wname + ".u"), m->st));
+        RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;
     }
+    EVFLY_REQUIRE(!d.pre_frames, "the fused first conv needs the Winograd path");
     if (pool_fused) *pool_fused = false;
     RUN(m, pn.c_str(), igemm_flops(d), bytes, igemm_launch(d, m->st));
     return 0;
@@ -479,7 +489,12 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     hipStream_t st = m->st;
 
     // ---- encoder (valid 3x3 convs; sizes of learner_models.py:373-390)
-    float *e11 = m->alloc((int64_t)F * 258 * 344 * 32);
+    // exact-fp32 mode: e11 (1 or 2 -> 32 channels, HBM-write-bound: 11.4 MB per frame) is never materialised; the
+    // Winograd kernel of e12 computes its input patch from the raw frame while staging it
+    static const bool no_fuse = getenv("EVFLY_NO_E11_FUSION") != nullptr;
+    const bool fuse_e11 = c.compute_dtype == EVFLY_DTYPE_F32 && m->has("e12.u") && !no_fuse;
+    float *e11 = fuse_e11 ? nullptr : m->alloc((int64_t)F * 258 * 344 * 32);
+    if (!fuse_e11)
     RUN(m, "e11_direct", 2.0 * F * 258 * 344 * 32 * 9 * cin, 4.0 * F * (260.0 * 346 + 258.0 * 344 * 32),
         launch_e11(frames, F, 260, 346, cin, c.form_bev, apply_form, c.evs_min_cutoff, m->W("e11.w"), m->W("e11.b"), e11, st));
     struct Lvl { int H, W, C; float *y; } lv[5];
@@ -501,6 +516,10 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         float *b = m->alloc((int64_t)F * (H - 2) * (W - 2) * chans[l]);
         pooled = l < 4 ? m->alloc((int64_t)F * ((H - 2) / 2) * ((W - 2) / 2) * chans[l]) : nullptr;
         pool_done = false;
+        if (l == 0 && fuse_e11) {
+            m->pre.frames = frames; m->pre.w = m->W("e11.w"); m->pre.b = m->W("e11.b"); m->pre.cin = cin;
+            m->pre.form_bev = c.form_bev; m->pre.apply_form = apply_form; m->pre.cutoff = c.evs_min_cutoff;
+        }
         if (int rc = conv(m, "conv3x3", names[l][1], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, chans[l],
                           pooled, &pool_done)) return rc;
         cur = b; H -= 2; W -= 2; C = chans[l];

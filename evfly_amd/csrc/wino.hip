@@ -48,6 +48,75 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
+// input formation of learner_models.py:476-494 (identical to ops.hip form_value; kept local so the fused producer
+// below is bitwise the arithmetic of k_e11)
+__device__ __forceinline__ float wino_form_value(float x, int form_bev, int apply_form, float cutoff) {
+    if (!apply_form) return x;
+    if (fabsf(x) < cutoff) x = 0.0f;
+    if (form_bev == 2) return x != 0.0f ? 1.0f : 0.0f;
+    if (form_bev == 1) return fabsf(x);
+    return x > 0.0f ? x : 0.0f;
+}
+
+// ---- fused first U-Net conv (learner_models.py:476-494,533): stage the formed (PH + 2) x (PW + 2) frame patch and
+// the 9 * CIN x 32 weights in LDS behind the patch buffer, then every thread computes (pixel pair, 4-channel chunk)
+// items of the swizzled patch directly. Same fmaf order as k_e11 (ky, kx, ci): bitwise the unfused result.
+template <int CIN, int NTHR>
+__device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom &g, float *patch, int buf_floats, int img0, int iy0,
+                                              int ix0, int tid) {
+    const int FW = g.PW + 2, FH = g.PH + 2, per = g.TY * g.TX;
+    float *fr = patch + buf_floats;                       // [CIN][IMGS][FH][FW]
+    const int nfr = g.IMGS * FH * FW;
+    float *wl = fr + CIN * nfr;                           // [9 * CIN][32] then bias [32]
+    for (int i = tid; i < nfr; i += NTHR) {
+        const int im = i / (FH * FW), rem = i - im * (FH * FW), fy = rem / FW, fx = rem - fy * FW;
+        const int img = img0 + im, gy = iy0 + fy, gx = ix0 + fx;
+        const float raw = (img < d.NI && gy < d.H + 2 && gx < d.W + 2) ? d.pre_frames[((int64_t)img * (d.H + 2) + gy) * (d.W + 2) + gx] : 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) fr[ci * nfr + i] = wino_form_value(raw, d.pre_form_bev, d.pre_apply_form, d.pre_cutoff);
+    }
+    for (int i = tid; i < 9 * CIN * 32 + 32; i += NTHR) wl[i] = i < 9 * CIN * 32 ? d.pre_w[i] : d.pre_b[i - 9 * CIN * 32];
+    __syncthreads();
+    const float *bl = wl + 9 * CIN * 32;
+    for (int idx = tid; idx < g.ngroups * 32; idx += NTHR) {
+        const int pp = idx >> 3, ch = idx & 7;
+        const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
+        const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
+        const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
+        const int px = 2 * pxh;
+        const bool row_ok = 2 * pp < g.npix && img0 + im < d.NI && iy0 + py < d.H;
+        float a0[4], a1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a0[c] = a1[c] = bl[ch * 4 + c];
+        const float *f0 = fr + (im * FH + py) * FW + px;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float v[CIN][4];                                  // four frame columns of this row, per input channel
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[ci][k] = f0[ci * nfr + ky * FW + k];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wl + ((ky * 3 + kx) * CIN + ci) * 32 + ch * 4);
+                    const float u0 = v[ci][kx], u1 = v[ci][kx + 1];
+                    a0[0] = fmaf(u0, w4.x, a0[0]); a0[1] = fmaf(u0, w4.y, a0[1]); a0[2] = fmaf(u0, w4.z, a0[2]); a0[3] = fmaf(u0, w4.w, a0[3]);
+                    a1[0] = fmaf(u1, w4.x, a1[0]); a1[1] = fmaf(u1, w4.y, a1[1]); a1[2] = fmaf(u1, w4.z, a1[2]); a1[3] = fmaf(u1, w4.w, a1[3]);
+                }
+        }
+        // NaN-propagating ReLU like torch.relu; pixels outside the (virtual) e11 map are zeros
+        const bool ok0 = row_ok && ix0 + px < d.W, ok1 = row_ok && ix0 + px + 1 < d.W;
+        const float4 o0 = ok0 ? make_float4(a0[0] < 0.f ? 0.f : a0[0], a0[1] < 0.f ? 0.f : a0[1], a0[2] < 0.f ? 0.f : a0[2], a0[3] < 0.f ? 0.f : a0[3])
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o1 = ok1 ? make_float4(a1[0] < 0.f ? 0.f : a1[0], a1[1] < 0.f ? 0.f : a1[1], a1[2] < 0.f ? 0.f : a1[2], a1[3] < 0.f ? 0.f : a1[3])
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(patch + pp * 64 + ((ch ^ key) << 2)) = o0;             // slot of (pixel 0, ch)
+        *reinterpret_cast<float4 *>(patch + pp * 64 + (((8 | ch) ^ key) << 2)) = o1;       // slot of (pixel 1, ch)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- kernel
 // Block tile = MT M-tiles of 32 Winograd tiles x 32 output channels over 4*MT waves: wave = (M-tile mt, position row
 // a in 0..3), four accumulator tiles (64 registers). Everything fits in 128 VGPRs: four waves per SIMD. MT = 2
@@ -122,7 +191,12 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + gi * 8 * 32), 16, 0, 0);
         }
     };
-    dma(0, patch);
+    if (d.pre_frames) {
+        if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, buf_floats, img0, iy0, ix0, tid);
+        else produce_patch<2, NTHR>(d, g, patch, buf_floats, img0, iy0, ix0, tid);
+    } else {
+        dma(0, patch);
+    }
     const int reps = (g.dbg & 32) ? 2 : 1;      // timing experiment: walk the K loop twice (results are garbage)
     for (int rep = 0; rep < reps; ++rep)
     for (int cc = 0; cc < nchunks; ++cc) {
@@ -324,7 +398,7 @@ bool wino_applicable(const ConvDesc &d) {
     static const int mode = getenv("EVFLY_WINO") ? atoi(getenv("EVFLY_WINO")) : 1;
     if (mode == 0) return false;
     return d.dtype == EVFLY_DTYPE_F32 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 && d.C % 32 == 0 &&
-           d.out_mode == OUT_ROWS && !d.res && d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0 && d.OH >= 1 && d.OW >= 1;
+           d.out_mode == OUT_ROWS && !d.res && (d.pre_frames || (d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0)) && d.OH >= 1 && d.OW >= 1;
 }
 
 namespace {
@@ -352,7 +426,9 @@ WinoCfg choose(const ConvDesc &d) {
 template <int MT>
 int launch(const ConvDesc &d, const float *U, const WinoGeom &g, const WinoCfg &c, hipStream_t st) {
     // patch buffer(s); the epilogue reuses them for the exchange sets (MT x 24 KB) + the transposed tile (MT x 16 KB)
-    const int lds = std::max(c.nbuf * g.ngroups * 8 * 32 * 4, MT * 40 * 1024);
+    int lds = std::max(c.nbuf * g.ngroups * 8 * 32 * 4, MT * 40 * 1024);
+    if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
+        lds = std::max(lds, (g.ngroups * 8 * 32 + d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
     auto kern = k_wino8<MT>;
     static bool lds_set = false;
     if (!lds_set) {
@@ -393,6 +469,8 @@ int wino_launch(const ConvDesc &d_in, const float *U, hipStream_t st) {
     const WinoCfg c = choose(d);
     EVFLY_REQUIRE(plan(d, g, c.MT, c.max_px), "wino: no tile plan");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
+    EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
+                  "wino: the fused first-conv producer needs C == 32 and 1 or 2 frame channels");
     if (int rc = igemm_zero_page(&d.zeros)) return rc;
     return c.MT == 2 ? launch<2>(d, U, g, c, st) : launch<1>(d, U, g, c, st);
 }
