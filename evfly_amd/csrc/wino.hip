@@ -3,20 +3,22 @@
 // Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A : 16 multiplies per 2x2 output tile and channel pair instead of 36,
 // i.e. 2.25x fewer MFMA flops than the direct implicit GEMM, all in fp32 (the transforms use only +-1 and +-1/2).
 //
-// Mapping. A block owns up to 64 Winograd tiles (IMGS images x TY x TX tiles of 2x2 outputs) and 32 output
-// channels. The raw (2TY+2) x (2TX+2) input patch of one 32-channel chunk is DMA'd into LDS once. LDS layout: pixel
-// PAIRS of 256 B (the CDNA4 LDS is 64 banks wide and serves ds_read_b128 in four 16-lane groups); the sixteen 16-B
-// slots of a pair are XOR-swizzled with key = (px/2 + (py/2)*TX + im*TY*TX) & 15, which for any fixed patch offset
-// equals (tile index + const) & 15 -- the 16 lanes of every ds_read_b128 group hold 16 raster-consecutive tiles
-// (mod 16), so every fragment read is bank-conflict free for every plan (TY, TX, IMGS). For each of the 16 Winograd positions (a, b) the MFMA computes
-// M_ab[tile, n] += V_ab[tile, c] * U_ab[n, c]:
+// Mapping. A block owns up to 32 * MT Winograd tiles (IMGS images x TY x TX tiles of 2x2 outputs, MT = 1 or 2) and
+// 32 output channels. The raw (2TY+2) x (2TX+2) input patch of one 32-channel chunk is DMA'd into LDS (double
+// buffered across chunks). LDS layout: pixel PAIRS of 256 B (the CDNA4 LDS is 64 banks wide and serves ds_read_b128
+// in four 16-lane groups); the sixteen 16-B slots of a pair are XOR-swizzled with
+// key = (px/2 + (py/2)*TX + im*TY*TX) & 15, which for any fixed patch offset equals (tile index + const) & 15 -- the
+// 16 lanes of every ds_read_b128 group hold 16 raster-consecutive tiles (mod 16), so every fragment read is
+// bank-conflict free for every plan (TY, TX, IMGS).
+// For each of the 16 Winograd positions (a, b) the MFMA computes M_ab[tile, n] += V_ab[tile, c] * U_ab[n, c]:
 //   * V = B^T d B is formed IN REGISTERS from eight ds_read_b128 of the raw patch (one v_fma for the row
 //     combination, one v_add / v_sub per MFMA operand for the column combination);
 //   * U = G g G^T is precomputed at weight-pack time and streamed from L2 straight into the B-operand registers,
-//     8 B per lane, in exactly the order the waves consume it (one linear pointer, prefetched one step ahead).
-// Wave w = (mt, a): M-tile mt (32 of the 64 tiles) x position row a x all four b: 4 accumulator tiles = 64
-// registers. The output transform is lane-local along b; along a the four waves of an M-tile trade partial sums
-// through LDS. nn.MaxPool2d(2, 2) fuses trivially: a Winograd tile IS one pooling window.
+//     8 B per lane, in exactly the order the waves consume it (one linear pointer, refilled right after use).
+// Wave w = (mt, a): M-tile mt x position row a x all four b: 4 accumulator tiles = 64 registers, 128 VGPRs in all.
+// The output transform is lane-local along b; along a the four waves of an M-tile trade partial sums through LDS,
+// then the finished tile is transposed through LDS for 16-B global stores. nn.MaxPool2d(2, 2) fuses trivially (a
+// Winograd tile IS one pooling window), and the first U-Net conv can be fused in as the patch producer.
 #include "igemm.h"
 
 #include <algorithm>
@@ -34,7 +36,7 @@ struct WinoGeom {
     int IMGS, TY, TX, PH, PW;   // tiles per block and patch size (pixels) per image
     int npix;                   // IMGS * PH * PW
     int ngroups;                // DMA groups of 8 pixels
-    int ntiles;                 // IMGS * TY * TX  (<= 64)
+    int ntiles;                 // IMGS * TY * TX  (<= 32 * MT)
     int bx, by, bi;             // blocks along x, y, image groups
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
