@@ -33,6 +33,7 @@ class ModelConfig(C.Structure):
         ("enc_pool_type", c_i), ("enc_pool_kernel", c_i * 4), ("enc_pool_stride", c_i * 4),
         ("enc_invert_pool_inputs", c_i),
         ("fc_num_layers", c_i), ("fc_size", c_i * 8), ("fc_act", c_i * 8),
+        ("is_deployment", c_i),
     ]
 
 

@@ -558,7 +558,12 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         y5 = hseq;
         m->tap("e5_lstm", hseq, F, 8, 13, 512);
     }
-    // ---- decoder (learner_models.py:553-583)
+    // ---- decoder (learner_models.py:553-583); is_deployment skips it unless a velpred head reads its output
+    if (c.is_deployment && !(c.velpred == 1 || c.velpred == 11)) {
+        if (depth_dev) *depth_dev = nullptr;
+        if (c.velpred == 2 && yvel_out) return velpred_chunk(m, y5, F, yvel_out);
+        return 0;
+    }
     static const int small[4][2] = {{16, 26}, {24, 44}, {40, 80}, {72, 152}};
     const float *dcur = y5;
     int dh = 8, dw = 13, dc = 512;
@@ -838,6 +843,9 @@ extern "C" int evfly_e2v_forward(evfly_model *m, const float *frames, const floa
                                  float *upconv_out, float *vel_out, void *stream) {
     if (int rc = check_model(m, stream)) return rc;
     EVFLY_REQUIRE(m->cfg.has_unet && m->cfg.head != EVFLY_HEAD_NONE, "e2v_forward needs a composite handle");
+    EVFLY_REQUIRE(!(m->cfg.is_deployment && !(m->cfg.velpred == 1 || m->cfg.velpred == 11)),
+                  "e2v_forward: is_deployment=True skips the decoder, there is no depth for the velocity model "
+                  "(the reference fails on None * 2 at learner_models.py:634)");
     EVFLY_REQUIRE(frames && desvel && vel_out && n_streams > 0 && T > 0, "e2v_forward: null argument");
     EVFLY_REQUIRE((h_state == nullptr) == (c_state == nullptr), "e2v_forward: h_state and c_state go together");
     const int per = std::max(1, kChunkFrames / T);

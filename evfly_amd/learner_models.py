@@ -265,6 +265,7 @@ class OrigUNet(HipModule):
         c.evs_min_cutoff = float(self.evs_min_cutoff)
         c.compute_dtype = self.compute_dtype
         c.velpred = self.velpred
+        c.is_deployment = int(bool(self.is_deployment))
         if self.velpred > 0:
             sp, fp = self.convnet_velpred.spec, self.velpred_head.fcnet.spec
             if sp['num_layers'] > 4 or fp['num_layers'] > 8:
@@ -323,9 +324,9 @@ class OrigUNet(HipModule):
         if x[2] is None:
             x[2] = (None, None)
         frames = x[0]
-        if self.is_deployment and not (self.velpred == 1 or self.velpred == 11):
-            raise NotImplementedError("is_deployment=True skips the decoder (:553); evfly_ros/run.py passes False")
         y_interp, y_upconv, h_unet = self._run(frames, x[2][0], 1, frames.shape[0])
+        if self.is_deployment and not (self.velpred == 1 or self.velpred == 11):
+            y_interp = y_upconv = None                                              # decoder skipped (:553)
         y_vel = torch.Tensor([1., 0., 0.]).repeat(frames.shape[0], 1)               # :590-591
         if self.velpred > 0:                                                        # :593-614
             y_vel = self.__dict__["_last_yvel"]

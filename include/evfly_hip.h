@@ -189,6 +189,9 @@ typedef struct evfly_model_config {
     int enc_invert_pool_inputs;
     int fc_num_layers;     /* <= EVFLY_MAX_FC_LAYERS; the last layer size must be 1 */
     int fc_size[8], fc_act[8];
+    /* OrigUNet(is_deployment=True): the decoder is skipped unless a velpred head consumes its output
+     * (velpred 1 / 11), learner/learner_models.py:553; depth_out / upconv_out are then left untouched. */
+    int is_deployment;
 } evfly_model_config;
 
 #define EVFLY_MAX_ENC_LAYERS 4

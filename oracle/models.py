@@ -132,8 +132,9 @@ def velpredictor_forward(sd, stem, x, fc):
 
 def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff=0.15,
                      skip_type="interp", num_recurrent=(1, 0), input_hw=(260, 346), num_in_channels=2,
-                     return_taps=False, velpred=0, enc_params=None, fc_params=None):
-    """learner/learner_models.py:521-616 with is_deployment=False (velpred 0 / 1 / 11 / 2, no lstm_velpred).
+                     return_taps=False, velpred=0, enc_params=None, fc_params=None, is_deployment=False):
+    """learner/learner_models.py:521-616 (velpred 0 / 1 / 11 / 2, no lstm_velpred; is_deployment skips the decoder
+    unless velpred is 1 or 11, :553).
     x: (T,1,260,346) float32 conditioned frames = consecutive steps of one stream.
     Returns y_vel, (y_interp, y_upconv, (h_unet, None))."""
     from .conditioning import form_input
@@ -156,6 +157,13 @@ def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff
         y_e5, h_unet = convlstm_forward(sd, P + "lstm.", y_e5, state)
     taps["y_e5"] = y_e5
     y = y_e5
+    if is_deployment and velpred not in (1, 11):                                     # :553: no decoder
+        y_vel = torch.tensor([1., 0., 0.]).repeat(x.shape[0], 1)
+        if velpred == 2:
+            enc = dynamic_convnet_forward(sd, P + "convnet_velpred.", y_e5, enc_params)
+            y_vel = velpredictor_forward(sd, P + "velpred_head.", enc, fc_params)
+        out = (y_vel, (None, None, (h_unet, None)))
+        return (out, taps) if return_taps else out
     for lvl, (enc, (big, small)) in enumerate(zip((y_e4, y_e3, y_e2, y_e1), _SKIPS), start=1):
         up = F.conv_transpose2d(y, _p(sd, P + f"unet_upconv{lvl}.weight"),
                                 _p(sd, P + f"unet_upconv{lvl}.bias"), stride=2)

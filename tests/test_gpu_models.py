@@ -192,6 +192,31 @@ def test_origunet_velpred_vs_golden(gpu_device, tag):
         assert rel_err(v2[i:i + 1].cpu(), o_i) < TOL
 
 
+def test_origunet_is_deployment_skips_decoder(gpu_device):
+    """learner_models.py:553: is_deployment=True runs the encoder + ConvLSTM only (and a velpred=2 head on y_e5)."""
+    g7, g9 = golden("g7_origunet"), golden("g9_velpred")
+    x = cond_frames(70, 2)
+    net, sd = _unet(gpu_device, is_deployment=True)
+    y_vel, (y_interp, y_upconv, (h_unet, h_vp)) = net([x.clone().to(gpu_device), None, None])
+    assert y_interp is None and y_upconv is None and h_vp is None
+    assert torch.equal(y_vel, torch.tensor([[1., 0., 0.]]).repeat(2, 1))
+    assert rel_err(h_unet[0][0].cpu(), g7["interp_bev2_h"]) < TOL and rel_err(h_unet[0][1].cpu(), g7["interp_bev2_c"]) < TOL
+    o_vel, (o_d, o_u, (o_h, _)) = om.origunet_forward(sd, x, None, is_deployment=True)
+    assert o_d is None and o_u is None and rel_err(h_unet[0][0].cpu(), o_h[0][0]) < TOL
+    case = syn.VELPRED_CASES["e5_nopool"]                     # velpred = 2 reads y_e5: unaffected by the skipped decoder
+    net, sd = _unet(gpu_device, is_deployment=True, **case)
+    y_vel, (y_interp, _, _) = net([cond_frames(90, 2).to(gpu_device), None, None])
+    assert y_interp is None and rel_err(y_vel.cpu(), g9["e5_nopool_vel"]) < TOL
+    # the composite cannot run without a depth map (the reference fails on None * 2 at :634)
+    import evfly_amd.learner_models as lm
+    comp = lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346],
+                                        velpred=0, form_BEV=2, evs_min_cutoff=0.15, skip_type="interp", is_deployment=True,
+                                        logger=lambda *a: None)
+    comp.load_state_dict(syn.fill_state_dict(comp.state_dict()))
+    with pytest.raises(RuntimeError, match="is_deployment"):
+        comp.to(gpu_device)([x.to(gpu_device), torch.tensor([[4.0]]), [None, None], None])
+
+
 def test_velpred_errors(gpu_device):
     from evfly_amd import _lib
     case = syn.VELPRED_CASES["sim"]
