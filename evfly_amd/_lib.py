@@ -33,7 +33,7 @@ class ModelConfig(C.Structure):
         ("enc_pool_type", c_i), ("enc_pool_kernel", c_i * 4), ("enc_pool_stride", c_i * 4),
         ("enc_invert_pool_inputs", c_i),
         ("fc_num_layers", c_i), ("fc_size", c_i * 8), ("fc_act", c_i * 8),
-        ("is_deployment", c_i),
+        ("is_deployment", c_i), ("velpred_lstm_layers", c_i),
     ]
 
 
@@ -59,7 +59,7 @@ SIGNATURES = {
     "evfly_model_load_tensor": (c_i, [c_p, C.c_char_p, c_p, C.POINTER(c_i64), c_i]),
     "evfly_model_finalize": (c_i, [c_p]),
     "evfly_model_destroy": (None, [c_p]),
-    "evfly_unet_forward": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "evfly_unet_forward": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "evfly_vit_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "evfly_vit_stage_forward": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "evfly_e2v_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

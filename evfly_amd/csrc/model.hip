@@ -67,6 +67,7 @@ struct evfly_model {
     size_t ev_used = 0;
     std::vector<ProfAgg> agg;
     hipStream_t st = nullptr;
+    int vp_hidden = 0;   // lstm_velpred hidden size = flattened conv features (set at finalize)
 
     ~evfly_model() {
         if (wdev) (void)hipFree(wdev);
@@ -341,13 +342,43 @@ int pack_velpred(evfly_model *m) {
         if (int rc = pack_conv(m, "", "__vpconv" + si, "vp.conv" + si)) return rc;
         cin = O;
     }
-    // fcnet consumes torch.flatten(x, 1) of a (C, H, W) tensor (:605); ours is HWC
+    // the consumer of torch.flatten(x, 1) of the (C, H, W) conv features (:605) -- lstm_velpred layer 0 when present
+    // (:607-609), else fc_0 -- gets its input columns permuted to our HWC order
     const int L = c.enc_num_layers;
     const int Cf = L ? g.C[L - 1] : g.C0, Hf = L ? g.ph[L - 1] : g.H0, Wf = L ? g.pw[L - 1] : g.W0;
     std::vector<int> perm((size_t)Cf * Hf * Wf);
     for (int ch = 0; ch < Cf; ++ch)
         for (int p = 0; p < Hf * Wf; ++p) perm[(size_t)ch * Hf * Wf + p] = p * Cf + ch;
     int fin = Cf * Hf * Wf;
+    m->vp_hidden = fin;
+    for (int k = 0; k < c.velpred_lstm_layers; ++k) {
+        // nn.LSTM(fin, fin): gate rows (i, f, g, o) are reordered to (i, f, o, g), the order of the shared cell kernel;
+        // b_ih + b_hh ride on the input-side GEMM
+        const std::string sk = std::to_string(k);
+        const HostTensor *wi = m->find("lstm_velpred.weight_ih_l" + sk, kUnetP), *wh = m->find("lstm_velpred.weight_hh_l" + sk, kUnetP);
+        const HostTensor *bi = m->find("lstm_velpred.bias_ih_l" + sk, kUnetP), *bh = m->find("lstm_velpred.bias_hh_l" + sk, kUnetP);
+        if (!wi || !wh || !bi || !bh) return fail(-4, "missing lstm_velpred tensors of layer %d", k);
+        const int H = fin;
+        EVFLY_REQUIRE(wi->shape.size() == 2 && wi->shape[0] == 4 * H && wi->shape[1] == H && wh->shape[0] == 4 * H && wh->shape[1] == H,
+                      "lstm_velpred layer %d: expected (%d,%d) weights", k, 4 * H, H);
+        auto src_row = [&](int r) { const int gate = r / H, u = r % H; return (gate == 2 ? 3 : gate == 3 ? 2 : gate) * H + u; };
+        HostTensor pi, ph, pb;
+        pi.shape = {4 * H, H}; pi.v.resize((size_t)4 * H * H); ph = pi; pb.shape = {4 * H}; pb.v.resize(4 * H);
+        for (int r = 0; r < 4 * H; ++r) {
+            const int sr = src_row(r);
+            for (int j = 0; j < H; ++j) {
+                const int dj = (k == 0) ? perm[j] : j;
+                pi.v[(size_t)r * H + dj] = wi->v[(size_t)sr * H + j];
+                ph.v[(size_t)r * H + j] = wh->v[(size_t)sr * H + j];
+            }
+            pb.v[r] = bi->v[sr] + bh->v[sr];
+        }
+        m->host["__vplstm_ih" + sk + ".weight"] = std::move(pi);
+        m->host["__vplstm_ih" + sk + ".bias"] = std::move(pb);
+        m->host["__vplstm_hh" + sk + ".weight"] = std::move(ph);
+        if (int rc = pack_linear(m, "", "__vplstm_ih" + sk, "vp.lstm.ih" + sk)) return rc;
+        if (int rc = pack_linear(m, "", "__vplstm_hh" + sk, "vp.lstm.hh" + sk)) return rc;
+    }
     for (int i = 0; i < c.fc_num_layers; ++i) {
         const std::string key = "velpred_head.fcnet.layers.fc_" + std::to_string(i);
         const HostTensor *w = m->find(key + ".weight", kUnetP);
@@ -355,7 +386,8 @@ int pack_velpred(evfly_model *m) {
         EVFLY_REQUIRE(w->shape.size() == 2 && w->shape[0] == c.fc_size[i] && w->shape[1] == fin,
                       "%s.weight: expected (%d,%d), got (%lld,%lld)", key.c_str(), c.fc_size[i], fin,
                       (long long)w->shape[0], (long long)(w->shape.size() > 1 ? w->shape[1] : 0));
-        if (int rc = pack_linear(m, kUnetP, key, "vp.fc" + std::to_string(i), true, i == 0 ? &perm : nullptr)) return rc;
+        if (int rc = pack_linear(m, kUnetP, key, "vp.fc" + std::to_string(i), true,
+                                 (i == 0 && c.velpred_lstm_layers == 0) ? &perm : nullptr)) return rc;
         fin = c.fc_size[i];
     }
     return 0;
@@ -478,10 +510,11 @@ int linear(evfly_model *m, const char *pname, const std::string &wname, const fl
 }  // namespace
 
 // ============================================================================ U-Net forward (one chunk)
-static int velpred_chunk(evfly_model *m, const float *x, int F, float *yvel);
+static int velpred_chunk(evfly_model *m, const float *x, int S, int T, float *vp_h, float *vp_c, float *yvel);
 
 static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *h_state, float *c_state,
-                      float *depth_out, float *upconv_out, float **depth_dev, float *yvel_out = nullptr) {
+                      float *depth_out, float *upconv_out, float **depth_dev, float *yvel_out = nullptr, float *vp_h = nullptr,
+                      float *vp_c = nullptr) {
     const auto &c = m->cfg;
     const int F = S * T;
     const int cin = (c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels;
@@ -561,7 +594,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     // ---- decoder (learner_models.py:553-583); is_deployment skips it unless a velpred head reads its output
     if (c.is_deployment && !(c.velpred == 1 || c.velpred == 11)) {
         if (depth_dev) *depth_dev = nullptr;
-        if (c.velpred == 2 && yvel_out) return velpred_chunk(m, y5, F, yvel_out);
+        if (c.velpred == 2 && yvel_out) return velpred_chunk(m, y5, S, T, vp_h, vp_c, yvel_out);
         return 0;
     }
     static const int small[4][2] = {{16, 26}, {24, 44}, {40, 80}, {72, 152}};
@@ -603,14 +636,15 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     RUN(m, "depth_bilinear", 0, 4.0 * F * c.input_h * c.input_w * 2, launch_bilinear(up, F, 68, 148, 1, 1, dp, c.input_h, c.input_w, 1, 0, 0, st));
     if (depth_dev) *depth_dev = dp;
     if (c.velpred > 0 && yvel_out)
-        return velpred_chunk(m, c.velpred == 1 ? dp : c.velpred == 11 ? up : y5, F, yvel_out);
+        return velpred_chunk(m, c.velpred == 1 ? dp : c.velpred == 11 ? up : y5, S, T, vp_h, vp_c, yvel_out);
     return 0;
 }
 
 // ============================================================================ velpred head (OrigUNet, velpred > 0)
 // learner_models.py:593-614: convnet_velpred(y_interp | y_upconv | y_e5) -> flatten -> velpred_head
-static int velpred_chunk(evfly_model *m, const float *x, int F, float *yvel) {
+static int velpred_chunk(evfly_model *m, const float *x, int S, int T, float *vp_h, float *vp_c, float *yvel) {
     const auto &c = m->cfg;
+    const int F = S * T;
     VpGeom g;
     if (int rc = velpred_geometry(c, g)) return rc;
     hipStream_t st = m->st;
@@ -634,6 +668,38 @@ static int velpred_chunk(evfly_model *m, const float *x, int F, float *yvel) {
     }
     m->tap("velpred_enc", const_cast<float *>(cur), F, H, W, C);
     int fin = H * W * C;
+    // ---- lstm_velpred (:607-609): nn.LSTM(fin, fin, num_layers) over the T frames of each stream (batch-as-time)
+    for (int k = 0; k < c.velpred_lstm_layers; ++k) {
+        const int Hd = fin;
+        const std::string sk = std::to_string(k);
+        float *xg = m->alloc((int64_t)F * 4 * Hd);
+        if (int rc = linear(m, "velpred_lstm_x", "vp.lstm.ih" + sk, cur, F, Hd, Hd, 4 * Hd, ACT_NONE, nullptr, 0, xg, 4 * Hd)) return rc;
+        float *z = m->alloc((int64_t)S * 4 * Hd), *hseq = m->alloc((int64_t)F * Hd);
+        float *hs = m->alloc((int64_t)S * Hd), *cs = m->alloc((int64_t)S * Hd);     // working state, (S, Hd) contiguous
+        if (!m->planning) {
+            if (vp_h) {   // caller state is (S, layers, Hd)
+                EVFLY_HIP(hipMemcpy2DAsync(hs, (size_t)Hd * 4, vp_h + (int64_t)k * Hd, (size_t)c.velpred_lstm_layers * Hd * 4, (size_t)Hd * 4, S, hipMemcpyDeviceToDevice, st));
+                EVFLY_HIP(hipMemcpy2DAsync(cs, (size_t)Hd * 4, vp_c + (int64_t)k * Hd, (size_t)c.velpred_lstm_layers * Hd * 4, (size_t)Hd * 4, S, hipMemcpyDeviceToDevice, st));
+            } else {
+                EVFLY_HIP(hipMemsetAsync(hs, 0, (size_t)S * Hd * 4, st));
+                EVFLY_HIP(hipMemsetAsync(cs, 0, (size_t)S * Hd * 4, st));
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            ConvDesc d; d.x = hs; d.ldx = Hd; d.NI = S; d.C = Hd; d.w = m->W("vp.lstm.hh" + sk + ".w");
+            d.ldw = m->planning ? round_up(Hd, 32) : m->wld["vp.lstm.hh" + sk];
+            conv_finish(d); d.Nc = 4 * Hd; d.y = z; d.ldy = 4 * Hd; d.dtype = c.compute_dtype;
+            d.res = xg + (int64_t)t * 4 * Hd; d.ldres = 4 * Hd; d.res_rpi = 1; d.res_img_rows = T;
+            RUN(m, "velpred_lstm_h", igemm_flops(d), 4.0 * (4.0 * Hd * Hd + S * 9.0 * Hd), igemm_launch(d, st));
+            RUN(m, "velpred_lstm_cell", 0, 4.0 * S * Hd * 8,
+                launch_convlstm_gates(z, S, Hd, cs, hs, hseq + (int64_t)t * Hd, 1, T, st));
+        }
+        if (vp_h && !m->planning) {
+            EVFLY_HIP(hipMemcpy2DAsync(vp_h + (int64_t)k * Hd, (size_t)c.velpred_lstm_layers * Hd * 4, hs, (size_t)Hd * 4, (size_t)Hd * 4, S, hipMemcpyDeviceToDevice, st));
+            EVFLY_HIP(hipMemcpy2DAsync(vp_c + (int64_t)k * Hd, (size_t)c.velpred_lstm_layers * Hd * 4, cs, (size_t)Hd * 4, (size_t)Hd * 4, S, hipMemcpyDeviceToDevice, st));
+        }
+        cur = hseq;
+    }
     for (int i = 0; i < c.fc_num_layers; ++i) {
         float *y = m->alloc((int64_t)F * c.fc_size[i]);
         if (int rc = linear(m, "velpred_fc", "vp.fc" + std::to_string(i), cur, F, fin, fin, c.fc_size[i], c.fc_act[i], nullptr, 0, y,
@@ -786,12 +852,14 @@ constexpr int kChunkFrames = 320;
 }  // namespace
 
 extern "C" int evfly_unet_forward(evfly_model *m, const float *frames, int n_streams, int T, float *h_state, float *c_state,
-                                  float *depth_out, float *upconv_out, float *yvel_out, void *stream) {
+                                  float *depth_out, float *upconv_out, float *yvel_out, float *velpred_h, float *velpred_c,
+                                  void *stream) {
     if (int rc = check_model(m, stream)) return rc;
     EVFLY_REQUIRE(m->cfg.has_unet, "handle has no U-Net");
     EVFLY_REQUIRE(frames && n_streams > 0 && T > 0, "unet_forward: empty batch");
     EVFLY_REQUIRE((h_state == nullptr) == (c_state == nullptr), "unet_forward: h_state and c_state go together");
     EVFLY_REQUIRE(m->cfg.velpred == 0 || yvel_out, "unet_forward: the handle has a velpred head, yvel_out is required");
+    EVFLY_REQUIRE((velpred_h == nullptr) == (velpred_c == nullptr), "unet_forward: velpred_h and velpred_c go together");
     const int per = std::max(1, kChunkFrames / T);
     const int64_t fr = (int64_t)m->cfg.input_h * m->cfg.input_w;
     for (int s0 = 0; s0 < n_streams; s0 += per) {
@@ -801,7 +869,9 @@ extern "C" int evfly_unet_forward(evfly_model *m, const float *frames, int n_str
                               c_state ? c_state + (int64_t)s0 * 104 * 512 : nullptr,
                               depth_out ? depth_out + (int64_t)s0 * T * fr : nullptr,
                               upconv_out ? upconv_out + (int64_t)s0 * T * 68 * 148 : nullptr, nullptr,
-                              m->cfg.velpred > 0 ? yvel_out + (int64_t)s0 * T * 3 : nullptr);
+                              m->cfg.velpred > 0 ? yvel_out + (int64_t)s0 * T * 3 : nullptr,
+                              velpred_h ? velpred_h + (int64_t)s0 * m->cfg.velpred_lstm_layers * m->vp_hidden : nullptr,
+                              velpred_c ? velpred_c + (int64_t)s0 * m->cfg.velpred_lstm_layers * m->vp_hidden : nullptr);
         };
         if (int rc = with_arena(m, body)) return rc;
     }
@@ -886,6 +956,7 @@ extern "C" int evfly_model_create(const evfly_model_config *cfg, evfly_model **o
         EVFLY_REQUIRE(cfg->velpred == 1 || cfg->velpred == 11 || cfg->velpred == 2, "velpred should be 0/1/11/2, but is %d", cfg->velpred);
         EVFLY_REQUIRE(cfg->enc_num_layers >= 0 && cfg->enc_num_layers <= EVFLY_MAX_ENC_LAYERS, "enc_num_layers out of range");
         EVFLY_REQUIRE(cfg->fc_num_layers >= 1 && cfg->fc_num_layers <= EVFLY_MAX_FC_LAYERS, "fc_num_layers out of range");
+        EVFLY_REQUIRE(cfg->velpred_lstm_layers >= 0 && cfg->velpred_lstm_layers <= 4, "velpred_lstm_layers out of range");
         EVFLY_REQUIRE(cfg->fc_size[cfg->fc_num_layers - 1] == 1, "velpred_head is built with num_out=1 (learner_models.py:462): "
                       "the last fc layer size must be 1");
         EVFLY_REQUIRE(cfg->enc_pool_type >= EVFLY_POOL_NONE && cfg->enc_pool_type <= EVFLY_POOL_AVG, "bad enc_pool_type");

@@ -243,9 +243,11 @@ class OrigUNet(HipModule):
             oc, oh, ow = self.convnet_velpred.out_shape(vh, vw)
             self.convnet_velpred_outsize = torch.Size([1, oc, oh, ow])
             mylogger(f'[OrigUNet] Calculated self.convnet_velpred_outsize = {self.convnet_velpred_outsize}')
-            if self._nrec[1] > 0:
-                raise NotImplementedError("lstm_velpred (num_recurrent[1] > 0, :457-459) is not built: every shipped "
-                                          "config sets num_recurrent = [1, 0]")
+            if self._nrec[1] > 0:                                            # :457-459
+                feat = oc * oh * ow
+                self.lstm_velpred = nn.LSTM(input_size=feat, hidden_size=feat, num_layers=self._nrec[1], dropout=0.1)
+                mylogger(f'[OrigUNet] LSTM for velocity prediction has '
+                         f'{sum(p.numel() for p in self.lstm_velpred.parameters() if p.requires_grad):,} parameters.')
             self.velpred_head = VelPredictor(fc_params=fc_params, input_size=oc * oh * ow, num_out=1, device=device,
                                              logger=mylogger)
             if self.velpred_head.fcnet.spec['layer_sizes'][-1] != 1:
@@ -266,6 +268,7 @@ class OrigUNet(HipModule):
         c.compute_dtype = self.compute_dtype
         c.velpred = self.velpred
         c.is_deployment = int(bool(self.is_deployment))
+        c.velpred_lstm_layers = self._nrec[1] if self.velpred > 0 else 0
         if self.velpred > 0:
             sp, fp = self.convnet_velpred.spec, self.velpred_head.fcnet.spec
             if sp['num_layers'] > 4 or fp['num_layers'] > 8:
@@ -300,7 +303,7 @@ class OrigUNet(HipModule):
     def _state_out(h, c, dev):
         return [[h.permute(0, 3, 1, 2).to(dev), c.permute(0, 3, 1, 2).to(dev)]]
 
-    def _run(self, frames, state, n_streams, T):
+    def _run(self, frames, state, n_streams, T, vp_state=None):
         dev = frames.device
         x = to_gpu(frames).reshape(-1, self.input_h, self.input_w)
         n = x.shape[0]
@@ -311,11 +314,22 @@ class OrigUNet(HipModule):
         depth = torch.empty(n, 1, self.input_h, self.input_w, device=x.device)
         upconv = torch.empty(n, 1, 68, 148, device=x.device)
         yvel = torch.empty(n, 3, device=x.device) if self.velpred > 0 else None
+        vh = vc = None
+        if self.velpred > 0 and self._nrec[1] > 0:                      # h_velpred of :609: (h, c) each (layers, F)
+            feat = self.lstm_velpred.hidden_size
+            if vp_state is None:
+                vh = torch.zeros(n_streams, self._nrec[1], feat, device=x.device); vc = torch.zeros_like(vh)
+            else:
+                vh = to_gpu(vp_state[0]).reshape(n_streams, self._nrec[1], feat).clone()
+                vc = to_gpu(vp_state[1]).reshape(n_streams, self._nrec[1], feat).clone()
         L = _lib.lib()
         _lib.check(L.evfly_unet_forward(self.hip().h, _lib.ptr(x), n_streams, T, _lib.ptr(h), _lib.ptr(c),
-                                        _lib.ptr(depth), _lib.ptr(upconv), _lib.ptr(yvel), _lib.cur_stream()))
+                                        _lib.ptr(depth), _lib.ptr(upconv), _lib.ptr(yvel), _lib.ptr(vh), _lib.ptr(vc),
+                                        _lib.cur_stream()))
         h_unet = self._state_out(h, c, dev) if h is not None else None
         self.__dict__["_last_yvel"] = yvel.to(dev) if yvel is not None else None
+        self.__dict__["_last_vp_state"] = None if vh is None else (
+            (vh[0].to(dev), vc[0].to(dev)) if n_streams == 1 else (vh.to(dev), vc.to(dev)))
         return depth.to(dev), upconv.to(dev), h_unet
 
     def forward(self, x):
@@ -324,13 +338,13 @@ class OrigUNet(HipModule):
         if x[2] is None:
             x[2] = (None, None)
         frames = x[0]
-        y_interp, y_upconv, h_unet = self._run(frames, x[2][0], 1, frames.shape[0])
+        y_interp, y_upconv, h_unet = self._run(frames, x[2][0], 1, frames.shape[0], vp_state=x[2][1])
         if self.is_deployment and not (self.velpred == 1 or self.velpred == 11):
             y_interp = y_upconv = None                                              # decoder skipped (:553)
         y_vel = torch.Tensor([1., 0., 0.]).repeat(frames.shape[0], 1)               # :590-591
         if self.velpred > 0:                                                        # :593-614
             y_vel = self.__dict__["_last_yvel"]
-        return y_vel, (y_interp, y_upconv, (h_unet, None))
+        return y_vel, (y_interp, y_upconv, (h_unet, self.__dict__.get("_last_vp_state")))
 
     def forward_streams(self, frames, state, n_streams, T):
         """Throughput entry: frames laid out [stream][t]; state [[h, c]] each (n_streams,512,8,13).

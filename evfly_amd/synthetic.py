@@ -131,6 +131,14 @@ def make_u8_frames(seed, n, H=480, W=640, rate=0.35):
     return ((128 + k) & 0xFF).astype(np.uint8)
 
 
+# velpred head WITH lstm_velpred (num_recurrent[1] > 0, learner_models.py:457-459): golden G12, run statefully
+VELPRED_LSTM_CASE = dict(
+    velpred=1, num_recurrent=[1, 2],
+    enc_params=dict(num_layers=2, kernel_sizes=[7, 5], kernel_strides=[4, 2], out_channels=[4, 8],
+                    activations=["tanh", "leaky_relu"], pool_type="avg", pool_kernels=[2, 3], pool_strides=[2, 2],
+                    conv_function="conv2d", invert_pool_inputs=False),
+    fc_params=dict(num_layers=2, layer_sizes=[32, 1], activations=["sigmoid", "tanh"], dropout_p=0.0))
+
 # OrigUNet velpred-head configurations used by the G9 golden and its parity tests. "sim" is
 # learner/configs/eval_config_sim_joint.txt:41-73 verbatim; the other two exercise velpred 1 / 2, avg / no
 # pooling, every activation code and the no-invert path.

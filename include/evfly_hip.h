@@ -192,6 +192,9 @@ typedef struct evfly_model_config {
     /* OrigUNet(is_deployment=True): the decoder is skipped unless a velpred head consumes its output
      * (velpred 1 / 11), learner/learner_models.py:553; depth_out / upconv_out are then left untouched. */
     int is_deployment;
+    /* num_recurrent[1]: layers of lstm_velpred = nn.LSTM(F, F) between the velpred encoder and its FC head, F = the
+     * flattened encoder features (learner_models.py:457-459, 607-609); 0 in every shipped config. */
+    int velpred_lstm_layers;
 } evfly_model_config;
 
 #define EVFLY_MAX_ENC_LAYERS 4
@@ -228,10 +231,11 @@ void evfly_model_destroy(evfly_model *m);
  * (the reference mutates its input in place, learner_models.py:477).
  * yvel_out (n_streams*T, 3) = y_vel of the velpred head (:589-616); required when the handle was
  * created with velpred > 0, ignored (may be NULL) otherwise - the constant [1,0,0] rows of :590-591
- * are the host mirror's business. */
+ * are the host mirror's business. velpred_h / velpred_c: (n_streams, velpred_lstm_layers, F) state of lstm_velpred,
+ * read and updated in place (h_velpred of :609); NULL = zeros in, state discarded. */
 int evfly_unet_forward(evfly_model *m, const float *frames, int n_streams, int T,
                        float *h_state, float *c_state, float *depth_out, float *upconv_out,
-                       float *yvel_out, void *stream);
+                       float *yvel_out, float *velpred_h, float *velpred_c, void *stream);
 
 /* Replaces LSTMNetVIT.forward learner/vitfly_models.py:132-150 / ViT.forward :170-186, including
  * refine_inputs :18-31. img: (n_streams*T, img_h, img_w) depth images (bilinearly resized to 60x90

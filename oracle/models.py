@@ -132,7 +132,7 @@ def velpredictor_forward(sd, stem, x, fc):
 
 def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff=0.15,
                      skip_type="interp", num_recurrent=(1, 0), input_hw=(260, 346), num_in_channels=2,
-                     return_taps=False, velpred=0, enc_params=None, fc_params=None, is_deployment=False):
+                     return_taps=False, velpred=0, enc_params=None, fc_params=None, is_deployment=False, vp_state=None):
     """learner/learner_models.py:521-616 (velpred 0 / 1 / 11 / 2, no lstm_velpred; is_deployment skips the decoder
     unless velpred is 1 or 11, :553).
     x: (T,1,260,346) float32 conditioned frames = consecutive steps of one stream.
@@ -159,10 +159,13 @@ def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff
     y = y_e5
     if is_deployment and velpred not in (1, 11):                                     # :553: no decoder
         y_vel = torch.tensor([1., 0., 0.]).repeat(x.shape[0], 1)
+        h_velpred = None
         if velpred == 2:
-            enc = dynamic_convnet_forward(sd, P + "convnet_velpred.", y_e5, enc_params)
-            y_vel = velpredictor_forward(sd, P + "velpred_head.", enc, fc_params)
-        out = (y_vel, (None, None, (h_unet, None)))
+            feat = torch.flatten(dynamic_convnet_forward(sd, P + "convnet_velpred.", y_e5, enc_params), 1)
+            if num_recurrent[1] > 0:
+                feat, h_velpred = lstm_forward(sd, P + "lstm_velpred.", feat, vp_state, num_layers=num_recurrent[1])
+            y_vel = velpredictor_forward(sd, P + "velpred_head.", feat, fc_params)
+        out = (y_vel, (None, None, (h_unet, h_velpred)))
         return (out, taps) if return_taps else out
     for lvl, (enc, (big, small)) in enumerate(zip((y_e4, y_e3, y_e2, y_e1), _SKIPS), start=1):
         up = F.conv_transpose2d(y, _p(sd, P + f"unet_upconv{lvl}.weight"),
@@ -174,12 +177,16 @@ def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff
     y_upconv = _conv(sd, P + "unet_out.", y)                                        # :583
     y_interp = F.interpolate(y_upconv, size=input_hw, mode="bilinear", align_corners=False)  # :497
     y_vel = torch.tensor([1., 0., 0.]).repeat(x.shape[0], 1)                        # :590-591
+    h_velpred = None
     if velpred > 0:                                                                 # :593-614
         src = {1: y_interp, 11: y_upconv, 2: y_e5}[velpred]
         enc = dynamic_convnet_forward(sd, P + "convnet_velpred.", src, enc_params)
         taps["velpred_enc"] = enc
-        y_vel = velpredictor_forward(sd, P + "velpred_head.", enc, fc_params)
-    out = (y_vel, (y_interp, y_upconv, (h_unet, None)))
+        feat = torch.flatten(enc, 1)                                                # :605
+        if num_recurrent[1] > 0:                                                    # :607-609, unbatched nn.LSTM over the frames
+            feat, h_velpred = lstm_forward(sd, P + "lstm_velpred.", feat, vp_state, num_layers=num_recurrent[1])
+        y_vel = velpredictor_forward(sd, P + "velpred_head.", feat, fc_params)
+    out = (y_vel, (y_interp, y_upconv, (h_unet, h_velpred)))
     return (out, taps) if return_taps else out
 
 

@@ -285,6 +285,22 @@ def g9():
     save("g9_velpred", **out)
 
 
+# ------------------------------------------------------------------ G12: velpred head with lstm_velpred, stateful
+def g12():
+    case = syn.VELPRED_LSTM_CASE
+    net = ref_lm.OrigUNet(num_in_channels=2, num_out_channels=1, input_shape=[1, 1, 260, 346], evs_min_cutoff=0.15,
+                          skip_type="interp", form_BEV=2, logger=lambda *a: None, **case).eval()
+    net.load_state_dict(syn.fill_state_dict(net, "origunet."))
+    x = cond_frames(120, 3)
+    with torch.no_grad():
+        v_all, (_, _, (h_unet_all, h_vp_all)) = net([x.clone(), None, None])            # 3 frames = 3 time steps
+        v0, (_, _, (h_unet, h_vp)) = net([x[:2].clone(), None, None])                   # 2 steps ...
+        v1, (_, _, (h_unet2, h_vp2)) = net([x[2:].clone(), None, (h_unet, h_vp)])       # ... then 1 more with both states
+    save("g12_velpred_lstm", vel_all=v_all.numpy(), vel_split=torch.cat([v0, v1]).numpy(), vp_h=h_vp_all[0].numpy(),
+         vp_c=h_vp_all[1].numpy(), vp_h_split=h_vp2[0].numpy(),
+         keys=np.array(sorted(k for k in net.state_dict() if "lstm_velpred" in k)))
+
+
 # ------------------------------------------------------------------ G10: simulator difflog events (N4)
 def _reference_compute_events():
     """run_competition.py imports rospy / cv_bridge at module level, so the module cannot be imported here. The
@@ -372,7 +388,7 @@ def g0():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     with torch.no_grad():
         for g in which:
             globals()[g]()

@@ -192,6 +192,24 @@ def test_origunet_velpred_vs_golden(gpu_device, tag):
         assert rel_err(v2[i:i + 1].cpu(), o_i) < TOL
 
 
+def test_origunet_velpred_lstm_vs_golden(gpu_device):
+    """G12: the velpred head with lstm_velpred (2 layers, 432 features), 3 frames at once and 2 + 1 with state hand-off."""
+    g = golden("g12_velpred_lstm")
+    net, sd = _unet(gpu_device, **syn.VELPRED_LSTM_CASE)
+    x = cond_frames(120, 3).to(gpu_device)
+    v_all, (_, _, (_, hv)) = net([x.clone(), None, None])
+    assert hv[0].shape == (2, 432)
+    assert rel_err(v_all.cpu(), g["vel_all"]) < TOL and rel_err(hv[0].cpu(), g["vp_h"]) < TOL and rel_err(hv[1].cpu(), g["vp_c"]) < TOL
+    v0, (_, _, (hu, hv0)) = net([x[:2].clone(), None, None])
+    v1, (_, _, (_, hv1)) = net([x[2:].clone(), None, (hu, hv0)])
+    assert rel_err(torch.cat([v0, v1]).cpu(), g["vel_split"]) < TOL and rel_err(hv1[0].cpu(), g["vp_h_split"]) < TOL
+    # two independent streams in one call == two separate calls
+    net.forward_streams(x[:2].clone(), None, 2, 1)
+    va = net.last_yvel
+    vb = torch.cat([net([x[i:i + 1].clone(), None, None])[0] for i in range(2)])
+    assert rel_err(va.cpu(), vb.cpu()) < 1e-5
+
+
 def test_origunet_is_deployment_skips_decoder(gpu_device):
     """learner_models.py:553: is_deployment=True runs the encoder + ConvLSTM only (and a velpred=2 head on y_e5)."""
     g7, g9 = golden("g7_origunet"), golden("g9_velpred")
@@ -226,7 +244,7 @@ def test_velpred_errors(gpu_device):
     depth = torch.empty(1, 260, 346, device=gpu_device)
     h = torch.zeros(1, 8, 13, 512, device=gpu_device); c = torch.zeros_like(h)
     rc = L.evfly_unet_forward(net.hip().h, _lib.ptr(x), 1, 1, _lib.ptr(h), _lib.ptr(c), _lib.ptr(depth), None, None,
-                              _lib.cur_stream())
+                              None, None, _lib.cur_stream())
     assert rc < 0 and b"yvel_out" in L.evfly_last_error()
     # a checkpoint without the BatchNorm statistics is refused at finalize, by key
     sd2 = {k: v for k, v in sd.items() if "running_var" not in k}

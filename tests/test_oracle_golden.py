@@ -221,12 +221,28 @@ def test_origunet_velpred(tag):
         assert float(taps["velpred_enc"].max()) <= 0.0
 
 
+def test_origunet_velpred_lstm_stateful():
+    """G12: lstm_velpred (num_recurrent[1] = 2) run over 3 frames at once and as 2 + 1 frames with both hidden states."""
+    g = golden("g12_velpred_lstm")
+    case = syn.VELPRED_LSTM_CASE
+    import evfly_amd.learner_models as lm
+    m = lm.OrigUNet(num_in_channels=2, num_out_channels=1, input_shape=[1, 1, 260, 346], evs_min_cutoff=0.15,
+                    skip_type="interp", form_BEV=2, logger=lambda *a: None, **case)
+    assert sorted(k for k in m.state_dict() if "lstm_velpred" in k) == list(g["keys"])
+    sd = syn.fill_state_dict(m.state_dict(), "origunet.")
+    x = cond_frames(120, 3)
+    kw = dict(velpred=case["velpred"], enc_params=case["enc_params"], fc_params=case["fc_params"], num_recurrent=(1, 2))
+    v_all, (_, _, (_, hv)) = om.origunet_forward(sd, x, None, **kw)
+    assert rel_err(v_all, g["vel_all"]) < TOL and rel_err(hv[0], g["vp_h"]) < TOL and rel_err(hv[1], g["vp_c"]) < TOL
+    v0, (_, _, (hu, hv0)) = om.origunet_forward(sd, x[:2], None, **kw)
+    v1, (_, _, (_, hv1)) = om.origunet_forward(sd, x[2:], hu, vp_state=hv0, **kw)
+    assert rel_err(torch.cat([v0, v1]), g["vel_split"]) < TOL and rel_err(hv1[0], g["vp_h_split"]) < TOL
+
+
 def test_velpred_shell_errors():
     import evfly_amd.learner_models as lm
     case = syn.VELPRED_CASES["sim"]
     base = dict(num_in_channels=2, num_out_channels=1, input_shape=[1, 1, 260, 346], logger=lambda *a: None)
-    with pytest.raises(NotImplementedError):       # lstm_velpred
-        lm.OrigUNet(num_recurrent=[1, 1], **base, **case)
     with pytest.raises(ValueError):
         lm.OrigUNet(num_recurrent=[1, 0], **base, **{**case, "velpred": 3})
     bad = {**case, "enc_params": {**case["enc_params"], "conv_function": "upconv2d"}}
