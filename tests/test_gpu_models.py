@@ -317,6 +317,29 @@ def test_multi_stream_matches_per_stream_oracle(gpu_device):
     assert rel_err(vp.reshape(S, T, 3).cpu(), v.reshape(S, T, 3)[perm].cpu()) < 1e-6
 
 
+def test_stream_chunking_matches_unchunked(gpu_device):
+    """More than 320 frames in one call: the library walks the streams in chunks (model.hip kChunkFrames) with state
+    slices per chunk. 66 streams x 5 steps = 64 + 2 streams; every stream must equal the same stream run in a small
+    batch, and carried states must land in the right rows."""
+    net, sd = _composite(gpu_device)
+    S, T = 66, 5
+    base = cond_frames(95, 4 * T)                                  # 4 distinct streams, tiled
+    idx = torch.arange(S) % 4
+    x = base.reshape(4, T, 1, 260, 346)[idx].reshape(S * T, 1, 260, 346).to(gpu_device)
+    desvel = torch.full((S * T, 1), 4.0, device=gpu_device)
+    v, (d, up, ((hu, _), (lh, lc))) = net.forward_streams([x, desvel, [None, None], None], S, T)
+    vs, (ds, _, ((hus, _), (lhs, lcs))) = net.forward_streams([x[: 4 * T], desvel[: 4 * T], [None, None], None], 4, T)
+    v = v.reshape(S, T, 3); vs = vs.reshape(4, T, 3)
+    assert rel_err(v.cpu(), vs[idx].cpu()) < 1e-5                   # incl. streams 64, 65 of the second chunk
+    assert rel_err(d.reshape(S, T, 260, 346)[65].cpu(), ds.reshape(4, T, 260, 346)[65 % 4].cpu()) < 1e-5
+    assert rel_err(hu[0][0][65].cpu(), hus[0][0][65 % 4].cpu()) < 1e-5 and rel_err(lh[64].cpu(), lhs[0].cpu()) < 1e-5
+    # second call with the carried states, again across the chunk boundary
+    v2, _ = net.forward_streams([x, desvel, [hu, None], (lh, lc)], S, T)
+    v2s, _ = net.forward_streams([x[: 4 * T], desvel[: 4 * T], [hus, None], (lhs, lcs)], 4, T)
+    assert rel_err(v2.reshape(S, T, 3).cpu(), v2s.reshape(4, T, 3)[idx].cpu()) < 1e-5
+    assert rel_err(v2.cpu(), v.reshape(S * T, 3).cpu()) > 1e-4      # the state did change the answer
+
+
 def test_composite_bf16_mfma(gpu_device):
     """bf16-operand MFMA path (BASELINE configs C3/C5) against the fp32 oracle, looser bound."""
     net, sd = _composite(gpu_device, "bf16")
