@@ -199,3 +199,19 @@ def test_to_events_time_slicing_vs_golden(gpu_device):
         perm = np.random.RandomState(1).permutation(len(ev["t"]))
         fr2 = te.slice_trajectory({k: v[perm] for k, v in ev.items()}, edges, 60, 80, thr, thr)
         assert np.array_equal(fr2, g[tag])
+
+
+def test_to_events_empty_and_out_of_range(gpu_device):
+    """Trajectories with no events at all, or none inside the frame / the windows, give all-zero frames."""
+    from evfly_amd import to_events as te
+    edges = np.array([0.0, 1e7, 2e7, 3e7])
+    empty = dict(x=np.zeros(0, np.int64), y=np.zeros(0, np.int64), t=np.zeros(0, np.int64), p=np.zeros(0, np.int64))
+    fr = te.slice_trajectory(empty, edges, 12, 16)
+    assert fr.shape == (3, 12, 16) and fr.dtype == np.float64 and not fr.any()
+    outside = dict(x=np.array([-1, 17, 3, 3]), y=np.array([2, 2, 13, 2]), t=np.array([5, 5, 5, 40_000_000]),
+                   p=np.array([1, 1, -1, 1]))
+    assert not te.slice_trajectory(outside, edges, 12, 16).any()
+    edge = dict(x=np.array([16, 0, 1]), y=np.array([12, 0, 1]), t=np.array([0, 29_999_990, 29_999_999]), p=np.array([1, -1, 1]))
+    fr = te.slice_trajectory(edge, edges, 12, 16, 0.2, 0.3)      # right / bottom edge inclusive (np.histogram2d)
+    # the third event is 1 ns before the last edge: float32(29 999 999) == 3e7, so the reference's `ts < t_end` drops it
+    assert fr[0, 11, 15] == 0.2 and fr[2, 0, 0] == -0.3 and np.count_nonzero(fr) == 2
