@@ -108,7 +108,7 @@ int evfly_condition_frames(const uint8_t *src_u8, const float *src_f32, int n, i
 
 /* Replaces Aligner.align -> remap_img -> cv2.remap(img, mapx, mapy, cv2.INTER_CUBIC), the rectification between
  * decode and centre crop when align_evframe is set (utils/calibration_tools/rectify_bag.py:91-98,117-138;
- * evfly_ros/run.py:338-340; every shipped config sets it, learner/configs/*.txt:10). OpenCV is a third-party
+ * evfly_ros/run.py:338-340; every shipped config sets it, line 10 of every learner/configs text file). OpenCV is a third-party
  * dependency that is not in the reference tree (environment.yaml: opencv 4.5.x): the kernel restates the published
  * remap algorithm for CV_32FC1 maps / CV_32FC1 image / INTER_CUBIC / BORDER_CONSTANT(0) -- coordinates rounded to
  * 1/32 pixel (cvRound(map * 32)), 4x4 window at (ix-1, iy-1), separable float weights cubic(fy)[r] * cubic(fx)[c]
