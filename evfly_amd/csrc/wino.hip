@@ -246,16 +246,25 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))
     //   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
     // sets in LDS: k0 = s_01, k1 = s_10, k2 = s_11, k3 = s_20, k4 = s_21, k5 = s_30
     __syncthreads();
-    float *xch = smem;                                 // [mt MT][set 6][r 16][lane 64]  = MT x 24 KB
-    auto at = [&](int k, int r) -> float & { return xch[((mt * 6 + k) * 16 + r) * 64 + lane]; };
+    float4 *xch = reinterpret_cast<float4 *>(smem);   // [mt MT][set 6][r / 4][lane 64] float4 (r % 4)  = MT x 24 KB
+    auto at4 = [&](int k, int q) -> float4 & { return xch[((mt * 6 + k) * 4 + q) * 64 + lane]; };   // 16-B LDS accesses
     float own[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float s0 = acc[0][r] + acc[1][r] + acc[2][r], s1 = acc[1][r] - acc[2][r] - acc[3][r];
-        if (a == 0) { at(0, r) = s1; own[r] = s0; }
-        else if (a == 1) { at(1, r) = s0; at(2, r) = s1; own[r] = s1; }
-        else if (a == 2) { at(3, r) = s0; at(4, r) = s1; own[r] = -s0; }
-        else { at(5, r) = s0; own[r] = -s1; }
+    for (int q = 0; q < 4; ++q) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * q + i;
+            s0[i] = acc[0][r] + acc[1][r] + acc[2][r];
+            s1[i] = acc[1][r] - acc[2][r] - acc[3][r];
+        }
+        const float4 v0 = make_float4(s0[0], s0[1], s0[2], s0[3]), v1 = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        if (a == 0) at4(0, q) = v1;
+        else if (a == 1) { at4(1, q) = v0; at4(2, q) = v1; }
+        else if (a == 2) { at4(3, q) = v0; at4(4, q) = v1; }
+        else at4(5, q) = v0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) own[4 * q + i] = a == 0 ? s0[i] : a == 1 ? s1[i] : a == 2 ? -s0[i] : -s1[i];
     }
     __syncthreads();
     const int kA = a == 0 ? 1 : a == 1 ? 0 : a == 2 ? 1 : 2, kB = a == 0 ? 3 : a == 1 ? 4 : a == 2 ? 5 : 4;
@@ -266,10 +275,15 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))
     // index arithmetic runs once per four channels instead of once per value
     float *ot = smem + MT * 6 * 16 * 64;               // MT x 16 KB behind the exchange sets
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        float y = own[r] + at(kA, r) + sB * at(kB, r) + bias;
-        ot[(tl * 4 + a) * 32 + fm] = apply_act(y, d.act);
+    for (int q = 0; q < 4; ++q) {
+        const float4 pa = at4(kA, q), pb = at4(kB, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * q + i;
+            const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            const float y = own[r] + f4e(pa, i) + sB * f4e(pb, i) + bias;
+            ot[(tl * 4 + a) * 32 + fm] = apply_act(y, d.act);
+        }
     }
     __syncthreads();
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
