@@ -41,7 +41,7 @@ struct WinoGeom {
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
     double cost;                // plan cost (launched tile slots + weighted patch pixels)
-    int dbg;                    // ablation switches (EVFLY_WINO_ABL): 1 no patch DMA, 4 no stores, 8 no LDS reads, 16 no U loads, 32 K loop twice
+    int dbg;                    // ablation switches (EVFLY_WINO_ABL): 1 no patch DMA, 4 no stores, 8 no LDS reads, 16 no U loads, 32 K loop twice, 64 no chunk barrier
 };
 
 // Opaque identity: stops hipcc from hoisting the per-step address XORs out of the chunk loop (LICM would turn six
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int reps = (g.dbg & 32) ? 2 : 1;      // timing experiment: walk the K loop twice (results are garbage)
     for (int rep = 0; rep < reps; ++rep)
     for (int cc = 0; cc < nchunks; ++cc) {
-        __syncthreads();            // chunk cc has landed; everyone is done reading the other buffer
+        if (!(g.dbg & 64)) __syncthreads();   // chunk cc has landed; everyone is done reading the other buffer
         const char *cur = reinterpret_cast<const char *>(patch + (cc & 1) * buf_floats);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
