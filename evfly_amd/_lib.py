@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevfly_hip.so")
+# EVFLY_LIB: developer override (A/B of two builds of the same ABI from tools/); the default is the in-tree build
+LIB_PATH = os.environ.get("EVFLY_LIB") or os.path.join(_HERE, "libevfly_hip.so")
 _LIB = None
 
 c_p = C.c_void_p

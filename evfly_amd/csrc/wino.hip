@@ -19,29 +19,53 @@
 // The output transform is lane-local along b; along a the four waves of an M-tile trade partial sums through LDS,
 // then the finished tile is transposed through LDS for 16-B global stores. nn.MaxPool2d(2, 2) fuses trivially (a
 // Winograd tile IS one pooling window), and the first U-Net conv can be fused in as the patch producer.
+//
+// Memory pipeline (hand counted). hipcc (ROCm 7.2) drains the whole vector-memory queue (s_waitcnt vmcnt(0)) at
+// every use of an ordinary load result while an LDS-DMA is outstanding, and before every ds_read that follows one,
+// so both kinds of load are issued from inline asm here and the kernel counts the queue itself:
+//   * patch DMA = ND x `buffer_load_dwordx4 ... lds` per wave and chunk through a buffer descriptor over the block's
+//     images (out-of-range lanes -- halo beyond the map, padded groups -- read zeros, no zero page, no branches);
+//     per-lane byte offsets are computed once per block, the chunk advances through the scalar offset;
+//   * U = `global_load_dwordx2` (scalar base + lane offset), four in flight per wave, each refilled right after the
+//     MFMAs that consumed it; the wait in front of a use is vmcnt(3) (or vmcnt(3 + ND) while the chunk's DMA pieces
+//     sit younger in the queue), never 0;
+//   * one barrier per chunk: `s_waitcnt vmcnt(4) lgkmcnt(0); s_barrier` -- the four U refills stay in flight across
+//     it; the DMA of chunk c+1 is issued right behind the barrier that opens chunk c (a whole chunk of MFMAs ahead).
 #include "igemm.h"
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <type_traits>
 #include <vector>
+
+// Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 no patch DMA,
+// 4 no global stores, 8 no LDS fragment reads, 16 no U loads. The shipped library is built with 0.
+#ifndef EVFLY_WINO_ABL
+#define EVFLY_WINO_ABL 0
+#endif
 
 namespace evfly {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int kAbl = EVFLY_WINO_ABL;
 
 struct WinoGeom {
     int IMGS, TY, TX, PH, PW;   // tiles per block and patch size (pixels) per image
     int npix;                   // IMGS * PH * PW
-    int ngroups;                // DMA groups of 8 pixels
+    int ngroups;                // DMA groups of 8 pixels (<= ND * waves: the kernel issues ND pieces per wave)
     int ntiles;                 // IMGS * TY * TX  (<= 32 * MT)
     int bx, by, bi;             // blocks along x, y, image groups
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
     double cost;                // plan cost (launched tile slots + weighted patch pixels)
-    int dbg;                    // ablation switches (EVFLY_WINO_ABL): 1 no patch DMA, 4 no stores, 8 no LDS reads, 16 no U loads, 32 K loop twice, 64 no chunk barrier
 };
 
 // Opaque identity: stops hipcc from hoisting the per-step address XORs out of the chunk loop (LICM would turn six
@@ -49,6 +73,32 @@ struct WinoGeom {
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// ---- hand-counted vector-memory queue (see the header). Every statement is `asm volatile`: program order among them
+// is the issue order the vmcnt arithmetic below assumes.
+// U refill: 8 B per lane from (scalar base + lane offset + OFF).
+template <int OFF>
+__device__ __forceinline__ void u_load(f32x2 &dst, unsigned voff, const float *sbase) {
+    if constexpr (kAbl & 16) { dst = f32x2{1.f, 2.f}; return; }
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+// wait until at most N vector-memory operations younger than `b`'s load are outstanding; naming `b` read-write pins
+// every consumer of it below the wait
+template <int N>
+__device__ __forceinline__ void u_wait(f32x2 &b) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b) : "n"(N)); }
+// one 1-KiB LDS-DMA piece: lane l's 16 B land at lds_addr + 16 l; M0 (the LDS base of the DMA) is compiler-reserved,
+// so it is saved and restored inside the statement
+__device__ __forceinline__ void dma_piece(unsigned voff, i32x4 srd, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+}
+// chunk barrier: this wave's DMA pieces of the chunk about to be read have landed (they are older than the NKEEP
+// U refills that stay in flight), its fragment reads of the buffer about to be overwritten have returned
+template <int NKEEP>
+__device__ __forceinline__ void chunk_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NKEEP) : "memory");
+}
 
 // input formation of learner_models.py:476-494 (identical to ops.hip form_value; kept local so the fused producer
 // below is bitwise the arithmetic of k_e11)
@@ -80,7 +130,8 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
     for (int i = tid; i < 9 * CIN * 32 + 32; i += NTHR) wl[i] = i < 9 * CIN * 32 ? d.pre_w[i] : d.pre_b[i - 9 * CIN * 32];
     __syncthreads();
     const float *bl = wl + 9 * CIN * 32;
-    for (int idx = tid; idx < g.ngroups * 32; idx += NTHR) {
+    const int nitems = g.ngroups * 32;
+    for (int idx = tid; idx < nitems; idx += NTHR) {
         const int pp = idx >> 3, ch = idx & 7;
         const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
         const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
@@ -122,12 +173,18 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
 // ---------------------------------------------------------------------------------------------------- kernel
 // Block tile = MT M-tiles of 32 Winograd tiles x 32 output channels over 4*MT waves: wave = (M-tile mt, position row
 // a in 0..3), four accumulator tiles (64 registers). Everything fits in 128 VGPRs: four waves per SIMD. MT = 2
-// (512 threads, 80 KB LDS, two blocks per CU) halves the halo and U traffic per MFMA; MT = 1 (256 threads, <= 40 KB
-// LDS, four blocks per CU) keeps four independent blocks in flight, which matters for the one- and two-chunk layers
-// whose load / MFMA / store phases are of similar length (e12: 64 MFMAs per wave between a cold DMA and the stores).
-template <int MT>
-__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino8(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
+// (512 threads, 80 KB LDS, two blocks per CU) halves the halo and the L2 -> L1 U traffic per MFMA; MT = 1 (256
+// threads, <= 48 KB LDS, three or four blocks per CU) keeps more independent blocks in flight, which matters for the
+// one- and two-chunk layers whose load / MFMA / store phases are of similar length (e12: 64 MFMAs per wave between the
+// patch production and the stores). ND = DMA pieces per wave and chunk; one patch buffer is ND * 4 * MT KiB.
+// ONE = single-chunk layer (C_in = 32): no DMA inside the chunk loop. MT = 1 blocks run three per CU with 168 registers
+// per wave (room to fetch the next quarter's fragments under the current quarter's MFMAs); MT = 2 blocks two per CU
+// with 128.
+template <int MT, int ND, bool ONE>
+__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 : 3, MT == 2 ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
     constexpr int NW = 4 * MT, NTHR = 256 * MT;
+    constexpr bool PREFETCH = MT == 1;
+    constexpr int BUF_FLOATS = ND * NW * 256;             // one patch buffer: ND * NW pieces of 1 KiB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;
 
@@ -169,77 +226,121 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     const int nchunks = d.C / 32;
-    // U stream: [nt][cc][j][hg][pos 16][lane 64][2]; this wave reads pos 4a .. 4a+3
-    const float2 *ub = reinterpret_cast<const float2 *>(U) + ((int64_t)nt * nchunks * 8 * 16 + 4 * a) * 64 + lane;
-    float2 bcur[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) bcur[p] = ub[p * 64];
-    ub += 16 * 64;
-
     const int iy0 = 2 * ty0, ix0 = 2 * tx0;
-    const int buf_floats = g.ngroups * 8 * 32;
-    auto dma = [&](int cc, float *dst) {
-        if (g.dbg & 1) return;
+
+    // ---- patch: either produced from the raw frame (fused first conv, single-chunk layers only) or DMA'd. Descriptor
+    // over the block's images, per-lane byte offsets of this wave's ND pieces.
+    i32x4 srd = {0, 0, 0, 0};
+    unsigned voff[ND] = {};
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)patch;        // LDS byte address of buffer 0
+    bool produced = false;
+    if constexpr (ONE) {
+        if (d.pre_frames) {
+            if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
+            else produce_patch<2, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
+            produced = true;
+        }
+    }
+    if (!produced) {
+        const int nimg = min(g.IMGS, d.NI - img0);
+        const uint64_t xb = (uint64_t)(uintptr_t)(d.x + (int64_t)img0 * d.H * d.W * d.ldx);
+        srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        srd[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
+        srd[2] = __builtin_amdgcn_readfirstlane((int)((int64_t)nimg * d.H * d.W * d.ldx * 4));
+        srd[3] = 0x00020000;
         const int pl = lane >> 4, sp = lane & 15;
-        for (int gi = wv; gi < g.ngroups; gi += NW) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int gi = wv + i * NW;
             const int pp = gi * 4 + pl;
             const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
             const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
             const int sl = sp ^ ((pxh + (py >> 1) * g.TX + im * per) & 15);
             const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
-            const int iy = iy0 + py, ix = ix0 + px, img = img0 + im;
-            const bool ok = 2 * pp < g.npix && img < d.NI && iy < d.H && ix < d.W;
-            const float *src = ok ? d.x + (((int64_t)img * d.H + iy) * d.W + ix) * d.ldx + cc * 32 + ch * 4 : d.zeros;
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + gi * 8 * 32), 16, 0, 0);
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = 2 * pp < g.npix && img0 + im < d.NI && iy < d.H && ix < d.W;
+            voff[i] = ok ? (unsigned)((((int64_t)im * d.H + iy) * d.W + ix) * d.ldx * 4 + ch * 16) : 0x7ffffff0u;   // out of range: zeros
+        }
+    }
+    // chunk cc -> buffer cc & 1. `live` false (behind the last chunk): the same ND pieces are issued with every lane out
+    // of range -- zeros into the idle buffer, no memory traffic -- so that the queue arithmetic below has no branch
+    auto dma = [&](int cc, bool live) {
+        if constexpr (kAbl & 1) return;
+        const unsigned dst = lds0 + (unsigned)((cc & 1) * BUF_FLOATS * 4) + (unsigned)wv * 1024u;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+            dma_piece(live ? voff[i] : 0x7ffffff0u, srd, __builtin_amdgcn_readfirstlane(cc * 128),
+                      __builtin_amdgcn_readfirstlane(dst + (unsigned)(i * NW) * 1024u));
+    };
+
+    // U stream: [nt][cc][j][hg][pos 16][lane 64][2]; this wave reads pos 4a .. 4a+3: 512 B apart, 8 KiB per half-step
+    const float *ub = U + (((int64_t)nt * nchunks * 8 * 16 + 4 * a) * 64) * 2;
+    const unsigned ulane = lane * 8;
+    f32x2 bcur[4];
+
+    if (!produced) dma(0, true);
+    u_load<0>(bcur[0], ulane, ub); u_load<512>(bcur[1], ulane, ub); u_load<1024>(bcur[2], ulane, ub); u_load<1536>(bcur[3], ulane, ub);
+    ub += 16 * 64 * 2;
+
+    float4 fu[4], fv[4];          // raw fragment rows rA / rB of the four patch columns
+    auto read_frag = [&](const char *cur, int j) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int x = (j << 5) | ((c & 1) << 7);
+            if constexpr (kAbl & 8) { fu[c] = make_float4(1.f, 2.f, 3.f, (float)lane); fv[c] = fu[c]; }
+            else {
+                fu[c] = *reinterpret_cast<const float4 *>(cur + (opaque(off0[0][c >> 1]) ^ x));
+                fv[c] = *reinterpret_cast<const float4 *>(cur + (opaque(off0[1][c >> 1]) ^ x));
+            }
         }
     };
-    if (d.pre_frames) {
-        if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, buf_floats, img0, iy0, ix0, tid);
-        else produce_patch<2, NTHR>(d, g, patch, buf_floats, img0, iy0, ix0, tid);
-    } else {
-        dma(0, patch);
-    }
-    const int reps = (g.dbg & 32) ? 2 : 1;      // timing experiment: walk the K loop twice (results are garbage)
-    for (int rep = 0; rep < reps; ++rep)
-    for (int cc = 0; cc < nchunks; ++cc) {
-        if (!(g.dbg & 64)) __syncthreads();   // chunk cc has landed; everyone is done reading the other buffer
-        const char *cur = reinterpret_cast<const char *>(patch + (cc & 1) * buf_floats);
+    float4 t[4];
+    auto combine = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            t[c] = make_float4(fmaf(sg, fv[c].x, fu[c].x), fmaf(sg, fv[c].y, fu[c].y), fmaf(sg, fv[c].z, fu[c].z), fmaf(sg, fv[c].w, fu[c].w));
+    };
+    // one half-step: channel pair e, e + 1 of the four positions (8 MFMAs); KW = operations younger than bcur[p]'s load
+    auto half_step = [&](auto kw, int hg) {
+        constexpr int KW = decltype(kw)::value;
+        const int e = 2 * hg;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float va, vb;
+            if (p == 0)      { va = f4e(t[0], e) - f4e(t[2], e); vb = f4e(t[0], e + 1) - f4e(t[2], e + 1); }
+            else if (p == 1) { va = f4e(t[1], e) + f4e(t[2], e); vb = f4e(t[1], e + 1) + f4e(t[2], e + 1); }
+            else if (p == 2) { va = f4e(t[2], e) - f4e(t[1], e); vb = f4e(t[2], e + 1) - f4e(t[1], e + 1); }
+            else             { va = f4e(t[1], e) - f4e(t[3], e); vb = f4e(t[1], e + 1) - f4e(t[3], e + 1); }
+            u_wait<KW>(bcur[p]);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, bcur[p].x, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, bcur[p].y, acc[p], 0, 0, 0);
+            // refill (one half-step of slack behind the end of U: unconditional)
+            if (p == 0) u_load<0>(bcur[0], ulane, ub);
+            else if (p == 1) u_load<512>(bcur[1], ulane, ub);
+            else if (p == 2) u_load<1024>(bcur[2], ulane, ub);
+            else u_load<1536>(bcur[3], ulane, ub);
+        }
+        ub += 16 * 64 * 2;
+    };
+
+    constexpr int KDMA = 3 + ((kAbl & 1) ? 0 : ND);     // while the chunk's DMA pieces sit younger than bcur's loads
+    for (int cc = 0; cc < (ONE ? 1 : nchunks); ++cc) {
+        chunk_barrier<4>();          // chunk cc has landed; everyone is done reading the other buffer
+        const char *cur = reinterpret_cast<const char *>(patch + (cc & 1) * BUF_FLOATS);
+        if constexpr (!ONE) dma(cc + 1, cc + 1 < nchunks);
+        read_frag(cur, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float4 t[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int x = (j << 5) | ((c & 1) << 7);
-                float4 u, v;
-                if (g.dbg & 8) { u = make_float4(1.f, 2.f, 3.f, (float)lane); v = u; }
-                else {
-                    u = *reinterpret_cast<const float4 *>(cur + (opaque(off0[0][c >> 1]) ^ x));
-                    v = *reinterpret_cast<const float4 *>(cur + (opaque(off0[1][c >> 1]) ^ x));
-                }
-                t[c] = make_float4(fmaf(sg, v.x, u.x), fmaf(sg, v.y, u.y), fmaf(sg, v.z, u.z), fmaf(sg, v.w, u.w));
-            }
-            // last fragment reads of the chunk are issued: the next chunk's DMA may start (hipcc orders every
-            // later ds_read behind an outstanding LDS-DMA with vmcnt(0), so it must not be issued earlier)
-            if (j == 3 && cc + 1 < nchunks) dma(cc + 1, patch + ((cc + 1) & 1) * buf_floats);
-#pragma unroll
-            for (int hg = 0; hg < 2; ++hg) {
-                // position-outer, refill after use (slack behind the last step: unconditional loads)
-                const int e = 2 * hg;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    float va, vb;
-                    if (p == 0)      { va = f4e(t[0], e) - f4e(t[2], e); vb = f4e(t[0], e + 1) - f4e(t[2], e + 1); }
-                    else if (p == 1) { va = f4e(t[1], e) + f4e(t[2], e); vb = f4e(t[1], e + 1) + f4e(t[2], e + 1); }
-                    else if (p == 2) { va = f4e(t[2], e) - f4e(t[1], e); vb = f4e(t[2], e + 1) - f4e(t[1], e + 1); }
-                    else             { va = f4e(t[1], e) - f4e(t[3], e); vb = f4e(t[1], e + 1) - f4e(t[3], e + 1); }
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, bcur[p].x, acc[p], 0, 0, 0);
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, bcur[p].y, acc[p], 0, 0, 0);
-                    if (!(g.dbg & 16)) bcur[p] = ub[p * 64];
-                }
-                ub += 16 * 64;
-            }
+            combine();
+            if (j == 0 && !ONE) half_step(std::integral_constant<int, KDMA>{}, 0);
+            else half_step(std::integral_constant<int, 3>{}, 0);
+            if constexpr (PREFETCH) { if (j < 3) read_frag(cur, j + 1); }      // next quarter's fragments fly under the second half-step
+            half_step(std::integral_constant<int, 3>{}, 1);
+            if constexpr (!PREFETCH) { if (j < 3) read_frag(cur, j + 1); }
         }
     }
+    // drain the slack refills before their registers die
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3]));
 
     // ---- output transform. Lane-local along b: s0 = M_a0 + M_a1 + M_a2, s1 = M_a1 - M_a2 - M_a3. Along a the four
     // waves of an M-tile trade through LDS; wave a owns output pixel (i, x) = (a >> 1, a & 1) of every tile:
@@ -292,7 +393,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int idx = tid + q * NTHR, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
         const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
         const int img = img0 + im, oy = 2 * (ty0 + ty) + (pix >> 1), ox = 2 * (tx0 + tx) + (pix & 1), n = n0 + c4 * 4;
-        if (tl >= g.ntiles || img >= d.NI || oy >= d.OH || ox >= d.OW || n >= d.Nc || (g.dbg & 4)) continue;
+        if (tl >= g.ntiles || img >= d.NI || oy >= d.OH || ox >= d.OW || n >= d.Nc || (kAbl & 4)) continue;
         const float4 v = *reinterpret_cast<const float4 *>(ot + pl * 32 + c4 * 4);
         float *dst = d.y + (((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy + n;
         if (vec) *reinterpret_cast<float4 *>(dst) = v;
@@ -303,7 +404,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
         const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx, n = n0 + c4 * 4;
         const int PHo = d.OH / 2, PWo = d.OW / 2;
-        if (tl < g.ntiles && img < d.NI && gy < PHo && gx < PWo && n < d.Nc && !(g.dbg & 4)) {
+        if (tl < g.ntiles && img < d.NI && gy < PHo && gx < PWo && n < d.Nc && !(kAbl & 4)) {
             const float4 p0 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 0) * 32 + c4 * 4);
             const float4 p1 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 1) * 32 + c4 * 4);
             const float4 p2 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 2) * 32 + c4 * 4);
@@ -383,7 +484,6 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
     g.n_btiles = g.bx * g.by * g.bi;
     g.cpx = cdiv(g.n_btiles, kNumXCD);
     g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
-    g.dbg = getenv("EVFLY_WINO_ABL") ? atoi(getenv("EVFLY_WINO_ABL")) : 0;
     return true;
 }
 
@@ -413,49 +513,81 @@ int wino_pack_device(const float *w, int cout, int cin, int64_t sn, int64_t sc, 
 bool wino_applicable(const ConvDesc &d) {
     static const int mode = getenv("EVFLY_WINO") ? atoi(getenv("EVFLY_WINO")) : 1;
     if (mode == 0) return false;
+    // the patch DMA addresses a block's (<= 4) images through one buffer descriptor: 32-bit byte offsets
+    const bool fits = d.pre_frames || (int64_t)4 * d.H * d.W * d.ldx * 4 < ((int64_t)1 << 31);
     return d.dtype == EVFLY_DTYPE_F32 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 && d.C % 32 == 0 &&
-           d.out_mode == OUT_ROWS && !d.res && (d.pre_frames || (d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0)) && d.OH >= 1 && d.OW >= 1;
+           d.out_mode == OUT_ROWS && !d.res && (d.pre_frames || (d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0)) && d.OH >= 1 && d.OW >= 1 && fits;
 }
 
 namespace {
 
-struct WinoCfg { int MT, nbuf, max_px; };
+// kernel variant: M-tiles per block, DMA pieces per wave and chunk (one patch buffer = ND * 4 * MT KiB = ND * MT * 32
+// pixels), patch buffers
+struct WinoCfg { int MT, ND, nbuf; int max_px() const { return ND * MT * 32; } };
 
-// One-chunk layers (C_in = 32: e12, e21, d42) run 256-thread blocks with a single patch buffer, four per CU; the
-// others 512-thread blocks with two 40 KB buffers, two per CU, unless the small block fills its tile slots much
-// better (MT = 1 on a multi-chunk layer: two 26 KB buffers, three blocks per CU). EVFLY_WINO_MT = 1 / 2 forces one.
-WinoCfg choose(const ConvDesc &d) {
+struct WinoPlan { WinoCfg c; WinoGeom g; double exec_flops, efficiency; bool ok; };
+
+// One-chunk layers (C_in = 32: e12, e21, d42) run 256-thread blocks with a single 40 KB patch buffer, four per CU;
+// the others 512-thread blocks with two 40 KB buffers, two per CU, unless the small block fills its tile slots much
+// better (MT = 1 on a multi-chunk layer: two 24 KB buffers, three blocks per CU). EVFLY_WINO_MT = 1 / 2 forces one.
+WinoPlan make_plan(const ConvDesc &d) {
     static const int force = getenv("EVFLY_WINO_MT") ? atoi(getenv("EVFLY_WINO_MT")) : 0;
     const int nchunks = d.C / 32;
-    const WinoCfg c2{2, nchunks > 1 ? 2 : 1, 320};
-    const WinoCfg c1 = nchunks == 1 ? WinoCfg{1, 1, 320} : WinoCfg{1, 2, 208};
-    if (force) return force == 2 ? c2 : c1;
-    if (nchunks == 1) return c1;
-    // multi-chunk layers: the small block is 5-15 % slower at equal tile efficiency (handicap 1.08) (measured on e32 / e42 / d11), but
-    // wins when 64-tile blocks fill badly (e51: 40 tiles per image)
+    const WinoCfg c2{2, 5, nchunks > 1 ? 2 : 1};
+    const WinoCfg c1 = nchunks == 1 ? WinoCfg{1, 10, 1} : WinoCfg{1, 6, 2};
     WinoGeom g1, g2;
-    const bool ok1 = plan(d, g1, c1.MT, c1.max_px), ok2 = plan(d, g2, c2.MT, c2.max_px);
-    if (ok1 && ok2) return 1.08 * g1.cost < g2.cost ? c1 : c2;
-    return ok2 ? c2 : c1;
+    const bool ok1 = plan(d, g1, c1.MT, c1.max_px()), ok2 = plan(d, g2, c2.MT, c2.max_px());
+    bool use2;
+    if (force) use2 = force == 2 ? ok2 : !ok1;
+    else if (nchunks == 1) use2 = !ok1;
+    // multi-chunk layers: the small block is 5-15 % slower at equal tile efficiency (handicap 1.08) (measured on e32 /
+    // e42 / d11), but wins when 64-tile blocks fill badly (e51: 40 tiles per image)
+    else use2 = ok1 && ok2 ? !(1.08 * g1.cost < g2.cost) : ok2;
+    WinoPlan p;
+    p.ok = use2 ? ok2 : ok1;
+    p.c = use2 ? c2 : c1;
+    p.g = use2 ? g2 : g1;
+    if (p.ok) {
+        // matrix-core flops the launch issues: 16 positions x tile slots x 32-channel slices x C_in, times 2
+        p.exec_flops = 2.0 * 16.0 * ((double)p.g.n_btiles * 32.0 * p.c.MT) * ((double)p.g.n_nt * 32.0) * d.C;
+        p.efficiency = (double)d.NI * cdiv(d.OH, 2) * cdiv(d.OW, 2) / (32.0 * p.c.MT * p.g.n_btiles);
+    } else {
+        p.exec_flops = p.efficiency = 0;
+    }
+    return p;
 }
 
-template <int MT>
-int launch(const ConvDesc &d, const float *U, const WinoGeom &g, const WinoCfg &c, hipStream_t st) {
+// plans depend on the geometry only: searched once per (NI, OH, OW, C, Nc)
+const WinoPlan &cached_plan(const ConvDesc &d) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int>, WinoPlan> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc);
+    auto it = cache.find(key);
+    if (it == cache.end()) it = cache.emplace(key, make_plan(d)).first;
+    return it->second;
+}
+
+template <int MT, int ND, bool ONE>
+int launch(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
+    const WinoGeom &g = p.g;
     // patch buffer(s); the epilogue reuses them for the exchange sets (MT x 24 KB) + the transposed tile (MT x 16 KB)
-    int lds = std::max(c.nbuf * g.ngroups * 8 * 32 * 4, MT * 40 * 1024);
+    const int buf = ND * 4 * MT * 1024;
+    int lds = std::max(p.c.nbuf * buf, MT * 40 * 1024);
     if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
-        lds = std::max(lds, (g.ngroups * 8 * 32 + d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
-    auto kern = k_wino8<MT>;
+        lds = std::max(lds, buf + (d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
+    auto kern = k_wino9<MT, ND, ONE>;
     static bool lds_set = false;
     if (!lds_set) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         lds_set = true;
     }
-    if (getenv("EVFLY_WINO_DBG")) {
+    static const bool dbg = getenv("EVFLY_WINO_DBG") != nullptr;
+    if (dbg) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256 * MT, lds);
-        fprintf(stderr, "wino<%d>: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, %d B LDS, %d blocks/CU\n", MT, d.NI,
-                d.OH, d.OW, d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, lds, nb);
+        fprintf(stderr, "wino<%d,%d,%d>: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, %d B LDS, %d blocks/CU\n", MT, ND, (int)ONE,
+                d.NI, d.OH, d.OW, d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, lds, nb);
     }
     hipLaunchKernelGGL(kern, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256 * MT), lds, st, d, U, g);
     EVFLY_LAUNCH_CHECK();
@@ -464,31 +596,21 @@ int launch(const ConvDesc &d, const float *U, const WinoGeom &g, const WinoCfg &
 
 }  // namespace
 
-double wino_efficiency(const ConvDesc &d) {
-    WinoGeom g;
-    const WinoCfg c = choose(d);
-    if (!plan(d, g, c.MT, c.max_px)) return 0;
-    return (double)d.NI * cdiv(d.OH, 2) * cdiv(d.OW, 2) / (32.0 * c.MT * g.n_btiles);
-}
+double wino_efficiency(const ConvDesc &d) { return cached_plan(d).efficiency; }
 
-// matrix-core flops the launch issues: 16 positions x tile slots x 32-channel slices x C_in, times 2
-double wino_exec_flops(const ConvDesc &d) {
-    WinoGeom g;
-    const WinoCfg c = choose(d);
-    if (!plan(d, g, c.MT, c.max_px)) return 0;
-    return 2.0 * 16.0 * ((double)g.n_btiles * 32.0 * c.MT) * ((double)g.n_nt * 32.0) * d.C;
-}
+double wino_exec_flops(const ConvDesc &d) { return cached_plan(d).exec_flops; }
 
-int wino_launch(const ConvDesc &d_in, const float *U, hipStream_t st) {
-    ConvDesc d = d_in;
-    WinoGeom g;
-    const WinoCfg c = choose(d);
-    EVFLY_REQUIRE(plan(d, g, c.MT, c.max_px), "wino: no tile plan");
+int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
+    const WinoPlan &p = cached_plan(d);
+    EVFLY_REQUIRE(p.ok, "wino: no tile plan");
+    EVFLY_REQUIRE(p.g.ngroups <= p.c.ND * 4 * p.c.MT, "wino: patch exceeds the DMA piece budget");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
                   "wino: the fused first-conv producer needs C == 32 and 1 or 2 frame channels");
-    if (int rc = igemm_zero_page(&d.zeros)) return rc;
-    return c.MT == 2 ? launch<2>(d, U, g, c, st) : launch<1>(d, U, g, c, st);
+    const bool one = d.C == 32;
+    EVFLY_REQUIRE(one || p.c.nbuf == 2, "wino: multi-chunk layers need two patch buffers");
+    if (p.c.MT == 2) return one ? launch<2, 5, true>(d, U, p, st) : launch<2, 5, false>(d, U, p, st);
+    return one ? launch<1, 10, true>(d, U, p, st) : launch<1, 6, false>(d, U, p, st);
 }
 
 }  // namespace evfly
