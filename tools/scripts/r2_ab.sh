@@ -1,8 +1,6 @@
-set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-(timeout 600 python -m pytest tests/test_gpu_wino.py -x -q 2>&1 | tail -15) > gpurun_out/r2a_wino_tests.log
-(timeout 300 python tools/conv_sweep.py 5 2>&1) > gpurun_out/r2a_sweep_new.log
-(EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_hip_r1.so timeout 300 python tools/conv_sweep.py 5 2>&1) > gpurun_out/r2a_sweep_old.log
-(timeout 300 python tools/conv_sweep.py 5 2>&1) > gpurun_out/r2a_sweep_new2.log
-tail -30 gpurun_out/r2a_wino_tests.log; paste gpurun_out/r2a_sweep_old.log gpurun_out/r2a_sweep_new.log | cut -c1-200
+L="e21 e22 e32 e42 d41 e51 d12"
+EVFLY_WINO_MT=1 EVFLY_WINO_STAGGER=0 timeout 300 python tools/conv_sweep.py 200 $L 2>&1 | grep -v amdgpu > gpurun_out/r2d_mt1_p.log
+EVFLY_WINO_MT=1 EVFLY_WINO_PERSIST=0 timeout 300 python tools/conv_sweep.py 200 $L 2>&1 | grep -v amdgpu > gpurun_out/r2d_mt1_np.log
+EVFLY_WINO_MT=2 EVFLY_WINO_PERSIST=0 timeout 300 python tools/conv_sweep.py 200 $L 2>&1 | grep -v amdgpu > gpurun_out/r2d_mt2_np.log
+paste <(awk '{print $1,$2}' gpurun_out/r2d_mt2_np.log) <(awk '{print $2}' gpurun_out/r2d_mt1_np.log) <(awk '{print $2}' gpurun_out/r2d_mt1_p.log)
