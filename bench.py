@@ -34,6 +34,7 @@ H, W = 260, 346
 # so its algorithmic-flop ceiling is a third of the bf16 peak.
 PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC = "r2_pmc_traffic.json"       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, summarised per kernel family
 
 
 def parse():
@@ -102,10 +103,21 @@ def cpu_baseline(sd, T, epw, budget_s):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start one rank per GPU as CHILD processes (nothing in this process has touched the
+        # GPU yet) and leave with their exit code -- never silently measure one GPU when N were asked for
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dist = None
@@ -215,28 +227,31 @@ def main():
         # --pmc WRITE_SIZE, separate runs of this script at the C2 shape; FETCH doubled per the gfx950 calibration in
         # profiles/README.md). PMC counters cannot be read inside this process, so the figure is null for other shapes.
         traffic, tnote = None, "no PMC summary for this shape/dtype"
-        pmc = os.path.join(REPO, "profiles", "r1f_pmc_traffic.json")
+        pmc = os.path.join(REPO, "profiles", PMC_TRAFFIC)
         if os.path.exists(pmc) and a.dtype == "f32" and (B, T, a.events_per_window) == (64, 5, 60_000):
             g = json.load(open(pmc))["kernels"]["wino_conv3x3"]
             traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
-            tnote = ("HBM bytes per launch, mean over the %d conv3x3 (k_wino8) launches of a step: (2 x FETCH_SIZE + "
-                     "WRITE_SIZE) from profiles/r1f_pmc_traffic.json; algorithmic = bytes_per_launch"
+            tnote = ("HBM bytes per launch, mean over the %d conv3x3 (k_wino9) launches of a step: (2 x FETCH_SIZE + "
+                     "WRITE_SIZE) from profiles/" + PMC_TRAFFIC + "; algorithmic = algorithmic.bytes_per_launch"
                      % g["launches_per_step"])
         if dom["flops"]:
-            out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(tfl, 2), "peak": PEAK[a.dtype],
-                               "unit": "TFLOP/s", "frac": round(tfl / PEAK[a.dtype], 4), "traffic": traffic, "traffic_note": tnote,
+            # `achieved` = the flops the matrix cores EXECUTE per second in this kernel family. For the Winograd
+            # F(2x2,3x3) kernel that is 16/36 of the direct-convolution count plus tile padding (exec_flops, from the
+            # launch plans); the algorithmic (direct-conv, SURVEY.md §8d: 2*M*N*K) rate is kept beside it as
+            # `algorithmic` -- it can exceed the MFMA peak and says nothing about headroom, `frac` does.
+            ex_flops = dom["exec_flops"] if dom["exec_flops"] else dom["flops"]
+            ex = ex_flops / (dom["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ex, 2), "peak": PEAK[a.dtype],
+                               "unit": "TFLOP/s", "frac": round(ex / PEAK[a.dtype], 4), "traffic": traffic, "traffic_note": tnote,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                               "flops_per_launch": dom["flops"] / dom["launches"],
-                               "bytes_per_launch": dom["bytes"] / dom["launches"]}
-            if dom["exec_flops"] and abs(dom["exec_flops"] - dom["flops"]) > 1e-6 * dom["flops"]:
-                # `achieved` is ALGORITHMIC work (direct 3x3 convolution flops) over time. The fp32 path runs Winograd
-                # F(2x2,3x3): the matrix cores issue 16/36 of that count (plus tile padding), so `frac` can approach or
-                # pass 1 while the MFMA pipe itself is at `mfma_issued.frac` of its peak.
-                ex = dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12
-                out["roofline"]["mfma_issued"] = {"tflops": round(ex, 2), "frac": round(ex / PEAK[a.dtype], 4),
-                                                  "flops_per_launch": dom["exec_flops"] / dom["launches"]}
-                out["roofline"]["note"] = ("achieved = algorithmic direct-conv flops / time; kernel = Winograd F(2x2,3x3) on "
-                                           "v_mfma_f32_32x32x2_f32, which issues 2.25x fewer multiplies: see mfma_issued")
+                               "flops_per_launch": ex_flops / dom["launches"],
+                               "algorithmic": {"tflops": round(tfl, 2), "frac_of_peak": round(tfl / PEAK[a.dtype], 4),
+                                               "flops_per_launch": dom["flops"] / dom["launches"],
+                                               "bytes_per_launch": dom["bytes"] / dom["launches"]},
+                               "note": ("achieved / frac = MFMA flops issued (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 issues "
+                                        "2.25x fewer multiplies than the direct 3x3 convolution it computes); algorithmic = direct-conv "
+                                        "flops over the same time") if dom["exec_flops"] and abs(dom["exec_flops"] - dom["flops"]) > 1e-6 * dom["flops"]
+                                       else "achieved = 2*M*N*K of the launches / their HIP-event time"}
         else:
             gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,

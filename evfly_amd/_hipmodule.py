@@ -67,33 +67,30 @@ class HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self.__dict__["_hip"] = None
-        self.__dict__["_hip_built_at"] = -1
+        self.__dict__["_hip_built_at"] = None
         self.__dict__["_epoch"] = 0
 
-    # ---- invalidation: anything that can change parameter values bumps this module's epoch; a
-    # handle is stale when the epoch sum over the module and its HipModule descendants moved (so
-    # `model.origunet.load_state_dict(...)`, evfly_ros/run.py:161, also invalidates `model`).
-    def _bump(self):
-        self.__dict__["_epoch"] += 1
-
-    def _epoch_sum(self):
-        return sum(m.__dict__["_epoch"] for m in self.modules() if isinstance(m, HipModule))
-
-    def _apply(self, fn, *a, **kw):
-        self._bump()
-        return super()._apply(fn, *a, **kw)
-
-    def load_state_dict(self, *a, **kw):
-        self._bump()
-        return super().load_state_dict(*a, **kw)
+    # ---- invalidation: the native handle holds a packed COPY of the weights, so it is stale whenever any parameter
+    # or buffer of this module tree changed. Overriding entry points (load_state_dict, _apply) is not enough:
+    # `parent.load_state_dict(ckpt)` recurses through `_load_from_state_dict` and never calls the children's
+    # `load_state_dict`, and `optimizer.step()` / `p.copy_()` / `p.data = ...` touch no module method at all. The handle
+    # is therefore keyed by a fingerprint of every tensor: (storage pointer, autograd version counter) -- in-place
+    # writes bump the version, re-assignment / `.to()` changes the pointer -- plus the compute dtype and an explicit
+    # epoch for writes torch cannot see (`refresh_weights()`).
+    def _fingerprint(self):
+        fp = [self.compute_dtype, self.__dict__["_epoch"]]
+        for t in self.parameters():
+            fp.append(t.data_ptr()); fp.append(t._version)
+        for t in self.buffers():
+            fp.append(t.data_ptr()); fp.append(t._version)
+        return hash(tuple(fp))
 
     def refresh_weights(self):
-        """Call after mutating parameters in place."""
-        self._bump()
+        """Force a rebuild (only needed after writes that bypass torch, e.g. through a raw pointer)."""
+        self.__dict__["_epoch"] += 1
 
     def set_compute_dtype(self, name):
         self.compute_dtype = {"f32": 0, "fp32": 0, "bf16": 1, "bf16x3": 2}[name]
-        self._bump()
         return self
 
     # ---- subclasses provide the config + key prefixing
@@ -105,11 +102,11 @@ class HipModule(nn.Module):
 
     def hip(self):
         h = self.__dict__["_hip"]
-        e = self._epoch_sum()
-        if h is None or self.__dict__["_hip_built_at"] != e:
+        fp = self._fingerprint()
+        if h is None or self.__dict__["_hip_built_at"] != fp:
             h = HipHandle(self._hip_config(), self._hip_state_dict())
             self.__dict__["_hip"] = h
-            self.__dict__["_hip_built_at"] = e
+            self.__dict__["_hip_built_at"] = fp
         return h
 
 

@@ -32,11 +32,13 @@ int fail(int code, const char *fmt, ...);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// ---- per-device growable scratch for the stateless entry points (voxelizer, accumulators,
-// conditioning). Growth frees + reallocates (hipFree synchronises, so no kernel still uses the
-// old block). Model handles own their own arenas.
-// slot 0: entry-point scratch; slot 1: split-K partial sums of the GEMM launcher (may be live together)
-int scratch_get(size_t bytes, void **out, int slot = 0);
+// ---- growable scratch for the stateless entry points (voxelizer, accumulators, conditioning, op_conv2d) and the
+// split-K slab of the GEMM launcher, keyed by (device, STREAM, slot): work queued on different streams (two model
+// handles, or a handle next to a stateless call) never shares a block, work on one stream is ordered by the stream.
+// Growth frees + reallocates (hipFree synchronises, so no kernel still uses the old block). Model handles own their
+// own arenas. slot 0: entry-point scratch; slot 1: split-K partial sums; slot 2: transformed weights of op_conv2d
+// (slots may be live together on one stream).
+int scratch_get(size_t bytes, void **out, hipStream_t stream, int slot = 0);
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -3,6 +3,7 @@
 
 #include <map>
 #include <mutex>
+#include <tuple>
 
 namespace evfly {
 
@@ -26,15 +27,15 @@ struct Scratch {
     void *ptr = nullptr;
     size_t cap = 0;
 };
-std::map<std::pair<int, int>, Scratch> g_scratch;   // (device, slot)
+std::map<std::tuple<int, hipStream_t, int>, Scratch> g_scratch;   // (device, stream, slot)
 std::mutex g_scratch_mu;
 }  // namespace
 
-int scratch_get(size_t bytes, void **out, int slot) {
+int scratch_get(size_t bytes, void **out, hipStream_t stream, int slot) {
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    Scratch &s = g_scratch[{dev, slot}];
+    Scratch &s = g_scratch[std::make_tuple(dev, stream, slot)];
     if (s.cap < bytes) {
         if (s.ptr) EVFLY_HIP(hipFree(s.ptr));
         s.ptr = nullptr;

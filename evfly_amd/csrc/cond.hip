@@ -192,7 +192,7 @@ extern "C" int evfly_difflog_events(const float *im, const float *prev_im, int n
     EVFLY_REQUIRE(pos_thresh > 0.f && neg_thresh > 0.f, "difflog_events: thresholds must be positive");
     hipStream_t st = as_stream(stream);
     void *mb = nullptr;
-    if (int rc = scratch_get((size_t)n * 4, &mb, 0)) return rc;
+    if (int rc = scratch_get((size_t)n * 4, &mb, st, 0)) return rc;
     EVFLY_HIP(hipMemsetAsync(mb, 0, (size_t)n * 4, st));
     const int64_t npix = (int64_t)height * width;
     const unsigned gx = (unsigned)std::min<int64_t>((npix + 255) / 256, 1024);

@@ -615,7 +615,7 @@ int launch_cfg(const ConvDesc &d, hipStream_t st) {
     float *slab = nullptr;
     if (splits > 1) {
         void *scr = nullptr;
-        if (int rc = scratch_get((size_t)splits * d.M * d.Nc * sizeof(float), &scr, 1)) return rc;
+        if (int rc = scratch_get((size_t)splits * d.M * d.Nc * sizeof(float), &scr, st, 1)) return rc;
         slab = static_cast<float *>(scr);
     }
     hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt, splits), dim3(256), lds, st, d, n_mt, n_nt, cpx, dbg, splits, slab);

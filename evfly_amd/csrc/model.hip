@@ -491,7 +491,7 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     if (wino_applicable(d) && m->has(wname + ".u")) {          // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
         d.y_pool = y_pool;                                     // nn.MaxPool2d(2,2): one window per Winograd tile
         if (pool_fused) *pool_fused = y_pool != nullptr;
-        m->next_exec = wino_exec_flops(d);
+        if (!m->planning && m->profiling) m->next_exec = wino_exec_flops(d);   // only a profiled launch consumes it
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;
     }
@@ -1072,14 +1072,14 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
     EVFLY_REQUIRE(d.K % 32 == 0, "op_conv2d: kh*kw*cin must be a multiple of 32 (weights are [cout][kh][kw][cin] unpadded)");
     if (cin % 32 == 0 && kh * kw > 1) {   // the kernel walks K chunk-major (igemm.h conv_k_index): permute a copy
         void *scr = nullptr;
-        if (int rc = scratch_get((size_t)cout * d.K * 4, &scr)) return rc;
+        if (int rc = scratch_get((size_t)cout * d.K * 4, &scr, as_stream(stream))) return rc;
         if (int rc = launch_repack_chunk_major(w_packed, cout, kh * kw, cin, static_cast<float *>(scr), as_stream(stream))) return rc;
         d.w = static_cast<const float *>(scr);
     }
     d.ldw = d.K; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
     if (wino_applicable(d) && !(getenv("EVFLY_WINO_OP") && atoi(getenv("EVFLY_WINO_OP")) == 0)) {
         void *u = nullptr;
-        if (int rc = scratch_get(wino_u_floats(cout, cin) * 4, &u, 2)) return rc;
+        if (int rc = scratch_get(wino_u_floats(cout, cin) * 4, &u, as_stream(stream), 2)) return rc;
         if (int rc = wino_pack_device(w_packed, cout, cin, (int64_t)9 * cin, 1, cin, static_cast<float *>(u), as_stream(stream))) return rc;
         return wino_launch(d, static_cast<const float *>(u), as_stream(stream));
     }

@@ -405,7 +405,7 @@ extern "C" int evfly_voxelize_windows(const uint16_t *x, const uint16_t *y, cons
     // scratch: starts[n_streams*(T+1)] i64 | unsorted[n_streams] i32
     void *scr = nullptr;
     const size_t starts_bytes = align_up((size_t)n_streams * (n_windows + 1) * 8, 256);
-    if (int rc = scratch_get(starts_bytes + align_up((size_t)n_streams * 4, 256), &scr)) return rc;
+    if (int rc = scratch_get(starts_bytes + align_up((size_t)n_streams * 4, 256), &scr, st)) return rc;
     int64_t *starts = (int64_t *)scr;
     int *unsorted = (int *)((char *)scr + starts_bytes);
     EVFLY_HIP(hipMemsetAsync(unsorted, 0, (size_t)n_streams * 4, st));
@@ -459,7 +459,7 @@ extern "C" int evfly_eventframe_rows_f64(const double *rows, int64_t n, int heig
     void *scr = nullptr;
     const size_t counts_bytes = align_up((size_t)2 * hw * 4, 256);
     const size_t blk_bytes = align_up((size_t)n_blocks * 4, 256);
-    if (int rc = scratch_get(counts_bytes + blk_bytes + 256, &scr)) return rc;
+    if (int rc = scratch_get(counts_bytes + blk_bytes + 256, &scr, st)) return rc;
     int32_t *counts = counts_i32 ? counts_i32 : (int32_t *)scr;
     unsigned *blk = (unsigned *)((char *)scr + counts_bytes);
     unsigned long long *total = (unsigned long long *)((char *)scr + counts_bytes + blk_bytes);
@@ -501,7 +501,7 @@ extern "C" int evfly_accumulate_u8(const uint16_t *x, const uint16_t *y, const u
     const int n_pix = width * height;
     void *scr = nullptr;
     const size_t plane = align_up((size_t)n_pix * 4, 256);
-    if (int rc = scratch_get(3 * plane + 256, &scr)) return rc;
+    if (int rc = scratch_get(3 * plane + 256, &scr, st)) return rc;
     unsigned *on = (unsigned *)scr, *off = (unsigned *)((char *)scr + plane);
     int *hot_list = (int *)((char *)scr + 2 * plane);
     int *hot_count = (int *)((char *)scr + 3 * plane);

@@ -66,7 +66,6 @@ struct WinoGeom {
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
     double cost;                // plan cost (launched tile slots + weighted patch pixels)
-    int stagger;                // persistent kernel: start delay of the second half of the grid, units of 4096 cycles
 };
 
 // Opaque identity: stops hipcc from hoisting the per-step address XORs out of the chunk loop (LICM would turn six
@@ -423,380 +422,6 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------- persistent kernel
-// Same tile program as k_wino9, as a work loop: a block walks the (patch tile, 32-channel slice) items of its XCD with
-// stride `lstride`, and the stage sequence (item, chunk) never drains:
-//   * the DMA of the NEXT stage -- the item's next chunk, or chunk 0 of the NEXT ITEM -- is issued right behind the
-//     barrier that opens a stage, so an item never waits for its first patch (in k_wino9 every block starts with a cold
-//     DMA round trip: 8-19 % of the layer time in the ablations);
-//   * the last half-step of an item refills the U registers from the next item's stream;
-//   * the epilogue borrows the patch buffer the item's last chunk has just vacated (the other buffer is receiving the
-//     next item); its global stores (always NST per wave: masked lanes are out-of-range buffer stores, not branches)
-//     retire under the next item's MFMAs instead of holding a finished block's slot (4-12 %);
-//   * per-block setup (lane constants, fragment offsets) is paid once per block instead of once per item.
-// Queue arithmetic on top of k_wino9's: the NST stores are younger than the four U refills of the item's last half-step
-// and older than everything the next stage issues, so the stage barrier behind an epilogue keeps 4 + NST operations in
-// flight and its first half-step waits with 3 + ND + NST.
-constexpr int NST = 5;      // epilogue stores per wave: 4 x 16 B of the tile + 1 x 16 B of the fused max-pool
-
-// lane id recomputed from the exec mask, opaque to CSE / hoisting: index arithmetic that is only needed between items must
-// not keep registers alive across the MFMA loop (the kernel sits at the 128-register cap)
-__device__ __forceinline__ int lane_now() {
-    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
-    return l;
-}
-
-template <int K0, int K1>   // vmcnt(K1) if flag else vmcnt(K0)
-__device__ __forceinline__ void u_wait_sel(f32x2 &b, int flag) {
-    asm volatile("s_cmp_lg_u32 %1, 0\n\ts_cbranch_scc1 .Lws1_%=\n\ts_waitcnt vmcnt(%2)\n\ts_branch .Lws2_%=\n.Lws1_%=:\n\ts_waitcnt vmcnt(%3)\n.Lws2_%=:"
-                 : "+v"(b) : "s"(flag), "n"(K0), "n"(K1) : "scc");
-}
-template <int K0, int K1>
-__device__ __forceinline__ void stage_barrier_sel(int flag) {
-    asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 .Lbs1_%=\n\ts_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_branch .Lbs2_%=\n.Lbs1_%=:\n\ts_waitcnt vmcnt(%2) lgkmcnt(0)\n.Lbs2_%=:\n\ts_barrier"
-                 ::"s"(flag), "n"(K0), "n"(K1) : "memory", "scc");
-}
-// workgroup barrier for LDS hand-offs inside the epilogue: LDS operations only, the vector-memory queue keeps flying
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-template <int MT, int ND>
-__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 : 3, MT == 2 ? 4 : 3))) void k_wino10(ConvDesc d, const float *__restrict__ U, WinoGeom g, int lstride) {
-    constexpr int NW = 4 * MT, NTHR = 256 * MT;
-    constexpr int BUF_FLOATS = ND * NW * 256;             // one patch buffer: ND * NW pieces of 1 KiB
-    constexpr bool PREFETCH = MT == 1;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int xcd = blockIdx.x % kNumXCD, l0 = blockIdx.x / kNumXCD;
-    const int nitems = min(g.cpx, g.n_btiles - xcd * g.cpx) * g.n_nt;       // items of this XCD (may be <= 0)
-    if (l0 >= nitems) return;
-    const int my_items = (nitems - l0 + lstride - 1) / lstride;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs
-    const int mt = MT == 2 ? (wv & 1) : 0, a = MT == 2 ? (wv >> 1) : wv;
-    const int fm = lane & 31, fh = lane >> 5;
-    const int per = g.TY * g.TX;
-    const int nchunks = d.C / 32;
-
-    // B^T row a: t = d[rA] + sg * d[rB]   (a = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
-    const int rA = a == 0 ? 0 : a == 2 ? 2 : 1, rB = a == 3 ? 3 : a == 2 ? 1 : 2;
-    const float sg = a == 1 ? 1.f : -1.f;
-    int off0[2][2];
-    {
-        int t = mt * 32 + fm;
-        if (t >= g.ntiles) t = 0;
-        const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int py = 2 * ty + (r == 0 ? rA : rB), pxh = tx + c;
-                const int pp = (im * g.PH + py) * (g.PW >> 1) + pxh;
-                const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
-                off0[r][c] = pp * 256 + ((fh ^ key) << 4);
-            }
-    }
-
-    // ---- items (all wave-uniform)
-    struct Item { int img0, ty0, tx0, nt; };
-    auto decode = [&](int i) {
-        const int bt = xcd * g.cpx + i / g.n_nt;
-        Item it;
-        it.nt = i % g.n_nt;
-        it.tx0 = (bt % g.bx) * g.TX;
-        it.ty0 = ((bt / g.bx) % g.by) * g.TY;
-        it.img0 = (bt / (g.bx * g.by)) * g.IMGS;
-        return it;
-    };
-    // patch DMA of an item: descriptor over its images + per-lane byte offsets of this wave's ND pieces. MT = 1 (168
-    // registers) keeps the offsets of the item being loaded; MT = 2 (128 registers: they would be spilled, and every reload
-    // drains the queue) recomputes them at each stage top, where the fragment registers are dead.
-    constexpr bool KEEP_VOFF = MT == 1;
-    i32x4 srd = {0, 0, 0, 0x00020000};
-    unsigned voff[KEEP_VOFF ? ND : 1];
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;        // LDS byte address of buffer 0
-    auto piece_off = [&](const Item &it, int i, int ln) -> unsigned {
-        const int pl = ln >> 4, sp = ln & 15;
-        const int pp = (wv + i * NW) * 4 + pl;
-        const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
-        const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
-        const int sl = sp ^ ((pxh + (py >> 1) * g.TX + im * per) & 15);
-        const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
-        const int iy = 2 * it.ty0 + py, ix = 2 * it.tx0 + px;
-        const bool ok = 2 * pp < g.npix && it.img0 + im < d.NI && iy < d.H && ix < d.W;
-        return ok ? (unsigned)(((im * d.H + iy) * d.W + ix) * (int)d.ldx * 4 + ch * 16) : 0x7ffffff0u;   // out of range: zeros
-    };
-    auto set_load_item = [&](const Item &it) {
-        const int nimg = min(g.IMGS, d.NI - it.img0);
-        const uint64_t xb = (uint64_t)(uintptr_t)(d.x + (int64_t)it.img0 * d.H * d.W * d.ldx);
-        srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
-        srd[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
-        srd[2] = __builtin_amdgcn_readfirstlane((int)((int64_t)nimg * d.H * d.W * d.ldx * 4));
-        if constexpr (KEEP_VOFF) {
-            const int ln = lane_now();
-#pragma unroll
-            for (int i = 0; i < ND; ++i) voff[i] = piece_off(it, i, ln);
-        }
-    };
-    // `it`: the item set_load_item was last called with. `live` false: ND all-out-of-range pieces (zeros into an idle buffer)
-    // keep the queue arithmetic branch-free
-    auto dma = [&](const Item &it, int buf, int cc, bool live) {
-        if constexpr (kAbl & 1) return;
-        const unsigned dst = lds0 + (unsigned)(buf * BUF_FLOATS * 4) + (unsigned)wv * 1024u;
-        const int ln = KEEP_VOFF ? 0 : lane_now();
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            unsigned v;
-            if constexpr (KEEP_VOFF) v = voff[i];
-            else v = piece_off(it, i, ln);
-            dma_piece(live ? v : 0x7ffffff0u, srd, __builtin_amdgcn_readfirstlane(cc * 128),
-                      __builtin_amdgcn_readfirstlane(dst + (unsigned)(i * NW) * 1024u));
-        }
-    };
-    // U stream of an item: [nt][cc][j][hg][pos 16][lane 64][2]; this wave reads pos 4a .. 4a+3: 512 B apart, 8 KiB per half-step
-    auto u_base = [&](int nt) { return U + (((int64_t)nt * nchunks * 8 * 16 + 4 * a) * 64) * 2; };
-    const unsigned ulane = lane * 8;
-    f32x2 bcur[4] = {};
-    f32x16 acc[4];
-    float4 fu[4], fv[4], t[4];
-
-    auto read_frag = [&](const char *cur, int j) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int x = (j << 5) | ((c & 1) << 7);
-            if constexpr (kAbl & 8) { fu[c] = make_float4(1.f, 2.f, 3.f, (float)lane); fv[c] = fu[c]; }
-            else {
-                fu[c] = *reinterpret_cast<const float4 *>(cur + (opaque(off0[0][c >> 1]) ^ x));
-                fv[c] = *reinterpret_cast<const float4 *>(cur + (opaque(off0[1][c >> 1]) ^ x));
-            }
-        }
-    };
-    auto combine = [&]() {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            t[c] = make_float4(fmaf(sg, fv[c].x, fu[c].x), fmaf(sg, fv[c].y, fu[c].y), fmaf(sg, fv[c].z, fu[c].z), fmaf(sg, fv[c].w, fu[c].w));
-    };
-    // one half-step (8 MFMAs). FIRST: the stage's DMA pieces (and, behind an epilogue, its NST stores) are younger than
-    // bcur's loads. `src`: where the refills come from.
-    auto half_step = [&](auto first, int hg, int after_epi, const float *src) {
-        constexpr bool FIRST = decltype(first)::value;
-        constexpr int KD = (kAbl & 1) ? 0 : ND;
-        const int e = 2 * hg;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float va, vb;
-            if (p == 0)      { va = f4e(t[0], e) - f4e(t[2], e); vb = f4e(t[0], e + 1) - f4e(t[2], e + 1); }
-            else if (p == 1) { va = f4e(t[1], e) + f4e(t[2], e); vb = f4e(t[1], e + 1) + f4e(t[2], e + 1); }
-            else if (p == 2) { va = f4e(t[2], e) - f4e(t[1], e); vb = f4e(t[2], e + 1) - f4e(t[1], e + 1); }
-            else             { va = f4e(t[1], e) - f4e(t[3], e); vb = f4e(t[1], e + 1) - f4e(t[3], e + 1); }
-            if constexpr (FIRST) u_wait_sel<3 + KD, 3 + KD + NST>(bcur[p], after_epi);
-            else u_wait<3>(bcur[p]);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, bcur[p].x, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, bcur[p].y, acc[p], 0, 0, 0);
-            if (p == 0) u_load<0>(bcur[0], ulane, src);
-            else if (p == 1) u_load<512>(bcur[1], ulane, src);
-            else if (p == 2) u_load<1024>(bcur[2], ulane, src);
-            else u_load<1536>(bcur[3], ulane, src);
-        }
-    };
-
-    // ---- stagger: the CU's blocks would otherwise run their MFMA phases and their epilogues in lockstep (they start
-    // together and every item takes the same time), leaving the matrix pipe idle during the common epilogue. The second
-    // half of the grid (the blocks that arrive on already-occupied CUs) starts half an item late.
-    if (g.stagger > 0 && l0 >= (lstride + 1) / 2)
-        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(64);      // 64 x 64 cycles each
-    // ---- prologue: first item's first chunk and first U registers
-    Item cur = decode(l0);
-    set_load_item(cur);
-    dma(cur, 0, 0, true);
-    const float *ub = u_base(cur.nt);
-    u_load<0>(bcur[0], ulane, ub); u_load<512>(bcur[1], ulane, ub); u_load<1024>(bcur[2], ulane, ub); u_load<1536>(bcur[3], ulane, ub);
-    ub += 16 * 64 * 2;
-
-    int stage = 0, after_epi = 0;
-    for (int k = 0; k < my_items; ++k) {
-        const bool has_next = k + 1 < my_items;
-        const Item nxt = decode(has_next ? l0 + (k + 1) * lstride : l0);
-        const float *ubn = u_base(nxt.nt);
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-
-        for (int cc = 0; cc < nchunks; ++cc, ++stage) {
-            stage_barrier_sel<4, 4 + NST>(after_epi);       // this stage's patch has landed; everyone is done with the other buffer
-            const char *curb = reinterpret_cast<const char *>(smem + (stage & 1) * BUF_FLOATS);
-            const bool last = cc + 1 == nchunks;
-            if (!last) dma(cur, (stage + 1) & 1, cc + 1, true);
-            else {
-                if (has_next) set_load_item(nxt);
-                dma(nxt, (stage + 1) & 1, 0, has_next);
-            }
-            read_frag(curb, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                combine();
-                if (j == 0) half_step(std::true_type{}, 0, after_epi, ub);
-                else half_step(std::false_type{}, 0, 0, ub);
-                ub += 16 * 64 * 2;
-                if constexpr (PREFETCH) { if (j < 3) read_frag(curb, j + 1); }      // next quarter's fragments fly under the second half-step
-                // the item's very last refill comes from the next item's stream
-                half_step(std::false_type{}, 1, 0, (j == 3 && last && has_next) ? ubn : ub);
-                ub += 16 * 64 * 2;
-                if constexpr (!PREFETCH) { if (j < 3) read_frag(curb, j + 1); }
-            }
-            after_epi = 0;
-        }
-        if (has_next) ub = ubn + 16 * 64 * 2;
-
-        // ---- epilogue of item `cur` in the buffer its last chunk vacated (the other one is receiving the next item)
-        float *eb = smem + ((stage - 1) & 1) * BUF_FLOATS;
-        const int img0 = cur.img0, ty0 = cur.ty0, tx0 = cur.tx0, n0 = cur.nt * 32;
-        // The next item's first U registers (and its first patch) have had the item's last half-step to land: wait for them
-        // here, in front of a barrier that waits for the slowest wave anyway. From here to the next stage barrier the queue
-        // holds nothing the compiler does not know about, so it may spill / move bcur freely across the epilogue.
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3]));
-        lds_barrier();               // every wave is done reading the patch
-        // Output transform. Lane-local along b: s0 = M_a0 + M_a1 + M_a2, s1 = M_a1 - M_a2 - M_a3. Along a the four waves of
-        // an M-tile trade through LDS; wave a owns output pixel (i, x) = (a >> 1, a & 1) of every tile:
-        //   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
-        // sets: k0 = s_01 (from a=0), k1 = s_10, k2 = s_11 (a=1), k3 = s_20, k4 = s_21 (a=2), k5 = s_30 (a=3); wave a adds
-        // (kA, kB) = (1,3), (0,4), (1,5), (2,4): y = (own + kA) + sB * kB. MT = 1: all six sets at once (24 KB). MT = 2 (48 KB
-        // of sets, 40 KB buffer): round 1 = k0, k1, k2, k4 in slots 0..3 (every wave's first addend, both addends of a = 1, 3),
-        // round 2 = k3, k5 in slots 0, 1 (second addend of a = 0, 2).
-        float4 *xch = reinterpret_cast<float4 *>(eb);
-        constexpr int NSLOT = MT == 1 ? 6 : 4;
-        const int lx = lane_now();
-        auto at4 = [&](int slot, int q) -> float4 & { return xch[((mt * NSLOT + slot) * 4 + q) * 64 + lx]; };
-        float own[16];
-        float4 keep[4];              // MT = 2: the set that travels in round 2 (a = 2: k3 = s0, a = 3: k5 = s0)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float s0[4], s1[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * q + i;
-                s0[i] = acc[0][r] + acc[1][r] + acc[2][r];
-                s1[i] = acc[1][r] - acc[2][r] - acc[3][r];
-            }
-            const float4 v0 = make_float4(s0[0], s0[1], s0[2], s0[3]), v1 = make_float4(s1[0], s1[1], s1[2], s1[3]);
-            if constexpr (MT == 1) {
-                if (a == 0) at4(0, q) = v1;
-                else if (a == 1) { at4(1, q) = v0; at4(2, q) = v1; }
-                else if (a == 2) { at4(3, q) = v0; at4(4, q) = v1; }
-                else at4(5, q) = v0;
-            } else {    // slots: k0 -> 0, k1 -> 1, k2 -> 2, k4 -> 3
-                if (a == 0) at4(0, q) = v1;
-                else if (a == 1) { at4(1, q) = v0; at4(2, q) = v1; }
-                else if (a == 2) { keep[q] = v0; at4(3, q) = v1; }
-                else keep[q] = v0;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) own[4 * q + i] = a == 0 ? s0[i] : a == 1 ? s1[i] : a == 2 ? -s0[i] : -s1[i];
-        }
-        lds_barrier();
-        const float sB = a < 2 ? 1.f : -1.f;
-        if constexpr (MT == 1) {
-            const int kA = a == 0 ? 1 : a == 1 ? 0 : a == 2 ? 1 : 2, kB = a == 0 ? 3 : a == 1 ? 4 : a == 2 ? 5 : 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 pa = at4(kA, q), pb = at4(kB, q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) own[4 * q + i] = own[4 * q + i] + f4e(pa, i) + sB * f4e(pb, i);
-            }
-        } else {
-            // round 1: first addend kA = k1, k0, k1, k2 (slots 1, 0, 1, 2); a = 1, 3 also their second one, k4 (slot 3)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 pa = at4(a == 1 ? 0 : a == 3 ? 2 : 1, q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) own[4 * q + i] += f4e(pa, i);
-                if (a & 1) {
-                    const float4 pb = at4(3, q);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) own[4 * q + i] += sB * f4e(pb, i);
-                }
-            }
-            lds_barrier();           // round 1 consumed
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (a == 2) at4(0, q) = keep[q];          // k3
-                else if (a == 3) at4(1, q) = keep[q];     // k5
-            }
-            lds_barrier();
-            // round 2: a = 0: + k3 (slot 0); a = 2: - k5 (slot 1)
-            if (!(a & 1)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 pb = at4(a == 0 ? 0 : 1, q);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) own[4 * q + i] += sB * f4e(pb, i);
-                }
-            }
-        }
-        lds_barrier();               // the sets are consumed: the transposed tile may overwrite them
-        // finished pixels go to LDS as [tile][pixel 4][channel 32] so that the global stores are 16-B vectors
-        float *ot = eb;
-        const int lo = lane_now(), fmo = lo & 31, fho = lo >> 5;
-        const bool nokl = n0 + fmo < d.Nc;
-        const float bias = (d.bias && nokl) ? d.bias[n0 + fmo] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fho;
-            const float y = own[r] + bias;
-            ot[(tl * 4 + a) * 32 + fmo] = apply_act(y, d.act);
-        }
-        lds_barrier();
-        {
-            // 16-B stores through a descriptor over the item's images: masked lanes are out of range (dropped), so every
-            // wave issues exactly NST store instructions
-            const int nimg = min(g.IMGS, d.NI - img0);
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-                d.y + (int64_t)img0 * d.OH * d.OW * d.ldy, 0, (int)((int64_t)nimg * d.OH * d.OW * d.ldy * 4), 0x00020000);
-            // (opaque: the item-invariant index arithmetic below must not be hoisted out of the item loop -- it would live in
-            // ~30 registers across the MFMA loop and spill)
-            const int te = wv * 64 + lane_now();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = te + q * NTHR, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
-                const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-                const int oy = 2 * (ty0 + ty) + (pix >> 1), ox = 2 * (tx0 + tx) + (pix & 1), n = n0 + c4 * 4;
-                const bool ok = tl < g.ntiles && img0 + im < d.NI && oy < d.OH && ox < d.OW && n < d.Nc && !(kAbl & 4);
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(ot + pl * 32 + c4 * 4);
-                const unsigned off = ok ? (unsigned)((((im * d.OH + oy) * d.OW + ox) * (int)d.ldy + n) * 4) : 0x7ffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b128(v, ry, off, 0, 0);
-            }
-            // fused nn.MaxPool2d(2, 2): the window is the Winograd tile; NaN wins like in torch. No pooled output: the same
-            // store instruction with every lane out of range.
-            const int PHo = d.OH / 2, PWo = d.OW / 2;
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-                d.y_pool ? d.y_pool + (int64_t)img0 * PHo * PWo * d.Nc : d.y, 0, d.y_pool ? (int)((int64_t)nimg * PHo * PWo * d.Nc * 4) : 0, 0x00020000);
-            const int c4 = te & 7, tl = te >> 3;
-            const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
-            const int gy = ty0 + ty, gx = tx0 + tx, n = n0 + c4 * 4;
-            const bool ok = d.y_pool && tl < g.ntiles && img0 + im < d.NI && gy < PHo && gx < PWo && n < d.Nc && !(kAbl & 4);
-            const float4 p0 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 0) * 32 + c4 * 4);
-            const float4 p1 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 1) * 32 + c4 * 4);
-            const float4 p2 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 2) * 32 + c4 * 4);
-            const float4 p3 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 3) * 32 + c4 * 4);
-#define MX(p, q) ((p) > (q) || (p) != (p) ? (p) : (q))
-            const float4 v = make_float4(MX(MX(p0.x, p1.x), MX(p2.x, p3.x)), MX(MX(p0.y, p1.y), MX(p2.y, p3.y)),
-                                         MX(MX(p0.z, p1.z), MX(p2.z, p3.z)), MX(MX(p0.w, p1.w), MX(p2.w, p3.w)));
-#undef MX
-            const unsigned off = ok ? (unsigned)((((im * PHo + gy) * PWo + gx) * d.Nc + n) * 4) : 0x7ffffff0u;
-            u32x4 vu;
-            vu[0] = __float_as_uint(v.x); vu[1] = __float_as_uint(v.y); vu[2] = __float_as_uint(v.z); vu[3] = __float_as_uint(v.w);
-            __builtin_amdgcn_raw_buffer_store_b128(vu, rp, off, 0, 0);
-        }
-        after_epi = 1;
-        cur = nxt;
-    }
-    // drain the slack refills before their registers die (the stores may still be flying; nothing reads them)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3]));
-}
-
 // ---------------------------------------------------------------------------------------------------- weights
 // U_ab = (G g G^T)[a][b], G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]; evaluated in double, rounded once.
 __host__ __device__ inline void wino_u16(const float g[9], float u[16]) {
@@ -860,7 +485,6 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
     g.n_nt = cdiv(d.Nc, 32);
     g.n_btiles = g.bx * g.by * g.bi;
     g.cpx = cdiv(g.n_btiles, kNumXCD);
-    g.stagger = 0;
     g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
     return true;
 }
@@ -968,34 +592,6 @@ int launch(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st)
     return 0;
 }
 
-// persistent work loop: one block per CU slot (two of 512 threads or three of 256), items strided per XCD
-template <int MT, int ND>
-int launch_persistent(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
-    const WinoGeom &g = p.g;
-    const int lds = 2 * ND * 4 * MT * 1024;
-    const int lstride = (kNumCU / kNumXCD) * (MT == 2 ? 2 : 3);
-    auto kern = k_wino10<MT, ND>;
-    static bool lds_set = false;
-    if (!lds_set) {
-        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        lds_set = true;
-    }
-    static const bool dbg = getenv("EVFLY_WINO_DBG") != nullptr;
-    if (dbg) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256 * MT, lds);
-        fprintf(stderr, "wino10<%d,%d>: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d items, %d B LDS, %d blocks/CU\n", MT, ND,
-                d.NI, d.OH, d.OW, d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles * g.n_nt, lds, nb);
-    }
-    const int per_xcd = std::min(lstride, g.cpx * g.n_nt);
-    WinoGeom gg = g;
-    static const int stg = getenv("EVFLY_WINO_STAGGER") ? atoi(getenv("EVFLY_WINO_STAGGER")) : 1;
-    gg.stagger = stg * (d.C / 32);     // ~ half an item: an item is C/32 chunks of 64 MFMAs per wave (>= 8192 cycles of a shared pipe)
-    hipLaunchKernelGGL(kern, dim3(kNumXCD * per_xcd), dim3(256 * MT), lds, st, d, U, gg, per_xcd);
-    EVFLY_LAUNCH_CHECK();
-    return 0;
-}
-
 }  // namespace
 
 double wino_efficiency(const ConvDesc &d) { return cached_plan(d).efficiency; }
@@ -1009,12 +605,6 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
                   "wino: the fused first-conv producer needs C == 32 and 1 or 2 frame channels");
-    // the persistent kernel stores 16-B vectors through buffer descriptors over a block's (<= 4) images
-    static const int persist = getenv("EVFLY_WINO_PERSIST") ? atoi(getenv("EVFLY_WINO_PERSIST")) : 1;
-    const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0 && (!d.y_pool || (((uintptr_t)d.y_pool) & 15) == 0) &&
-                     (int64_t)4 * d.OH * d.OW * d.ldy * 4 < ((int64_t)1 << 31);
-    if (persist && !d.pre_frames && vec)
-        return p.c.MT == 2 ? launch_persistent<2, 5>(d, U, p, st) : launch_persistent<1, 6>(d, U, p, st);
     const bool one = d.C == 32;
     if (p.c.MT == 2) return one ? launch<2, 5, true>(d, U, p, st) : launch<2, 5, false>(d, U, p, st);
     return one ? launch<1, 6, true>(d, U, p, st) : launch<1, 6, false>(d, U, p, st);

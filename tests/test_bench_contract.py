@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r1f_bench.json, produced by `python bench.py` on the MI355X box) carries every
+"""The committed bench line (profiles/r2_bench.json, produced by `python bench.py` on the MI355X box) carries every
 field of the bench contract; guards against a refactor of bench.py dropping one."""
 import json
 import os
@@ -7,7 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    b = json.load(open(os.path.join(REPO, "profiles", "r1f_bench.json")))
+    b = json.load(open(os.path.join(REPO, "profiles", "r2_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in b, k
@@ -18,7 +18,8 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert 0 < r["mfma_issued"]["frac"] < 1 and r["mfma_issued"]["tflops"] < r["achieved"]     # Winograd: issued < algorithmic
+    # `achieved` / `frac` count the flops the matrix cores issue; the direct-conv (algorithmic) rate sits beside them
+    assert 0 < r["frac"] < 1 and r["algorithmic"]["tflops"] > r["achieved"]                     # Winograd: issued < algorithmic
     c = b["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

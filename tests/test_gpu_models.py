@@ -300,6 +300,32 @@ def test_composite_checkpoint_loading_paths(gpu_device):
     assert torch.equal(v0, v2)
 
 
+def test_handle_invalidation_parent_load_and_inplace_updates(gpu_device):
+    """The native handle packs a copy of the weights: a PARENT-level load_state_dict (nn.Module recurses through
+    _load_from_state_dict, never through the children's load_state_dict) must refresh a child's handle that was built
+    earlier, and so must in-place parameter writes (optimizer.step / p.copy_) and `.data` re-assignment."""
+    net, sd = _composite(gpu_device)
+    x = cond_frames(81, 1).to(gpu_device)
+    d0, _ = net.origunet([x.clone(), None, [None, None]])[1][:2]          # builds the CHILD handle
+    v0, _ = net([x.clone(), torch.tensor([[4.0]], device=gpu_device), [None, None], None])
+    net.load_state_dict({k: v * 1.01 for k, v in sd.items()})             # parent-level load
+    d1, _ = net.origunet([x.clone(), None, [None, None]])[1][:2]
+    assert not torch.equal(d0, d1), "child handle kept stale weights after parent.load_state_dict"
+    net.load_state_dict(sd)
+    d2, _ = net.origunet([x.clone(), None, [None, None]])[1][:2]
+    assert torch.equal(d0, d2)
+    with torch.no_grad():                                                   # in-place write, no module method involved
+        net.origunet.unet_e11.bias.add_(0.05)
+    d3, _ = net.origunet([x.clone(), None, [None, None]])[1][:2]
+    assert not torch.equal(d0, d3), "in-place parameter update was not picked up"
+    with torch.no_grad():
+        net.origunet.unet_e11.bias.sub_(0.05)
+    w = net.origunet.unet_out.weight
+    w.data = (w.data * 1.5)                                                 # storage re-assignment
+    d4, _ = net.origunet([x.clone(), None, [None, None]])[1][:2]
+    assert not torch.equal(d0, d4), ".data re-assignment was not picked up"
+
+
 def test_multi_stream_matches_per_stream_oracle(gpu_device):
     """The throughput entry (streams batched, batch-as-time inside each) == every stream run alone."""
     net, sd = _composite(gpu_device)
