@@ -14,7 +14,7 @@
 //   * V = B^T d B is formed IN REGISTERS from eight ds_read_b128 of the raw patch (one v_fma for the row
 //     combination, one v_add / v_sub per MFMA operand for the column combination);
 //   * U = G g G^T is precomputed at weight-pack time and streamed from L2 straight into the B-operand registers,
-//     8 B per lane, in exactly the order the waves consume it (one linear pointer, refilled right after use).
+//     16 B per lane, in exactly the order the waves consume it (one linear pointer, refilled right after use).
 // Wave w = (mt, a): M-tile mt x position row a x all four b: 4 accumulator tiles = 64 registers, 128 VGPRs in all.
 // The output transform is lane-local along b; along a the four waves of an M-tile trade partial sums through LDS,
 // then the finished tile is transposed through LDS for 16-B global stores. nn.MaxPool2d(2, 2) fuses trivially (a
@@ -26,10 +26,10 @@
 //   * patch DMA = ND x `buffer_load_dwordx4 ... lds` per wave and chunk through a buffer descriptor over the block's
 //     images (out-of-range lanes -- halo beyond the map, padded groups -- read zeros, no zero page, no branches);
 //     per-lane byte offsets are computed once per block, the chunk advances through the scalar offset;
-//   * U = `global_load_dwordx2` (scalar base + lane offset), four in flight per wave, each refilled right after the
-//     MFMAs that consumed it; the wait in front of a use is vmcnt(3) (or vmcnt(3 + ND) while the chunk's DMA pieces
-//     sit younger in the queue), never 0;
-//   * one barrier per chunk: `s_waitcnt vmcnt(4) lgkmcnt(0); s_barrier` -- the four U refills stay in flight across
+//   * U = `global_load_dwordx4` (scalar base + lane offset; the operand pairs of two adjacent positions), two in flight
+//     per wave, each refilled right after the four MFMAs that consumed it; the wait in front of a use is vmcnt(1) (or
+//     vmcnt(1 + ND) while the chunk's DMA pieces sit younger in the queue), never 0;
+//   * one barrier per chunk: `s_waitcnt vmcnt(2) lgkmcnt(0); s_barrier` -- the two U refills stay in flight across
 //     it; the DMA of chunk c+1 is issued right behind the barrier that opens chunk c (a whole chunk of MFMAs ahead).
 #include "igemm.h"
 
@@ -42,7 +42,7 @@
 #include <vector>
 
 // Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 no patch DMA,
-// 4 no global stores, 8 no LDS fragment reads, 16 no U loads. The shipped library is built with 0.
+// 4 no global stores, 8 no LDS fragment reads, 16 no U loads, 64 no chunk barrier. The shipped library is built with 0.
 #ifndef EVFLY_WINO_ABL
 #define EVFLY_WINO_ABL 0
 #endif
@@ -52,6 +52,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -73,33 +74,35 @@ struct WinoGeom {
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ float tq(const f32x4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
 // ---- hand-counted vector-memory queue (see the header). Every statement is `asm volatile`: program order among them
 // is the issue order the vmcnt arithmetic below assumes.
-// U refill: 8 B per lane from (scalar base + lane offset + OFF).
+// U refill: 16 B per lane -- the (k, k + 1) operand pairs of TWO adjacent positions -- from (scalar base + lane offset + OFF).
+// "+v": the refill lands in the SAME registers, so it is ordered behind the MFMAs that read the old values (with "=v" hipcc
+// renames the destination, hoists the load and doubles the registers).
 template <int OFF>
-__device__ __forceinline__ void u_load(f32x2 &dst, unsigned voff, const float *sbase) {
-    if constexpr (kAbl & 16) { dst = f32x2{1.f, 2.f}; return; }
-    // "+v": the refill lands in the SAME registers, so it is ordered behind the MFMAs that read the old pair (with "=v"
-    // hipcc renames the destination, hoists the load and keeps 16 registers for the four pairs instead of 8)
-    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
+__device__ __forceinline__ void u_load(f32x4 &dst, unsigned voff, const float *sbase) {
+    if constexpr (kAbl & 16) { dst = f32x4{1.f, 2.f, 3.f, 4.f}; return; }
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
 }
 // wait until at most N vector-memory operations younger than `b`'s load are outstanding; naming `b` read-write pins
 // every consumer of it below the wait
 template <int N>
-__device__ __forceinline__ void u_wait(f32x2 &b) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b) : "n"(N)); }
-// one 1-KiB LDS-DMA piece: lane l's 16 B land at lds_addr + 16 l; M0 (the LDS base of the DMA) is compiler-reserved,
-// so it is saved and restored inside the statement
+__device__ __forceinline__ void u_wait(f32x4 &b) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b) : "n"(N)); }
+// one 1-KiB LDS-DMA piece: lane l's 16 B land at lds_addr + 16 l. M0 holds the LDS base of the DMA; nothing else in this
+// translation unit uses M0 (gfx950 DS instructions do not need it; checked in the ISA: no other reference), so it is
+// simply overwritten
 __device__ __forceinline__ void dma_piece(unsigned voff, i32x4 srd, unsigned soff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
 // chunk barrier: this wave's DMA pieces of the chunk about to be read have landed (they are older than the NKEEP
 // U refills that stay in flight), its fragment reads of the buffer about to be overwritten have returned
 template <int NKEEP>
 __device__ __forceinline__ void chunk_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NKEEP) : "memory");
+    if constexpr (kAbl & 64) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NKEEP) : "memory");      // ablation: no workgroup barrier
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NKEEP) : "memory");
 }
 
 // input formation of learner_models.py:476-494 (identical to ops.hip form_value; kept local so the fused producer
@@ -185,10 +188,14 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
 template <int MT, int ND, bool ONE>
 __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 : 3, MT == 2 ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
     constexpr int NW = 4 * MT, NTHR = 256 * MT;
-    constexpr bool PREFETCH = MT == 1;
+#ifndef EVFLY_WINO_PF2
+#define EVFLY_WINO_PF2 0
+#endif
+    constexpr int PREFETCH = MT == 1 ? 1 : EVFLY_WINO_PF2;
     constexpr int BUF_FLOATS = ND * NW * 256;             // one patch buffer: ND * NW pieces of 1 KiB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)patch;        // LDS byte address of buffer 0
 
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
     const int bt = xcd * g.cpx + slot / g.n_nt, nt = slot % g.n_nt;
@@ -234,7 +241,6 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     // over the block's images, per-lane byte offsets of this wave's ND pieces.
     i32x4 srd = {0, 0, 0, 0};
     unsigned voff[ND] = {};
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)patch;        // LDS byte address of buffer 0
     bool produced = false;
     if constexpr (ONE) {
         if (d.pre_frames) {
@@ -275,74 +281,93 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
                       __builtin_amdgcn_readfirstlane(dst + (unsigned)(i * NW) * 1024u));
     };
 
-    // U stream: [nt][cc][j][hg][pos 16][lane 64][2]; this wave reads pos 4a .. 4a+3: 512 B apart, 8 KiB per half-step
-    const float *ub = U + (((int64_t)nt * nchunks * 8 * 16 + 4 * a) * 64) * 2;
-    const unsigned ulane = lane * 8;
-    f32x2 bcur[4] = {};
+    // U stream: [nt][cc][j][hg][pos pair 8][lane 64][pos 2][2]; this wave reads pairs 2a, 2a + 1 (positions 4a .. 4a+3):
+    // two 16-B loads 1 KiB apart per half-step, 8 KiB per half-step
+    const float *ub = U + (((int64_t)nt * nchunks * 8 * 8 + 2 * a) * 64) * 4;
+    const unsigned ulane = lane * 16;
+    f32x4 bcur[2] = {};
 
     if (!produced) dma(0, true);
-    u_load<0>(bcur[0], ulane, ub); u_load<512>(bcur[1], ulane, ub); u_load<1024>(bcur[2], ulane, ub); u_load<1536>(bcur[3], ulane, ub);
+    u_load<0>(bcur[0], ulane, ub); u_load<1024>(bcur[1], ulane, ub);
     ub += 16 * 64 * 2;
 
-    float4 fu[4], fv[4];          // raw fragment rows rA / rB of the four patch columns
-    auto read_frag = [&](const char *cur, int j) {
+    f32x4 fu[4], fv[4];           // raw fragment rows rA / rB of the four patch columns
+    // fragment addresses of the current chunk: off0 + buffer offset, passed through `opaque` ONCE per chunk (LICM would
+    // otherwise hoist the 32 XORed addresses out of the chunk loop and spill); the XOR with x touches bits 5..7 only, the
+    // buffer offset is a multiple of 8 KiB, so (off0 + buf) ^ x == (off0 ^ x) + buf: one v_xor per read
+    // (addresses are absolute LDS byte addresses and the reads go through address_space(3) pointers built from them:
+    // a generic `smem + offset` costs one more v_add per read)
+    typedef const __attribute__((address_space(3))) f32x4 lds_f4;
+    int ofr[2][2];
+    auto set_frag_base = [&](int buf_bytes) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) ofr[r][c] = opaque(off0[r][c] + buf_bytes + (int)lds0);
+    };
+    auto read_frag = [&](int j, int c0 = 0, int c1 = 4) {
+#pragma unroll
+        for (int c = c0; c < c1; ++c) {
             const int x = (j << 5) | ((c & 1) << 7);
-            if constexpr (kAbl & 8) { fu[c] = make_float4(1.f, 2.f, 3.f, (float)lane); fv[c] = fu[c]; }
+            if constexpr (kAbl & 8) { fu[c] = f32x4{1.f, 2.f, 3.f, (float)lane}; fv[c] = fu[c]; }
             else {
-                fu[c] = *reinterpret_cast<const float4 *>(cur + (opaque(off0[0][c >> 1]) ^ x));
-                fv[c] = *reinterpret_cast<const float4 *>(cur + (opaque(off0[1][c >> 1]) ^ x));
+                fu[c] = *(lds_f4 *)(uintptr_t)(unsigned)(ofr[0][c >> 1] ^ x);
+                fv[c] = *(lds_f4 *)(uintptr_t)(unsigned)(ofr[1][c >> 1] ^ x);
             }
         }
     };
-    float4 t[4];
+    f32x4 t[4];
     auto combine = [&]() {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            t[c] = make_float4(fmaf(sg, fv[c].x, fu[c].x), fmaf(sg, fv[c].y, fu[c].y), fmaf(sg, fv[c].z, fu[c].z), fmaf(sg, fv[c].w, fu[c].w));
+            t[c] = f32x4{fmaf(sg, fv[c].x, fu[c].x), fmaf(sg, fv[c].y, fu[c].y), fmaf(sg, fv[c].z, fu[c].z), fmaf(sg, fv[c].w, fu[c].w)};
     };
-    // one half-step: channel pair e, e + 1 of the four positions (8 MFMAs); KW = operations younger than bcur[p]'s load
+    // one half-step: channel pair e, e + 1 of the four positions (8 MFMAs); KW = operations younger than bcur[q]'s load
     auto half_step = [&](auto kw, int hg) {
         constexpr int KW = decltype(kw)::value;
         const int e = 2 * hg;
+        // column combinations of the four positions first (8 VALU), then the 8 MFMAs: no VALU -> MFMA operand wait states
+        float va[4], vb[4];
+        va[0] = tq(t[0], e) - tq(t[2], e); vb[0] = tq(t[0], e + 1) - tq(t[2], e + 1);
+        va[1] = tq(t[1], e) + tq(t[2], e); vb[1] = tq(t[1], e + 1) + tq(t[2], e + 1);
+        va[2] = tq(t[2], e) - tq(t[1], e); vb[2] = tq(t[2], e + 1) - tq(t[1], e + 1);
+        va[3] = tq(t[1], e) - tq(t[3], e); vb[3] = tq(t[1], e + 1) - tq(t[3], e + 1);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float va, vb;
-            if (p == 0)      { va = f4e(t[0], e) - f4e(t[2], e); vb = f4e(t[0], e + 1) - f4e(t[2], e + 1); }
-            else if (p == 1) { va = f4e(t[1], e) + f4e(t[2], e); vb = f4e(t[1], e + 1) + f4e(t[2], e + 1); }
-            else if (p == 2) { va = f4e(t[2], e) - f4e(t[1], e); vb = f4e(t[2], e + 1) - f4e(t[1], e + 1); }
-            else             { va = f4e(t[1], e) - f4e(t[3], e); vb = f4e(t[1], e + 1) - f4e(t[3], e + 1); }
-            u_wait<KW>(bcur[p]);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, bcur[p].x, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, bcur[p].y, acc[p], 0, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+            u_wait<KW>(bcur[q]);
+            acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q], bcur[q].x, acc[2 * q], 0, 0, 0);
+            acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q], bcur[q].y, acc[2 * q], 0, 0, 0);
+            acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q + 1], bcur[q].z, acc[2 * q + 1], 0, 0, 0);
+            acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q + 1], bcur[q].w, acc[2 * q + 1], 0, 0, 0);
             // refill (one half-step of slack behind the end of U: unconditional)
-            if (p == 0) u_load<0>(bcur[0], ulane, ub);
-            else if (p == 1) u_load<512>(bcur[1], ulane, ub);
-            else if (p == 2) u_load<1024>(bcur[2], ulane, ub);
-            else u_load<1536>(bcur[3], ulane, ub);
+            if (q == 0) u_load<0>(bcur[0], ulane, ub);
+            else u_load<1024>(bcur[1], ulane, ub);
         }
         ub += 16 * 64 * 2;
     };
 
-    constexpr int KDMA = 3 + ((kAbl & 1) ? 0 : ND);     // while the chunk's DMA pieces sit younger than bcur's loads
+    constexpr int KDMA = 1 + ((kAbl & 1) ? 0 : ND);     // while the chunk's DMA pieces sit younger than bcur's loads
     for (int cc = 0; cc < (ONE ? 1 : nchunks); ++cc) {
-        chunk_barrier<4>();          // chunk cc has landed; everyone is done reading the other buffer
-        const char *cur = reinterpret_cast<const char *>(patch + (cc & 1) * BUF_FLOATS);
+        chunk_barrier<2>();          // chunk cc has landed; everyone is done reading the other buffer
+        set_frag_base((cc & 1) * BUF_FLOATS * 4);
         if constexpr (!ONE) dma(cc + 1, cc + 1 < nchunks);
-        read_frag(cur, 0);
+        read_frag(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             combine();
             if (j == 0 && !ONE) half_step(std::integral_constant<int, KDMA>{}, 0);
-            else half_step(std::integral_constant<int, 3>{}, 0);
-            if constexpr (PREFETCH) { if (j < 3) read_frag(cur, j + 1); }      // next quarter's fragments fly under the second half-step
-            half_step(std::integral_constant<int, 3>{}, 1);
-            if constexpr (!PREFETCH) { if (j < 3) read_frag(cur, j + 1); }
+            else half_step(std::integral_constant<int, 1>{}, 0);
+            // the next quarter's fragments fly under the second half-step: all of them where the registers allow it
+            // (MT = 1), the first two columns (16 of the 32 registers) at the 128-register cap (MT = 2)
+            if constexpr (PREFETCH == 1) { if (j < 3) read_frag(j + 1); }
+            if constexpr (PREFETCH == 2) { if (j < 3) read_frag(j + 1, 0, 2); }
+            half_step(std::integral_constant<int, 1>{}, 1);
+            if constexpr (PREFETCH == 0) { if (j < 3) read_frag(j + 1); }
+            if constexpr (PREFETCH == 2) { if (j < 3) read_frag(j + 1, 2, 4); }
         }
     }
     // drain the slack refills before their registers die
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3]));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
 
     // ---- output transform. Lane-local along b: s0 = M_a0 + M_a1 + M_a2, s1 = M_a1 - M_a2 - M_a3. Along a the four
     // waves of an M-tile trade through LDS; wave a owns output pixel (i, x) = (a >> 1, a & 1) of every tile:
@@ -442,7 +467,7 @@ __host__ __device__ inline void wino_u16(const float g[9], float u[16]) {
 __host__ __device__ inline size_t wino_u_index(int n, int c, int pos, int ncc) {
     const int nt = n >> 5, nl = n & 31, cc = c >> 5, cl = c & 31;
     const int ch = cl >> 2, e = cl & 3, j = ch >> 1, h = ch & 1, hg = e >> 1, e2 = e & 1;
-    return ((((((size_t)nt * ncc + cc) * 4 + j) * 2 + hg) * 16 + pos) * 64 + (h * 32 + nl)) * 2 + e2;
+    return (((((((size_t)nt * ncc + cc) * 4 + j) * 2 + hg) * 8 + (pos >> 1)) * 64 + (h * 32 + nl)) * 2 + (pos & 1)) * 2 + e2;
 }
 
 // w: element (n, c, tap) at n*sn + c*sc + tap*st

@@ -1,6 +1,6 @@
 # usage: bash tools/scripts/abl_sweep.sh <reps> <layer ...>  -- Winograd kernel ablation builds (libevfly_abl<bits>.so, see EVFLY_WINO_ABL in wino.hip)
 cd $GRAFT_REPO_ROOT
 R=$1; shift
-for a in hip abl1 abl4 abl29; do
+for a in $(ls evfly_amd/libevfly_abl*.so | sed 's/.*libevfly_//; s/.so//'); do
   echo "== $a"; EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_$a.so python3 tools/conv_sweep.py $R "$@" 2>&1 | grep -v amdgpu.ids
 done
