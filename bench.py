@@ -13,8 +13,9 @@ scaling, no data-path collective) and the ranks all_gather their velocity rows o
 Prints ONE JSON line (contract in the task brief) with two extra objects:
   roofline     -- the dominant kernel family (the 3x3 convolutions: Winograd F(2x2,3x3) on the fp32 matrix cores),
                   timed with HIP events on the launch stream inside the timed region (evfly_model_set_profiling +
-                  evfly_model_set_profile_filter); `achieved` counts algorithmic direct-conv flops, `mfma_issued`
-                  the flops the matrix cores execute
+                  evfly_model_set_profile_filter); `achieved` / `frac` count the flops the matrix cores EXECUTE
+                  (16/36 of the direct-convolution count plus tile padding), `algorithmic` the direct-conv flops
+                  (2*M*N*K) over the same time
   cpu_baseline -- the CPU oracle (oracle/, a port) on a bounded sample of the same workload
 """
 import argparse
@@ -232,8 +233,8 @@ def main():
             g = json.load(open(pmc))["kernels"]["wino_conv3x3"]
             traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
             tnote = ("HBM bytes per launch, mean over the %d conv3x3 (k_wino9) launches of a step: (2 x FETCH_SIZE + "
-                     "WRITE_SIZE) from profiles/" + PMC_TRAFFIC + "; algorithmic = algorithmic.bytes_per_launch"
-                     % g["launches_per_step"])
+                     "WRITE_SIZE) from profiles/%s; algorithmic = algorithmic.bytes_per_launch"
+                     % (g["launches_per_step"], PMC_TRAFFIC))
         if dom["flops"]:
             # `achieved` = the flops the matrix cores EXECUTE per second in this kernel family. For the Winograd
             # F(2x2,3x3) kernel that is 16/36 of the direct-convolution count plus tile padding (exec_flops, from the
