@@ -4,13 +4,24 @@ Mirror of learner/learner.py:1167-1272 without the configargparse dependency (no
 the build image): the same option names, types, `nargs`, defaults and `action`s, the same
 config-file syntax (`key = value`, lists as `[a, b]`, booleans as `True`/`False`,
 `checkpoint_path` appended per list entry, unknown keys ignored via parse_known_args), and
-command-line arguments overriding the file. The training side of learner.py (Learner) is out of
-scope.
+command-line arguments overriding the file.
+
+`Learner` -- the offline caller of the models (learner/learner.py:35-495, 497-620, 920-1165): dataset loading through
+`dataloading.dataloader` / `preload`, model construction and checkpoint loading by `model_type`, and `run_model` /
+`validation` over trajectories with the reference's batch-as-time convention, input / ground-truth selection and loss
+terms. Training itself (optimizer step, augmentation, TensorBoard, plots) is out of scope: `run_model`
+in mode 'train' with `do_step=True` raises.
 """
 import argparse
 import getpass
 import os
 import sys
+from datetime import datetime
+from os.path import join as opj
+
+import numpy as np
+import torch
+import torch.nn.functional as F
 
 try:
     uname = getpass.getuser()
@@ -129,3 +140,293 @@ def argparsing(filename=None, argv=None):
         args.config = files[0]
     print(f'[CONFIGARGPARSE] Parsing args from config file {args.config}')
     return args
+
+
+# ---------------------------------------------------------------------------------------------- Learner
+_ARG_FIELDS = ['device', 'basedir', 'logdir', 'datadir', 'ws_suffix', 'data_augmentation', 'evs_min_cutoff', 'rescale_depth',
+               'rescale_evs', 'domain_randomization', 'bev', 'short', 'use_h5', 'model_type', 'skip_type', 'velpred',
+               'num_recurrent', 'num_in_channels', 'num_out_channels', 'val_split', 'seed', 'batch_size', 'load_trainval',
+               'checkpoint_path', 'combine_checkpoints', 'lr', 'N_eps', 'lr_warmup_epochs', 'lr_decay', 'save_model_freq',
+               'val_freq', 'optional_loss_param', 'events', 'keep_collisions', 'do_transform', 'resize_input',
+               'eval_tools_freq', 'eval_tools_on_best', 'print_trainprogress_freq', 'loss_weights', 'split_method',
+               'num_outputs']
+_BLOCKS = {'enc': ['num_layers', 'kernel_sizes', 'kernel_strides', 'out_channels', 'activations', 'pool_type',
+                   'invert_pool_inputs', 'pool_kernels', 'pool_strides', 'conv_function'],
+           'dec': ['num_layers', 'kernel_sizes', 'kernel_strides', 'out_channels', 'activations', 'pool_type', 'pool_kernels',
+                   'pool_strides', 'conv_function'],
+           'fc': ['num_layers', 'layer_sizes', 'activations', 'dropout_p']}
+
+
+class Learner:
+    """learner/learner.py:35 -- two ways in, as in the reference: `Learner(args)` (a parsed config: dataset + model), or
+    `Learner(dataset_name=..., no_model=True, ...)` (dataset only, what utils/to_h5.py:100 does)."""
+
+    def __init__(self, args=None, dataset_name=None, short=0, no_model=False, val_split=0.2, events='', do_transform=False,
+                 use_h5=True, workspace=None):
+        self.args = args
+        if args is not None:
+            for f in _ARG_FIELDS:
+                setattr(self, f, getattr(args, f))
+            self.dataset_name = args.dataset
+            for blk, names in _BLOCKS.items():
+                setattr(self, blk + '_params', {n: getattr(args, f'{blk}_{n}') for n in names})
+        else:                                                        # dataset-only defaults (:125-199)
+            self.__dict__.update(
+                device='cuda' if not no_model else 'cpu', basedir=f'/home/{uname}/evfly_ws/src/evfly', logdir='learner/logs',
+                datadir='../../data/datasets', ws_suffix='', dataset_name=dataset_name, data_augmentation=0.0,
+                evs_min_cutoff=0.0, rescale_depth=0.0, rescale_evs=0.0, domain_randomization=0.0, bev=0, short=short,
+                use_h5=use_h5, model_type='LSTMNet', skip_type='crop', velpred=0, num_recurrent=[0], num_in_channels=2,
+                num_out_channels=1, val_split=val_split, seed=-2, batch_size=0, load_trainval=True, checkpoint_path=None,
+                combine_checkpoints=False, lr=1e-5, N_eps=500, lr_warmup_epochs=5, lr_decay=False, save_model_freq=25,
+                val_freq=10, optional_loss_param=[0.0, 0.0], events=events, keep_collisions=True, do_transform=do_transform,
+                resize_input=None, eval_tools_freq=0, eval_tools_on_best=False, print_trainprogress_freq=1,
+                loss_weights=None, split_method='train-val', num_outputs=2)
+            self.enc_params = dict(num_layers=2, kernel_sizes=[5, 5], kernel_strides=[2, 2], out_channels=[16, 64],
+                                   activations=['relu', 'relu'], pool_type='max', invert_pool_inputs=False,
+                                   pool_kernels=[2, 2], pool_strides=[2, 2], conv_function='conv2d')
+            self.dec_params = dict(num_layers=2, kernel_sizes=[5, 5], kernel_strides=[2, 2], out_channels=[64, 16],
+                                   activations=['relu', 'relu'], pool_type='none', pool_kernels=[2, 2], pool_strides=[2, 2],
+                                   conv_function='upconv2d')
+            self.fc_params = dict(num_layers=2, layer_sizes=[128, 64], activations=['relu', 'relu'], dropout_p=0.5)
+        if not isinstance(self.dataset_name, list):
+            self.dataset_name = [self.dataset_name]
+        if isinstance(self.checkpoint_path, list) and len(self.checkpoint_path) == 1:
+            self.checkpoint_path = self.checkpoint_path[0]
+        if self.events != '':
+            self.events += '_tf.npy' if self.do_transform else '.npy'                     # :236-240
+        self.previous_tag = None
+        if self.seed is not None and self.seed >= 0:
+            np.random.seed(self.seed)
+            torch.manual_seed(self.seed)
+
+        # workspace: log.txt + train_val_dirs.npy (no TensorBoard writer, no source snapshot)
+        if workspace is None:
+            workspace = opj(self.basedir, self.logdir, datetime.now().strftime('d%m_%d_t%H_%M')) + self.ws_suffix
+            base, k = workspace, 2
+            while os.path.exists(workspace):
+                workspace, k = base + f'_{k}', k + 1
+        self.workspace = workspace
+        os.makedirs(self.workspace, exist_ok=True)
+        self.logfile = open(opj(self.workspace, 'log.txt'), 'w')
+        self.mylogger(f'[Learner init] Making workspace {self.workspace}')
+        if self.combine_checkpoints and not isinstance(self.checkpoint_path, list):
+            self.combine_checkpoints = False
+        if self.dataset_name is None or self.dataset_name[0] in (None, '', 'None'):
+            raise ValueError('[Learner init] No dataset name provided')
+        self.dataset_dir = [dn if os.path.isabs(dn) else opj(self.datadir, dn) for dn in self.dataset_name]
+
+        train_val_dirs = None
+        if self.checkpoint_path not in ('', [''], None) and self.load_trainval:                    # :311-321
+            cp = self.checkpoint_path[0] if isinstance(self.checkpoint_path, list) else self.checkpoint_path
+            try:
+                train_val_dirs = tuple(np.load(opj(os.path.dirname(cp), 'train_val_dirs.npy'), allow_pickle=True))
+                self.mylogger('[Learner init] Loaded train_val_dirs from checkpoint')
+            except Exception:
+                self.mylogger('[Learner init] Could not load train_val_dirs from checkpoint, dataloading from scratch')
+        self.learner_dataloading(val_split=self.val_split, short=self.short, seed=self.seed, train_val_dirs=train_val_dirs,
+                                 events=self.events, keep_collisions=self.keep_collisions)
+        self.num_training_steps = self.train_trajlength.shape[0]
+        self.num_val_steps = self.val_trajlength.shape[0]
+        self.model = None
+        if not no_model:
+            self._build_model()
+            self.num_eps_trained = 0
+            self.load_from_checkpoint(self.checkpoint_path)
+            self.mylogger(f'[SETUP] Number of parameters: {sum(p.numel() for p in self.model.parameters()):,}')
+
+    # ------------------------------------------------------------------ plumbing
+    def mylogger(self, msg):
+        """:421-433 -- tagged lines to stdout and log.txt, a blank line between tags."""
+        tag = msg.split('[')[1].split(']')[0] if '[' in msg and ']' in msg else None
+        if tag is not None and tag != self.previous_tag:
+            print('')
+            self.logfile.write('\n')
+        print(msg)
+        self.logfile.write(msg + '\n')
+        self.previous_tag = tag
+
+    def combine_state_dicts(self, state_dicts, model_names=None):
+        from .sim import combine_state_dicts
+        return combine_state_dicts(state_dicts, model_names)
+
+    def _build_model(self):
+        from . import learner_models as lm
+        mt = self.model_type[0] if isinstance(self.model_type, list) and len(self.model_type) == 1 else self.model_type
+        self.model_type = mt
+        kw = dict(num_in_channels=self.num_in_channels, num_out_channels=self.num_out_channels, num_recurrent=self.num_recurrent,
+                  logger=self.mylogger, velpred=self.velpred, enc_params=self.enc_params, fc_params=self.fc_params,
+                  form_BEV=self.bev, evs_min_cutoff=self.evs_min_cutoff, skip_type=self.skip_type)
+        self.mylogger('[SETUP] Establishing model.')
+        if mt == 'OrigUNet':                                                                  # :351-355
+            self.model = lm.OrigUNet(input_shape=list(self.train_ims.shape), **kw)
+        elif isinstance(mt, list) and mt[0] == 'OrigUNet' and mt[1] == 'VITFLY_ViTLSTM':           # :366-383
+            self.model = lm.OrigUNet_w_VITFLY_ViTLSTM(input_shape=[1, 1, self.resize_input[0], self.resize_input[1]],
+                                                      dec_params=self.dec_params, is_deployment=False, **kw)
+        else:
+            raise ValueError(f'[SETUP] Invalid model_type {mt}.')
+        self.model = self.model.to(self.device).float().eval()
+
+    def load_from_checkpoint(self, checkpoint_path):
+        """:456-495 -- one file for a single model (strict=False), one file per sub-module for the composite, or the
+        two files merged with `<model_type>.` prefixes when `combine_checkpoints`."""
+        if checkpoint_path in ('', [''], None, [None], [], ['None']):
+            return
+        try:
+            self.num_eps_trained = int(checkpoint_path[-10:-4])
+        except Exception:
+            self.num_eps_trained = 0
+        self.mylogger(f'[SETUP] Loading checkpoint from {checkpoint_path}, already trained for {self.num_eps_trained} epochs')
+        load = lambda f: torch.load(f, map_location='cpu')
+        if self.combine_checkpoints:
+            self.model.load_state_dict(self.combine_state_dicts([load(cp) for cp in checkpoint_path],
+                                                                model_names=[self.model_type[0].lower(), self.model_type[1].lower()]))
+        elif not isinstance(self.model_type, list):
+            self.model.load_state_dict(load(checkpoint_path), strict=False)
+        else:
+            self.model.origunet.load_state_dict(load(checkpoint_path[0]))
+            self.model.vitfly_vitlstm.load_state_dict(load(checkpoint_path[1]))
+
+    # ------------------------------------------------------------------ data
+    def learner_dataloading(self, val_split, short=0, seed=None, train_val_dirs=None, events='', keep_collisions=False):
+        """:497-620 -- every dataset through dataloader + preload, velocity commands cut from the metadata (columns 13..15
+        of the png / h5 layout, 12..14 of the legacy one), datasets concatenated, train_val_dirs.npy saved."""
+        from .dataloading import dataloader, preload
+        keys = ('meta', 'velcmd', 'ims', 'depths', 'trajlength', 'desvel', 'evs', 'dirs', 'dirs_ids')
+        acc = {m: {k: [] for k in keys} for m in ('train', 'val')}
+        self.dataset_numtrajs = []
+        for data_dir in self.dataset_dir:
+            full = data_dir if os.path.isabs(data_dir) else opj(self.basedir, data_dir)
+            self.mylogger(f'[DATALOADER] Loading from {data_dir} from set {self.dataset_dir}')
+            train, val, is_png = dataloader(full, val_split=val_split, short=short, seed=seed, train_val_dirs=train_val_dirs,
+                                            events=events, keep_collisions=keep_collisions,
+                                            logger=self.mylogger, do_clean_dataset=False, do_transform=self.do_transform,
+                                            use_h5=self.use_h5, resize_input=self.resize_input, split_method=self.split_method,
+                                            rescale_depth=self.rescale_depth, rescale_evs=self.rescale_evs,
+                                            evs_min_cutoff=self.evs_min_cutoff)
+            for m, tup in (('train', train), ('val', val)):
+                meta, (ims, depths), lens, desvel, evs, dirs, ids = tup
+                meta, ims, depths, desvel, evs = preload((meta, ims, depths, desvel, evs), 'cpu')
+                if m == 'train' and meta.shape[0] > 0:
+                    assert ims.max() <= 1.0 and ims.min() >= 0.0, 'Images not normalized (values outside [0.0, 1.0])'
+                    assert ims.max() > 0.50, "Images not normalized (values only below 0.10, possibly due to not normalizing images from 'old' dataset)"
+                cols = range(13, 16) if is_png else range(12, 15)
+                for k, v in zip(keys, (meta, meta[:, cols], ims, depths, lens, desvel, evs, dirs, ids)):
+                    acc[m][k].append(v)
+            self.dataset_numtrajs.append((len(train[2]), len(val[2])))
+        for m in ('train', 'val'):
+            a = acc[m]
+            for k in ('meta', 'velcmd', 'ims', 'desvel'):
+                setattr(self, f'{m}_{k}', torch.cat(a[k], 0))
+            setattr(self, f'{m}_depths', torch.cat(a['depths'], 0) if all(d is not None for d in a['depths']) else None)
+            setattr(self, f'{m}_evs', [t for ds in a['evs'] if ds is not None for t in ds] if any(e is not None for e in a['evs']) else None)
+            setattr(self, f'{m}_trajlength', np.concatenate(a['trajlength'], 0))
+            setattr(self, f'{m}_dirs', [d for ds in a['dirs'] for d in ds])
+            setattr(self, f'{m}_dirs_ids', [int(i) for ds in a['dirs_ids'] for i in ds])
+        np.save(opj(self.workspace, 'train_val_dirs.npy'),
+                np.array((self.train_dirs, self.val_dirs, self.train_dirs_ids, self.val_dirs_ids), dtype=object))
+
+    # ------------------------------------------------------------------ model over one trajectory
+    def run_model(self, it, traj_starts, traj_lengths, traj_ids, mode, return_inputs=False, seq_input=False, batch_size=0,
+                  do_step=True):
+        """:920-1165. Trajectory `it` (frames 1 .. L-1) in chunks of `batch_size` (0 = the whole trajectory): every chunk is
+        ONE model call whose batch rows are consecutive time steps (batch-as-time: fresh recurrent state per chunk, as in
+        the reference, which passes None). Returns ((loss, loss_terms), ((pred_vel, pred_vision), extras)) and, with
+        `return_inputs`, the inputs and ground truths."""
+        if mode not in ('train', 'val'):
+            raise ValueError(f'[RUN_MODEL] Invalid run_model mode {mode}.')
+        if mode == 'train' and do_step:
+            raise NotImplementedError('[RUN_MODEL] the training step (backward + optimizer) is out of scope of evfly_amd; '
+                                      "use do_step=False or mode='val'")
+        g = lambda k: getattr(self, f'{mode}_{k}')
+        ims, depths, desvel, velcmd, evs = g('ims'), g('depths'), g('desvel'), g('velcmd'), g('evs')
+        weights = torch.Tensor(self.loss_weights) if self.loss_weights is not None else torch.ones(2)
+        loss, loss_terms = 0.0, torch.zeros_like(weights)
+        n = int(traj_lengths[it]) - 1
+        preds_full = (torch.zeros((n, 3)), torch.zeros((n, 1, self.train_ims.shape[-2], self.train_ims.shape[-1])))
+        gts_full = (torch.zeros_like(preds_full[0]), torch.zeros_like(preds_full[1]))
+        ids = np.arange(traj_starts[it] + 1, traj_starts[it] + traj_lengths[it])
+        bs = len(ids) if batch_size <= 0 else batch_size
+        extras = ()
+        dev = self.device
+        with torch.no_grad():
+            for batch_ids in (ids[i:i + bs] for i in range(0, len(ids), bs)):
+                ev_rows = batch_ids - 1 - traj_starts[it]
+                if self.num_in_channels == 1:
+                    if depths is None:
+                        raise ValueError('[RUN_MODEL] num_in_channels = 1 but no depths available.')
+                    x = depths[batch_ids, ...].unsqueeze(1)
+                elif self.num_in_channels == 2:
+                    if evs is None:
+                        raise ValueError('[RUN_MODEL] num_in_channels = 2 but no evs available.')
+                    x = evs[traj_ids[it]][ev_rows, ...].unsqueeze(1)
+                else:
+                    raise ValueError(f'[RUN_MODEL] Invalid num_in_channels {self.num_in_channels}.')
+                if self.num_out_channels == 1:
+                    if depths is None:
+                        raise ValueError('[RUN_MODEL] num_out_channels = 1 but no depths available.')
+                    gt_frames = depths[batch_ids, ...].unsqueeze(1)
+                elif self.num_out_channels == 2:
+                    gt_frames = evs[traj_ids[it]][ev_rows, ...].unsqueeze(1)
+                else:
+                    raise ValueError(f'[RUN_MODEL] Invalid num_out_channels {self.num_out_channels}.')
+                dv = desvel[batch_ids].view(-1, 1)
+                gt = (velcmd[batch_ids, ...], gt_frames)
+                x, dv = x.to(dev).float(), dv.to(dev).float()
+                gt_norms = [(gt[0] / desvel[batch_ids].view(-1, 1)).to(dev).float(), gt[1].to(dev).float()]
+
+                if seq_input:                                   # legacy: one call per frame (:1084-1090)
+                    pv = torch.stack([self.model([xi.unsqueeze(0), vi.unsqueeze(0)])[0] for xi, vi in zip(x, dv)]).squeeze()
+                    preds = (pv, torch.zeros_like(gt_norms[1]))
+                elif self.model_type == 'OrigUNet':
+                    pv, extras = self.model([x, dv, None])
+                    preds = (pv.to(dev), extras[0])
+                elif isinstance(self.model_type, list) and self.model_type[0] == 'OrigUNet' and self.model_type[1] == 'VITFLY_ViTLSTM':
+                    pv, extras = self.model([x, dv, [None, None], None])
+                    preds = (pv, extras[0])
+                    preds[0][:, 2] = 0.0                        # :1074
+                else:
+                    raise ValueError(f'[RUN_MODEL] model_type {self.model_type} not supported.')
+                rows = batch_ids - (traj_starts[it] + 1)
+                preds_full[0][rows, ...] = preds[0].cpu(); preds_full[1][rows, ...] = preds[1].cpu()
+                gts_full[0][rows, ...] = gt[0].cpu(); gts_full[1][rows, ...] = gt[1].cpu()
+
+                for i, (w, gn, pr) in enumerate(zip(weights, gt_norms, preds)):                      # :1101-1144
+                    olp = self.optional_loss_param
+                    if i == 0 and olp is not None and olp[0] != 0.0:
+                        term = F.mse_loss(gn, pr, reduction='none')
+                        value = term.mean().item()
+                        sm = torch.logical_or(gn[:, 1].abs() > 0.0, gn[:, 2].abs() > 0.0)
+                        term = (term * (olp[0] * sm.float() + (~sm).float()).unsqueeze(1).repeat(1, 3)).mean()
+                    elif i == 1 and olp is not None and len(olp) > 1 and olp[1] != 0.0:
+                        term = F.mse_loss(gn, pr, reduction='none')
+                        value = term.mean().item()
+                        if olp[1] < 0:
+                            term = term * (1.0 / (gn + 0.1))
+                        if olp[1] == -2.0:
+                            term = term * (gn < 0.99).float()
+                        term = term.mean()
+                    else:
+                        term = F.mse_loss(gn, pr)
+                        value = term.item()
+                    loss_terms[i] += value
+                    loss = loss + w * term.cpu()
+        assert not torch.isnan(torch.as_tensor(loss)), f'[RUN_MODEL] Loss is NaN at iteration {it}'
+        out = (loss, loss_terms.detach().cpu().numpy()), (preds_full, extras)
+        if return_inputs:
+            out += ((ims[ids, ...].unsqueeze(1), evs[traj_ids[it]].unsqueeze(1) if evs is not None else None,
+                     desvel[ids].unsqueeze(1), gts_full),)
+        return out
+
+    def validation(self):
+        """:751-801 without the TensorBoard / plotting side: mean loss and loss terms over the validation trajectories."""
+        starts = np.cumsum(self.val_trajlength) - self.val_trajlength
+        tot, terms = 0.0, 0.0
+        for it in range(self.num_val_steps):
+            (l, lt), _ = self.run_model(it, starts, self.val_trajlength, np.arange(self.num_val_steps), 'val', batch_size=self.batch_size)
+            tot, terms = tot + float(l), terms + lt
+        n = max(1, self.num_val_steps)
+        return tot / n, terms / n
+
+    def train(self):
+        raise NotImplementedError('training is out of scope of evfly_amd (SURVEY.md §2); use the reference learner to train, '
+                                  'then load its checkpoints here')

@@ -369,6 +369,102 @@ def g11():
     save("g11_time_slices", **out)
 
 
+# ------------------------------------------------------------------ G13: dataset folders -> dataloader / preload
+def make_mini_dataset(root):
+    """A tiny trajectory-folder dataset in the layout learner/dataloading.py reads (:157-173, :196-360): four
+    trajectories of 26x34 gray PNG pairs (`<t>_im.png`, `<t>_depth.png`), a 21-column data.csv each, and the
+    evs_frames.npy object array of to_events.py (float64, one (n_i - 1, H, W) array per trajectory). Irregularities
+    the loader has to handle: trajectory 1 logs one timestamp twice and holds an image without a metadata row,
+    trajectory 2 has a collision flag (dropped unless keep_collisions). Committed as test data; regenerated here."""
+    from PIL import Image
+    import shutil
+    if os.path.isdir(root):
+        shutil.rmtree(root)
+    rs = np.random.RandomState(77)
+    H, W = 26, 34
+    lens = [5, 6, 4, 5]
+    evs = np.empty(len(lens), dtype=object)
+    for ti, n in enumerate(lens):
+        d = os.path.join(root, f"{ti:04d}")
+        os.makedirs(d)
+        ts = np.round(100.0 + ti + 0.033 * np.arange(n), 3)
+        rows = []
+        for k, t in enumerate(ts):
+            row = np.zeros(21)
+            row[0] = k; row[1] = t; row[2] = 3.0 + ti                       # desired velocity column (:370-372)
+            row[3:13] = rs.uniform(-1, 1, 10)
+            row[13:16] = rs.uniform(-1, 1, 3) * (3.0 + ti)                   # velocity command columns 13..15
+            row[16:20] = rs.uniform(-1, 1, 4)
+            row[20] = 1.0 if (ti == 2 and k == 2) else 0.0                   # collision flag = last column
+            rows.append(row)
+            Image.fromarray(rs.randint(0, 256, (H, W)).astype(np.uint8)).save(os.path.join(d, f"{t:.3f}_im.png"))
+            Image.fromarray(rs.randint(0, 256, (H, W)).astype(np.uint8)).save(os.path.join(d, f"{t:.3f}_depth.png"))
+        if ti == 1:
+            rows.insert(3, rows[2].copy())                                   # duplicated timestamp: the first copy goes
+            t_extra = 200.5                                                  # an image with no metadata row
+            Image.fromarray(rs.randint(0, 256, (H, W)).astype(np.uint8)).save(os.path.join(d, f"{t_extra:.3f}_im.png"))
+            Image.fromarray(rs.randint(0, 256, (H, W)).astype(np.uint8)).save(os.path.join(d, f"{t_extra:.3f}_depth.png"))
+        with open(os.path.join(d, "data.csv"), "w") as f:
+            f.write(",".join(f"c{k}" for k in range(21)) + "\n")
+            for row in rows:
+                f.write(",".join(repr(float(v)) for v in row) + "\n")
+        cnt = rs.poisson(0.7, (n - 1, H, W)) - rs.poisson(0.7, (n - 1, H, W))
+        evs[ti] = 0.2 * cnt.astype(np.float64)
+    np.save(os.path.join(root, "evs_frames.npy"), evs, allow_pickle=True)
+
+
+def _reference_dataloading():
+    """Import learner/dataloading.py from the reference. Its top-level `import cv2` / `import h5py` name packages this
+    image does not have; for the folder-dataset path only `cv2.imread(path, IMREAD_GRAYSCALE)` is reached, which is
+    provided by an 8-bit-gray PNG decode through PIL (byte-identical for such files). Nothing of h5py is reached."""
+    import importlib
+    import types
+    from PIL import Image
+    cv2 = types.ModuleType("cv2")
+    cv2.IMREAD_GRAYSCALE = 0
+    cv2.imread = lambda path, flag=0: np.asarray(Image.open(path).convert("L"), dtype=np.uint8)
+    sys.modules.setdefault("cv2", cv2)
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    return importlib.import_module("dataloading")
+
+
+def g13():
+    ref_dl = _reference_dataloading()
+    root = os.path.join(HERE, "mini_dataset")
+    make_mini_dataset(root)
+    quiet = lambda *a: None
+    out = {}
+
+    def pack(tag, res, preloaded=None):
+        for part, tup in (("train", res[0]), ("val", res[1])):
+            meta, (ims, depths), lens, desvel, evs, folders, ids = tup[:7]
+            out[f"{tag}_{part}_meta"] = meta.numpy()
+            out[f"{tag}_{part}_ims"] = ims.numpy()
+            out[f"{tag}_{part}_depths"] = depths.numpy()
+            out[f"{tag}_{part}_lens"] = np.asarray(lens)
+            out[f"{tag}_{part}_desvel"] = desvel.numpy()
+            out[f"{tag}_{part}_folders"] = np.array([os.path.basename(os.path.normpath(f)) for f in folders])
+            out[f"{tag}_{part}_ids"] = np.asarray(ids)
+            if evs is not None:
+                for k, e in enumerate(evs):
+                    out[f"{tag}_{part}_evs{k}"] = np.asarray(e, dtype=np.float32)     # preload()'s .float()
+            if len(tup) > 7:
+                out[f"{tag}_{part}_unmatched"] = np.array([len(u) for u in tup[7]])
+        out[f"{tag}_flag"] = np.array(bool(res[2]))
+
+    # A: plain load, shuffle by seed, 25 % validation split, collisions dropped
+    pack("a", ref_dl.dataloader(root, val_split=0.25, short=0, seed=3, do_transform=False, events="evs_frames", logger=quiet,
+                                use_h5=False, return_unmatched=True))
+    # B: collisions kept, no shuffle (seed -2), val-train split, fixed rescales + cutoff
+    pack("b", ref_dl.dataloader(root, val_split=0.5, short=0, seed=-2, do_transform=False, events="evs_frames", logger=quiet,
+                                use_h5=False, keep_collisions=True, split_method="val-train", rescale_depth=0.8,
+                                rescale_evs=0.6, evs_min_cutoff=0.15))
+    # C: the training configuration of learner/configs: resize to a new size, per-frame q97 rescale, cutoff
+    pack("c", ref_dl.dataloader(root, val_split=0.25, short=3, seed=-2, do_transform=False, events="evs_frames", logger=quiet,
+                                use_h5=False, resize_input=[20, 30], rescale_evs=-1.0, evs_min_cutoff=0.15))
+    save("g13_dataloader", **out)
+
+
 # ------------------------------------------------------------------ G0: state-dict key inventory
 def g0():
     import json
@@ -388,7 +484,7 @@ def g0():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     with torch.no_grad():
         for g in which:
             globals()[g]()
