@@ -185,7 +185,8 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
 // ONE = single-chunk layer (C_in = 32): no DMA inside the chunk loop. MT = 1 blocks run three per CU with 168 registers
 // per wave (room to fetch the next quarter's fragments under the current quarter's MFMAs); MT = 2 blocks two per CU
 // with 128.
-template <int MT, int ND, bool ONE>
+// ACT = the activation compiled in (ACT_RELU: every U-Net layer) or -1 = d.act at run time.
+template <int MT, int ND, bool ONE, int ACT>
 __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 : 3, MT == 2 ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
     constexpr int NW = 4 * MT, NTHR = 256 * MT;
 #ifndef EVFLY_WINO_PF2
@@ -228,11 +229,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
             }
     }
 
-    f32x16 acc[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    f32x16 acc[4];          // not zero-filled: the first half-step of chunk 0 starts every accumulator from C = 0
 
     const int nchunks = d.C / 32;
     const int iy0 = 2 * ty0, ix0 = 2 * tx0;
@@ -323,21 +320,23 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
             t[c] = f32x4{fmaf(sg, fv[c].x, fu[c].x), fmaf(sg, fv[c].y, fu[c].y), fmaf(sg, fv[c].z, fu[c].z), fmaf(sg, fv[c].w, fu[c].w)};
     };
     // one half-step: channel pair e, e + 1 of the four positions (8 MFMAs); KW = operations younger than bcur[q]'s load
-    auto half_step = [&](auto kw, int hg) {
+    auto half_step = [&](auto kw, auto first, int hg) {
         constexpr int KW = decltype(kw)::value;
+        constexpr bool FIRST = decltype(first)::value;      // the very first half-step of the block: accumulate from zero
         const int e = 2 * hg;
-        // column combinations of the four positions first (8 VALU), then the 8 MFMAs: no VALU -> MFMA operand wait states
+        // column combinations of the four positions first (8 VALU), then the 8 MFMAs
         float va[4], vb[4];
         va[0] = tq(t[0], e) - tq(t[2], e); vb[0] = tq(t[0], e + 1) - tq(t[2], e + 1);
         va[1] = tq(t[1], e) + tq(t[2], e); vb[1] = tq(t[1], e + 1) + tq(t[2], e + 1);
         va[2] = tq(t[2], e) - tq(t[1], e); vb[2] = tq(t[2], e + 1) - tq(t[1], e + 1);
         va[3] = tq(t[1], e) - tq(t[3], e); vb[3] = tq(t[1], e + 1) - tq(t[3], e + 1);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             u_wait<KW>(bcur[q]);
-            acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q], bcur[q].x, acc[2 * q], 0, 0, 0);
+            acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q], bcur[q].x, FIRST ? zero : acc[2 * q], 0, 0, 0);
             acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q], bcur[q].y, acc[2 * q], 0, 0, 0);
-            acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q + 1], bcur[q].z, acc[2 * q + 1], 0, 0, 0);
+            acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q + 1], bcur[q].z, FIRST ? zero : acc[2 * q + 1], 0, 0, 0);
             acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q + 1], bcur[q].w, acc[2 * q + 1], 0, 0, 0);
             // refill (one half-step of slack behind the end of U: unconditional)
             if (q == 0) u_load<0>(bcur[0], ulane, ub);
@@ -347,7 +346,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     };
 
     constexpr int KDMA = 1 + ((kAbl & 1) ? 0 : ND);     // while the chunk's DMA pieces sit younger than bcur's loads
-    for (int cc = 0; cc < (ONE ? 1 : nchunks); ++cc) {
+    // one chunk: barrier, DMA of the next chunk, 4 quarter-steps of 2 half-steps (64 MFMAs per wave). Chunk 0 is peeled
+    // (FIRST): its first half-step initialises the accumulators.
+    auto chunk = [&](int cc, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         chunk_barrier<2>();          // chunk cc has landed; everyone is done reading the other buffer
         set_frag_base((cc & 1) * BUF_FLOATS * 4);
         if constexpr (!ONE) dma(cc + 1, cc + 1 < nchunks);
@@ -355,17 +357,19 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             combine();
-            if (j == 0 && !ONE) half_step(std::integral_constant<int, KDMA>{}, 0);
-            else half_step(std::integral_constant<int, 1>{}, 0);
-            // the next quarter's fragments fly under the second half-step: all of them where the registers allow it
-            // (MT = 1), the first two columns (16 of the 32 registers) at the 128-register cap (MT = 2)
+            if (j == 0) half_step(std::integral_constant<int, ONE ? 1 : KDMA>{}, std::integral_constant<bool, FIRST>{}, 0);
+            else half_step(std::integral_constant<int, 1>{}, std::false_type{}, 0);
+            // the next quarter's fragments fly under the second half-step where the registers allow it (MT = 1)
             if constexpr (PREFETCH == 1) { if (j < 3) read_frag(j + 1); }
             if constexpr (PREFETCH == 2) { if (j < 3) read_frag(j + 1, 0, 2); }
-            half_step(std::integral_constant<int, 1>{}, 1);
+            half_step(std::integral_constant<int, 1>{}, std::false_type{}, 1);
             if constexpr (PREFETCH == 0) { if (j < 3) read_frag(j + 1); }
             if constexpr (PREFETCH == 2) { if (j < 3) read_frag(j + 1, 2, 4); }
         }
-    }
+    };
+    chunk(0, std::true_type{});
+    if constexpr (!ONE)
+        for (int cc = 1; cc < nchunks; ++cc) chunk(cc, std::false_type{});
     // drain the slack refills before their registers die
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
 
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
             const int r = 4 * q + i;
             const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
             const float y = own[r] + f4e(pa, i) + sB * f4e(pb, i) + bias;
-            ot[(tl * 4 + a) * 32 + fm] = apply_act(y, d.act);
+            ot[(tl * 4 + a) * 32 + fm] = apply_act(y, ACT >= 0 ? ACT : d.act);
         }
     }
     __syncthreads();
@@ -591,15 +595,15 @@ const WinoPlan &cached_plan(const ConvDesc &d) {
     return it->second;
 }
 
-template <int MT, int ND, bool ONE>
-int launch(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
+template <int MT, int ND, bool ONE, int ACT>
+int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
     const WinoGeom &g = p.g;
     // patch buffer(s); the epilogue reuses them for the exchange sets (MT x 24 KB) + the transposed tile (MT x 16 KB)
     const int buf = ND * 4 * MT * 1024;
     int lds = std::max((ONE ? 1 : 2) * buf, MT * 40 * 1024);
     if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
         lds = std::max(lds, buf + (d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
-    auto kern = k_wino9<MT, ND, ONE>;
+    auto kern = k_wino9<MT, ND, ONE, ACT>;
     static bool lds_set = false;
     if (!lds_set) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -615,6 +619,11 @@ int launch(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st)
     hipLaunchKernelGGL(kern, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256 * MT), lds, st, d, U, g);
     EVFLY_LAUNCH_CHECK();
     return 0;
+}
+
+template <int MT, int ND, bool ONE>
+int launch(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
+    return d.act == ACT_RELU ? launch_act<MT, ND, ONE, ACT_RELU>(d, U, p, st) : launch_act<MT, ND, ONE, -1>(d, U, p, st);
 }
 
 }  // namespace

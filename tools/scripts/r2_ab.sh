@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for v in hip pr1 pr3 hip; do EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_$v.so timeout 300 python tools/conv_sweep.py 200 2>&1 | grep -v amdgpu > gpurun_out/r2h_$v.log; done
-paste <(awk '{print $1,$2}' gpurun_out/r2h_hip.log) <(awk '{print $2}' gpurun_out/r2h_pr1.log) <(awk '{print $2}' gpurun_out/r2h_pr3.log)
+(timeout 600 python -m pytest tests/test_gpu_wino.py -x -q 2>&1 | tail -3)
+for v in prev hip; do EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_$v.so timeout 300 python tools/conv_sweep.py 200 2>&1 | grep -v amdgpu > gpurun_out/r2f_$v.log; done
+paste <(awk '{print $1,$2,$NF}' gpurun_out/r2f_prev.log) <(awk '{print $2,$NF}' gpurun_out/r2f_hip.log)
