@@ -73,6 +73,9 @@ struct WinoGeom {
 // offsets into 48 loop-invariant registers and spill).
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// 24-bit multiply (full-rate v_mul_u32_u24; v_mul_lo_u32 is quarter rate): every index product in this file has operands < 2^24
+__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
+
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 __device__ __forceinline__ float tq(const f32x4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
@@ -138,9 +141,9 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
     const int nitems = g.ngroups * 32;
     for (int idx = tid; idx < nitems; idx += NTHR) {
         const int pp = idx >> 3, ch = idx & 7;
-        const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
-        const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
-        const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
+        const int Y = m24(pp, g.mPWh) >> 20, pxh = pp - m24(Y, g.PW >> 1);
+        const int im = m24(Y, g.mPH) >> 20, py = Y - m24(im, g.PH);
+        const int key = (pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15;
         const int px = 2 * pxh;
         const bool row_ok = 2 * pp < g.npix && img0 + im < d.NI && iy0 + py < d.H;
         float a0[4], a1[4];
@@ -217,14 +220,14 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     {
         int t = mt * 32 + fm;
         if (t >= g.ntiles) t = 0;
-        const int im = (t * g.mPer) >> 20, rem = t - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+        const int im = m24(t, g.mPer) >> 20, rem = t - m24(im, per), ty = m24(rem, g.mTX) >> 20, tx = rem - m24(ty, g.TX);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int py = 2 * ty + (r == 0 ? rA : rB), pxh = tx + c;
-                const int pp = (im * g.PH + py) * (g.PW >> 1) + pxh;
-                const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
+                const int pp = m24(m24(im, g.PH) + py, g.PW >> 1) + pxh;
+                const int key = (pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15;
                 off0[r][c] = pp * 256 + ((fh ^ key) << 4);
             }
     }
@@ -258,13 +261,13 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
         for (int i = 0; i < ND; ++i) {
             const int gi = wv + i * NW;
             const int pp = gi * 4 + pl;
-            const int Y = (pp * g.mPWh) >> 20, pxh = pp - Y * (g.PW >> 1);
-            const int im = (Y * g.mPH) >> 20, py = Y - im * g.PH;
-            const int sl = sp ^ ((pxh + (py >> 1) * g.TX + im * per) & 15);
+            const int Y = m24(pp, g.mPWh) >> 20, pxh = pp - m24(Y, g.PW >> 1);
+            const int im = m24(Y, g.mPH) >> 20, py = Y - m24(im, g.PH);
+            const int sl = sp ^ ((pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15);
             const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
             const int iy = iy0 + py, ix = ix0 + px;
             const bool ok = 2 * pp < g.npix && img0 + im < d.NI && iy < d.H && ix < d.W;
-            voff[i] = ok ? (unsigned)((((int64_t)im * d.H + iy) * d.W + ix) * d.ldx * 4 + ch * 16) : 0x7ffffff0u;   // out of range: zeros
+            voff[i] = ok ? (unsigned)(m24(m24(m24(im, d.H) + iy, d.W) + ix, (int)d.ldx * 4) + ch * 16) : 0x7ffffff0u;   // out of range: zeros
         }
     }
     // chunk cc -> buffer cc & 1. `live` false (behind the last chunk): the same ND pieces are issued with every lane out
@@ -419,20 +422,22 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     }
     __syncthreads();
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
+    float *ybase = d.y + (int64_t)img0 * d.OH * d.OW * d.ldy;        // image img0 (wave-uniform)
+    const int yimg = d.OH * d.OW * (int)d.ldy;                         // floats per output image (< 2^24, checked by the launcher)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int idx = tid + q * NTHR, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
-        const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+        const int im = m24(tl, g.mPer) >> 20, rem = tl - m24(im, per), ty = m24(rem, g.mTX) >> 20, tx = rem - m24(ty, g.TX);
         const int img = img0 + im, oy = 2 * (ty0 + ty) + (pix >> 1), ox = 2 * (tx0 + tx) + (pix & 1), n = n0 + c4 * 4;
         if (tl >= g.ntiles || img >= d.NI || oy >= d.OH || ox >= d.OW || n >= d.Nc || (kAbl & 4)) continue;
         const float4 v = *reinterpret_cast<const float4 *>(ot + pl * 32 + c4 * 4);
-        float *dst = d.y + (((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy + n;
+        float *dst = ybase + (m24(im, yimg) + m24(m24(oy, d.OW) + ox, (int)d.ldy) + n);      // 32-bit offset inside the block's images
         if (vec) *reinterpret_cast<float4 *>(dst) = v;
         else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
     }
     if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): the window is the Winograd tile; NaN wins like in torch
         const int c4 = tid & 7, tl = tid >> 3;
-        const int im = (tl * g.mPer) >> 20, rem = tl - im * per, ty = (rem * g.mTX) >> 20, tx = rem - ty * g.TX;
+        const int im = m24(tl, g.mPer) >> 20, rem = tl - m24(im, per), ty = m24(rem, g.mTX) >> 20, tx = rem - m24(ty, g.TX);
         const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx, n = n0 + c4 * 4;
         const int PHo = d.OH / 2, PWo = d.OW / 2;
         if (tl < g.ntiles && img < d.NI && gy < PHo && gx < PWo && n < d.Nc && !(kAbl & 4)) {
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
             const float4 v = make_float4(MX(MX(p0.x, p1.x), MX(p2.x, p3.x)), MX(MX(p0.y, p1.y), MX(p2.y, p3.y)),
                                          MX(MX(p0.z, p1.z), MX(p2.z, p3.z)), MX(MX(p0.w, p1.w), MX(p2.w, p3.w)));
 #undef MX
-            float *dst = d.y_pool + (((int64_t)img * PHo + gy) * PWo + gx) * d.Nc + n;
+            float *dst = d.y_pool + (int64_t)img0 * PHo * PWo * d.Nc + (m24(im, m24(PHo, PWo) * d.Nc) + m24(m24(gy, PWo) + gx, d.Nc) + n);
             if ((d.Nc & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
             else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
         }
@@ -637,6 +642,8 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
     EVFLY_REQUIRE(p.ok, "wino: no tile plan");
     EVFLY_REQUIRE(p.g.ngroups <= p.c.ND * 4 * p.c.MT, "wino: patch exceeds the DMA piece budget");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
+    EVFLY_REQUIRE((int64_t)d.OH * d.OW * d.ldy < (1 << 24) && (int64_t)d.H * d.W * d.ldx < (1 << 24),
+                  "wino: image larger than 2^24 floats (24-bit index arithmetic)");
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
                   "wino: the fused first-conv producer needs C == 32 and 1 or 2 frame channels");
     const bool one = d.C == 32;
