@@ -608,6 +608,8 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
     int lds = std::max((ONE ? 1 : 2) * buf, MT * 40 * 1024);
     if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
         lds = std::max(lds, buf + (d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
+    static const int lds_min = getenv("EVFLY_WINO_LDS_MIN") ? atoi(getenv("EVFLY_WINO_LDS_MIN")) : 0;   // occupancy experiments
+    lds = std::max(lds, lds_min);
     auto kern = k_wino9<MT, ND, ONE, ACT>;
     static bool lds_set = false;
     if (!lds_set) {

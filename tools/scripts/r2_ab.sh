@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-(timeout 600 python -m pytest tests/test_gpu_wino.py -x -q 2>&1 | tail -3)
-for v in prev hip; do EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_$v.so timeout 300 python tools/conv_sweep.py 200 2>&1 | grep -v amdgpu > gpurun_out/r2f_$v.log; done
-paste <(awk '{print $1,$2,$NF}' gpurun_out/r2f_prev.log) <(awk '{print $2,$NF}' gpurun_out/r2f_hip.log)
+L="e22 e32 e42 d11 d31"
+EVFLY_WINO_MT=1 timeout 300 python tools/conv_sweep.py 200 $L 2>&1 | grep -v amdgpu > gpurun_out/r2i_a.log
+EVFLY_WINO_MT=1 EVFLY_WINO_LDS_MIN=81920 timeout 300 python tools/conv_sweep.py 200 $L 2>&1 | grep -v amdgpu > gpurun_out/r2i_b.log
+EVFLY_WINO_MT=2 timeout 300 python tools/conv_sweep.py 200 $L 2>&1 | grep -v amdgpu > gpurun_out/r2i_c.log
+paste <(awk '{print $1,$2}' gpurun_out/r2i_c.log) <(awk '{print $2}' gpurun_out/r2i_a.log) <(awk '{print $2}' gpurun_out/r2i_b.log)
