@@ -49,6 +49,28 @@ def test_batch_vs_oracle(gpu_device, clustered):
     assert counts.sum() == len(batch["x"])          # every event lands in exactly one window
 
 
+def test_full_c2_batch_size_independent_properties(gpu_device):
+    """BASELINE.json C2 at FULL size (64 streams x 5 windows x 60 000 events = 19.2 M events): properties that need no
+    oracle pass over the whole batch -- every event lands in exactly one window bin, per-window totals equal the window's
+    event count, the polarity split equals the polarity histogram, float frames are 0.2 * (P - N) of the counts, and
+    the first six streams are bit-identical to the same streams voxelized alone (the oracle-checked case above)."""
+    B, T = 64, 5
+    batch = syn.make_batch(B, T, H, W, events_per_window=60_000)
+    f32, f64, counts = _vox(batch, H, W)
+    n = len(batch["x"])
+    assert counts.shape == (B, T, 2, H, W) and int(counts.sum()) == n
+    per_win = counts.reshape(B, T, -1).sum(-1)
+    assert (per_win.sum(1) == T * 60_000).all()                        # every stream: T x 60 000 events, all inside its windows
+    for b in (0, 17, 63):                                              # window totals from the timestamps alone
+        t = batch["t"][batch["offsets"][b]:batch["offsets"][b + 1]]
+        assert np.array_equal(per_win[b], np.diff(np.searchsorted(t, batch["edges"][b], side="left")))
+    assert int(counts[:, :, 0].sum()) == int((batch["p"] > 0).sum()) and int(counts[:, :, 1].sum()) == int((batch["p"] <= 0).sum())
+    assert np.array_equal(f64, ovox.signed_frame(counts[:, :, 0], counts[:, :, 1])) and np.array_equal(f32, f64.astype(np.float32))
+    small = syn.make_batch(6, T, H, W, events_per_window=60_000)
+    _, _, c6 = _vox(small, H, W)
+    assert np.array_equal(counts[:6], c6)
+
+
 def test_sensor_size_thresholds_and_01(gpu_device):
     """C3-shaped: 480x640, T=10, {0,1} polarity convention, unequal thresholds."""
     B, T, Hh, Ww = 2, 10, 480, 640
