@@ -295,9 +295,16 @@ def main():
                                     "note": "fp32-grade split precision (error ~2^-16 per product); informational"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd, T, a.events_per_window, a.cpu_seconds)
-        print(json.dumps(out))
+    # The ONE JSON line goes last: RCCL writes a banner (host name, library path) into the C stdio buffer, which a pipe only
+    # flushes at exit -- behind everything Python printed, on every rank. Flush C stdio on all ranks, meet, then print.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
