@@ -185,17 +185,17 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
 // threads, <= 48 KB LDS, three or four blocks per CU) keeps more independent blocks in flight, which matters for the
 // one- and two-chunk layers whose load / MFMA / store phases are of similar length (e12: 64 MFMAs per wave between the
 // patch production and the stores). ND = DMA pieces per wave and chunk; one patch buffer is ND * 4 * MT KiB.
-// ONE = single-chunk layer (C_in = 32): no DMA inside the chunk loop. MT = 1 blocks run three per CU with 168 registers
-// per wave (room to fetch the next quarter's fragments under the current quarter's MFMAs); MT = 2 blocks two per CU
-// with 128.
+// ONE = single-chunk layer (C_in = 32): no DMA inside the chunk loop. Multi-chunk MT = 1 blocks run three per CU with
+// <= 168 registers per wave (room to fetch the next quarter's fragments under the current quarter's MFMAs); MT = 2
+// blocks two per CU and single-chunk MT = 1 blocks four per CU with <= 128.
 // ACT = the activation compiled in (ACT_RELU: every U-Net layer) or -1 = d.act at run time.
 template <int MT, int ND, bool ONE, int ACT>
-__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 : 3, MT == 2 ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
+__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT == 2 || ONE) ? 4 : 3, (MT == 2 || ONE) ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
     constexpr int NW = 4 * MT, NTHR = 256 * MT;
 #ifndef EVFLY_WINO_PF2
 #define EVFLY_WINO_PF2 0
 #endif
-    constexpr int PREFETCH = MT == 1 ? 1 : EVFLY_WINO_PF2;
+    constexpr int PREFETCH = (MT == 1 && !ONE) ? 1 : EVFLY_WINO_PF2;
     constexpr int BUF_FLOATS = ND * NW * 256;             // one patch buffer: ND * NW pieces of 1 KiB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;
@@ -573,7 +573,11 @@ WinoPlan make_plan(const ConvDesc &d) {
     const bool ok1 = plan(d, g1, c1.MT, c1.max_px()), ok2 = plan(d, g2, c2.MT, c2.max_px());
     bool use2;
     if (force) use2 = force == 2 ? ok2 : !ok1;
-    // the small block is ~5 % slower at equal tile efficiency (measured on e22 / e32 / e42 / d11)
+    // single-chunk layers (C_in = 32: e12, e21, d42): 64 MFMAs per wave between a cold patch and the output transform --
+    // what counts is independent blocks in flight: 32-tile blocks, FOUR per CU (128 registers), measured 7 % ahead of the
+    // 64-tile blocks (two per CU) and of three 32-tile blocks per CU
+    else if (d.C == 32) use2 = !ok1;
+    // multi-chunk layers: the small block is ~5 % slower at equal tile efficiency (measured on e22 / e32 / e42 / d11)
     else use2 = ok1 && ok2 ? !(1.08 * g1.cost < g2.cost) : ok2;
     WinoPlan p;
     p.ok = use2 ? ok2 : ok1;
