@@ -192,10 +192,9 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
 template <int MT, int ND, bool ONE, int ACT>
 __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT == 2 || ONE) ? 4 : 3, (MT == 2 || ONE) ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
     constexpr int NW = 4 * MT, NTHR = 256 * MT;
-#ifndef EVFLY_WINO_PF2
-#define EVFLY_WINO_PF2 0
-#endif
-    constexpr int PREFETCH = (MT == 1 && !ONE) ? 1 : EVFLY_WINO_PF2;
+    // next quarter's fragments fetched under the current quarter's second half-step: only where 168 registers allow it
+    // (at the 128-register cap it measured +-1 %)
+    constexpr int PREFETCH = (MT == 1 && !ONE) ? 1 : 0;
     constexpr int BUF_FLOATS = ND * NW * 256;             // one patch buffer: ND * NW pieces of 1 KiB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;
@@ -305,9 +304,9 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
 #pragma unroll
             for (int c = 0; c < 2; ++c) ofr[r][c] = opaque(off0[r][c] + buf_bytes + (int)lds0);
     };
-    auto read_frag = [&](int j, int c0 = 0, int c1 = 4) {
+    auto read_frag = [&](int j) {
 #pragma unroll
-        for (int c = c0; c < c1; ++c) {
+        for (int c = 0; c < 4; ++c) {
             const int x = (j << 5) | ((c & 1) << 7);
             if constexpr (kAbl & 8) { fu[c] = f32x4{1.f, 2.f, 3.f, (float)lane}; fv[c] = fu[c]; }
             else {
@@ -364,10 +363,8 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             else half_step(std::integral_constant<int, 1>{}, std::false_type{}, 0);
             // the next quarter's fragments fly under the second half-step where the registers allow it (MT = 1)
             if constexpr (PREFETCH == 1) { if (j < 3) read_frag(j + 1); }
-            if constexpr (PREFETCH == 2) { if (j < 3) read_frag(j + 1, 0, 2); }
             half_step(std::integral_constant<int, 1>{}, std::false_type{}, 1);
             if constexpr (PREFETCH == 0) { if (j < 3) read_frag(j + 1); }
-            if constexpr (PREFETCH == 2) { if (j < 3) read_frag(j + 1, 2, 4); }
         }
     };
     chunk(0, std::true_type{});
@@ -612,8 +609,6 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
     int lds = std::max((ONE ? 1 : 2) * buf, MT * 40 * 1024);
     if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
         lds = std::max(lds, buf + (d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
-    static const int lds_min = getenv("EVFLY_WINO_LDS_MIN") ? atoi(getenv("EVFLY_WINO_LDS_MIN")) : 0;   // occupancy experiments
-    lds = std::max(lds, lds_min);
     auto kern = k_wino9<MT, ND, ONE, ACT>;
     static bool lds_set = false;
     if (!lds_set) {
