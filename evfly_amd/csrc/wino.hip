@@ -67,6 +67,9 @@ struct WinoGeom {
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
     double cost;                // plan cost (launched tile slots + weighted patch pixels)
+    // per-plan DMA table (device memory, built once per plan / row pitch / device): entry (piece g, lane l) =
+    // { byte offset of the lane's 16 B relative to the block's patch origin (0x7ffffff0: padding lane), py | px << 8 }
+    const uint2 *tab;
 };
 
 // Opaque identity: stops hipcc from hoisting the per-step address XORs out of the chunk loop (LICM would turn six
@@ -211,6 +214,16 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const int mt = MT == 2 ? (wv & 1) : 0, a = MT == 2 ? (wv >> 1) : wv;
     const int fm = lane & 31, fh = lane >> 5;
     const int per = g.TY * g.TX;
+    // this wave's DMA table entries, requested first: their L2 round trip runs under the index arithmetic below
+    // (multi-chunk kernels only: in a single-chunk block the patch's cold round trip is the critical path, and a table
+    // load in front of the DMA issue lengthens it -- measured +7..11 % there against -1..-5 % on the multi-chunk layers)
+    constexpr bool TABLE = !ONE;
+    uint2 te[TABLE ? ND : 1];
+    if constexpr (TABLE) {
+        const uint2 *tb = g.tab + wv * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) te[i] = tb[i * NW * 64];
+    }
 
     // B^T row a: t = d[rA] + sg * d[rB]   (a = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
     const int rA = a == 0 ? 0 : a == 2 ? 2 : 1, rB = a == 3 ? 3 : a == 2 ? 1 : 2;
@@ -249,24 +262,38 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         }
     }
     if (!produced) {
+        // descriptor from the block's patch origin (img0, iy0, ix0) to the end of its image group: images past the batch
+        // and rows past the last image fall out of range by themselves; what is left to mask is the patch hanging over the
+        // right / bottom edge of an image -- edge blocks only. The per-lane offsets come from the plan's table (the mul-shift
+        // divisions they replace cost 3-8 % of a layer: measured by executing them twice).
         const int nimg = min(g.IMGS, d.NI - img0);
-        const uint64_t xb = (uint64_t)(uintptr_t)(d.x + (int64_t)img0 * d.H * d.W * d.ldx);
+        const int64_t org = ((int64_t)img0 * d.H + iy0) * d.W + ix0;
+        const uint64_t xb = (uint64_t)(uintptr_t)(d.x + org * d.ldx);
         srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
         srd[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
-        srd[2] = __builtin_amdgcn_readfirstlane((int)((int64_t)nimg * d.H * d.W * d.ldx * 4));
+        srd[2] = __builtin_amdgcn_readfirstlane((int)(((int64_t)nimg * d.H * d.W - ((int64_t)iy0 * d.W + ix0)) * d.ldx * 4));
         srd[3] = 0x00020000;
-        const int pl = lane >> 4, sp = lane & 15;
+        const bool interior = iy0 + g.PH <= d.H && ix0 + g.PW <= d.W;       // wave-uniform
+        if constexpr (!TABLE) {
+            const int pl = lane >> 4, sp = lane & 15, hrem = d.H - iy0, wrem = d.W - ix0;
 #pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int gi = wv + i * NW;
-            const int pp = gi * 4 + pl;
-            const int Y = m24(pp, g.mPWh) >> 20, pxh = pp - m24(Y, g.PW >> 1);
-            const int im = m24(Y, g.mPH) >> 20, py = Y - m24(im, g.PH);
-            const int sl = sp ^ ((pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15);
-            const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool ok = 2 * pp < g.npix && img0 + im < d.NI && iy < d.H && ix < d.W;
-            voff[i] = ok ? (unsigned)(m24(m24(m24(im, d.H) + iy, d.W) + ix, (int)d.ldx * 4) + ch * 16) : 0x7ffffff0u;   // out of range: zeros
+            for (int i = 0; i < ND; ++i) {
+                const int pp = (wv + i * NW) * 4 + pl;
+                const int Y = m24(pp, g.mPWh) >> 20, pxh = pp - m24(Y, g.PW >> 1);
+                const int im = m24(Y, g.mPH) >> 20, py = Y - m24(im, g.PH);
+                const int sl = sp ^ ((pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15);
+                const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
+                const bool ok = 2 * pp < g.npix && py < hrem && px < wrem;
+                voff[i] = ok ? (unsigned)(m24(m24(m24(im, d.H) + py, d.W) + px, (int)d.ldx * 4) + ch * 16) : 0x7ffffff0u;
+            }
+        } else if (interior) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) voff[i] = te[i].x;
+        } else {
+            const int hrem = d.H - iy0, wrem = d.W - ix0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+                voff[i] = ((int)(te[i].y & 0xffu) < hrem && (int)(te[i].y >> 8) < wrem) ? te[i].x : 0x7ffffff0u;      // out of range: zeros
         }
     }
     // chunk cc -> buffer cc & 1. `live` false (behind the last chunk): the same ND pieces are issued with every lane out
@@ -516,6 +543,7 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
     g.n_nt = cdiv(d.Nc, 32);
     g.n_btiles = g.bx * g.by * g.bi;
     g.cpx = cdiv(g.n_btiles, kNumXCD);
+    g.tab = nullptr;
     g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
     return true;
 }
@@ -601,6 +629,49 @@ const WinoPlan &cached_plan(const ConvDesc &d) {
     return it->second;
 }
 
+// DMA table of a plan for input row pitch ldx (floats): same arithmetic the kernel used to run per block
+// (piece g = 4 pixel pairs x 16 slots; slot = (pixel of the pair, 4-channel group) XOR-swizzled by the pair's key)
+std::vector<uint2> build_dma_table(const WinoGeom &g, int H, int W, int64_t ldx, int npieces) {
+    std::vector<uint2> t((size_t)npieces * 64);
+    const int per = g.TY * g.TX;
+    for (int gi = 0; gi < npieces; ++gi)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int pl = lane >> 4, sp = lane & 15;
+            const int pp = gi * 4 + pl;
+            const int Y = pp / (g.PW / 2), pxh = pp % (g.PW / 2);
+            const int im = Y / g.PH, py = Y % g.PH;
+            const int sl = sp ^ ((pxh + (py >> 1) * g.TX + im * per) & 15);
+            const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
+            uint2 e;
+            e.y = (unsigned)py | ((unsigned)px << 8);
+            e.x = 2 * pp < g.npix ? (unsigned)((((int64_t)im * H + py) * W + px) * ldx * 4 + ch * 16) : 0x7ffffff0u;
+            if (2 * pp >= g.npix) e.y = 0xffffu;           // padding lane: masked on the edge path too
+            t[(size_t)gi * 64 + lane] = e;
+        }
+    return t;
+}
+
+// device copy per (geometry, row pitch, device); lives as long as the library
+int dma_table(const ConvDesc &d, const WinoPlan &p, const uint2 **out) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int64_t, int>, const uint2 *> cache;
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, d.ldx, dev);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        const int npieces = p.c.ND * 4 * p.c.MT;
+        const std::vector<uint2> host = build_dma_table(p.g, d.H, d.W, d.ldx, npieces);
+        void *dp = nullptr;
+        EVFLY_HIP(hipMalloc(&dp, host.size() * sizeof(uint2)));
+        EVFLY_HIP(hipMemcpy(dp, host.data(), host.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        it = cache.emplace(key, static_cast<const uint2 *>(dp)).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
 template <int MT, int ND, bool ONE, int ACT>
 int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
     const WinoGeom &g = p.g;
@@ -622,7 +693,10 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
         fprintf(stderr, "wino9<%d,%d,%d>: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, %d B LDS, %d blocks/CU\n", MT, ND, (int)ONE,
                 d.NI, d.OH, d.OW, d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, lds, nb);
     }
-    hipLaunchKernelGGL(kern, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256 * MT), lds, st, d, U, g);
+    WinoGeom gg = g;
+    if (!ONE)
+        if (int rc = dma_table(d, p, &gg.tab)) return rc;
+    hipLaunchKernelGGL(kern, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256 * MT), lds, st, d, U, gg);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
