@@ -70,6 +70,11 @@ struct WinoGeom {
     // per-plan DMA table (device memory, built once per plan / row pitch / device): entry (piece g, lane l) =
     // { byte offset of the lane's 16 B relative to the block's patch origin (0x7ffffff0: padding lane), py | px << 8 }
     const uint2 *tab;
+    // per-plan lane tables of the same allocation: fragment offsets [wave][lane] -> off0[2][2] (byte offsets inside a
+    // patch buffer); store entries [q 4][thread] and pool entries [thread] = { float offset relative to the block's
+    // output origin, row | col << 8 | image << 16 (0xffffffff: no tile behind this thread) }
+    const int4 *ftab;
+    const uint2 *stab, *ptab;
 };
 
 // Opaque identity: stops hipcc from hoisting the per-step address XORs out of the chunk loop (LICM would turn six
@@ -226,22 +231,12 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     }
 
     // B^T row a: t = d[rA] + sg * d[rB]   (a = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
-    const int rA = a == 0 ? 0 : a == 2 ? 2 : 1, rB = a == 3 ? 3 : a == 2 ? 1 : 2;
+    // (rows rA = 0, 1, 2, 1 and rB = 2, 2, 1, 3 of the patch: in the plan's fragment table)
     const float sg = a == 1 ? 1.f : -1.f;
     int off0[2][2];
     {
-        int t = mt * 32 + fm;
-        if (t >= g.ntiles) t = 0;
-        const int im = m24(t, g.mPer) >> 20, rem = t - m24(im, per), ty = m24(rem, g.mTX) >> 20, tx = rem - m24(ty, g.TX);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int py = 2 * ty + (r == 0 ? rA : rB), pxh = tx + c;
-                const int pp = m24(m24(im, g.PH) + py, g.PW >> 1) + pxh;
-                const int key = (pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15;
-                off0[r][c] = pp * 256 + ((fh ^ key) << 4);
-            }
+        const int4 f = g.ftab[wv * 64 + lane];          // (row rA / rB) x (column pair 0 / 1) of this lane's tile
+        off0[0][0] = f.x; off0[0][1] = f.y; off0[1][0] = f.z; off0[1][1] = f.w;
     }
 
     f32x16 acc[4];          // not zero-filled: the first half-step of chunk 0 starts every accumulator from C = 0
@@ -446,25 +441,28 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     }
     __syncthreads();
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
-    float *ybase = d.y + (int64_t)img0 * d.OH * d.OW * d.ldy;        // image img0 (wave-uniform)
-    const int yimg = d.OH * d.OW * (int)d.ldy;                         // floats per output image (< 2^24, checked by the launcher)
+    // output origin of the block (wave-uniform); per-thread offsets and coordinates come from the plan's tables
+    const int oy0 = 2 * ty0, ox0 = 2 * tx0;
+    float *ybase = d.y + ((int64_t)img0 * d.OH * d.OW + (int64_t)oy0 * d.OW + ox0) * d.ldy + n0;
+    const int hrem = d.OH - oy0, wrem = d.OW - ox0, irem = d.NI - img0, nrem = d.Nc - n0 - (tid & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int idx = tid + q * NTHR, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
-        const int im = m24(tl, g.mPer) >> 20, rem = tl - m24(im, per), ty = m24(rem, g.mTX) >> 20, tx = rem - m24(ty, g.TX);
-        const int img = img0 + im, oy = 2 * (ty0 + ty) + (pix >> 1), ox = 2 * (tx0 + tx) + (pix & 1), n = n0 + c4 * 4;
-        if (tl >= g.ntiles || img >= d.NI || oy >= d.OH || ox >= d.OW || n >= d.Nc || (kAbl & 4)) continue;
-        const float4 v = *reinterpret_cast<const float4 *>(ot + pl * 32 + c4 * 4);
-        float *dst = ybase + (m24(im, yimg) + m24(m24(oy, d.OW) + ox, (int)d.ldy) + n);      // 32-bit offset inside the block's images
+        const uint2 e = g.stab[q * NTHR + tid];
+        const bool ok = e.y != 0xffffffffu && (int)(e.y & 0xffu) < hrem && (int)((e.y >> 8) & 0xffu) < wrem && (int)(e.y >> 16) < irem &&
+                        nrem > 0 && !(kAbl & 4);
+        if (!ok) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(ot + (tid + q * NTHR) * 4);
+        float *dst = ybase + e.x;
         if (vec) *reinterpret_cast<float4 *>(dst) = v;
-        else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
+        else { dst[0] = v.x; if (nrem > 1) dst[1] = v.y; if (nrem > 2) dst[2] = v.z; if (nrem > 3) dst[3] = v.w; }
     }
     if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): the window is the Winograd tile; NaN wins like in torch
-        const int c4 = tid & 7, tl = tid >> 3;
-        const int im = m24(tl, g.mPer) >> 20, rem = tl - m24(im, per), ty = m24(rem, g.mTX) >> 20, tx = rem - m24(ty, g.TX);
-        const int img = img0 + im, gy = ty0 + ty, gx = tx0 + tx, n = n0 + c4 * 4;
         const int PHo = d.OH / 2, PWo = d.OW / 2;
-        if (tl < g.ntiles && img < d.NI && gy < PHo && gx < PWo && n < d.Nc && !(kAbl & 4)) {
+        const uint2 e = g.ptab[tid];
+        const bool ok = e.y != 0xffffffffu && (int)(e.y & 0xffu) < PHo - ty0 && (int)((e.y >> 8) & 0xffu) < PWo - tx0 && (int)(e.y >> 16) < irem &&
+                        nrem > 0 && !(kAbl & 4);
+        if (ok) {
+            const int c4 = tid & 7, tl = tid >> 3;
             const float4 p0 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 0) * 32 + c4 * 4);
             const float4 p1 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 1) * 32 + c4 * 4);
             const float4 p2 = *reinterpret_cast<const float4 *>(ot + (tl * 4 + 2) * 32 + c4 * 4);
@@ -473,9 +471,9 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             const float4 v = make_float4(MX(MX(p0.x, p1.x), MX(p2.x, p3.x)), MX(MX(p0.y, p1.y), MX(p2.y, p3.y)),
                                          MX(MX(p0.z, p1.z), MX(p2.z, p3.z)), MX(MX(p0.w, p1.w), MX(p2.w, p3.w)));
 #undef MX
-            float *dst = d.y_pool + (int64_t)img0 * PHo * PWo * d.Nc + (m24(im, m24(PHo, PWo) * d.Nc) + m24(m24(gy, PWo) + gx, d.Nc) + n);
+            float *dst = d.y_pool + ((int64_t)img0 * PHo * PWo + (int64_t)ty0 * PWo + tx0) * d.Nc + n0 + e.x;
             if ((d.Nc & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
-            else { dst[0] = v.x; if (n + 1 < d.Nc) dst[1] = v.y; if (n + 2 < d.Nc) dst[2] = v.z; if (n + 3 < d.Nc) dst[3] = v.w; }
+            else { dst[0] = v.x; if (nrem > 1) dst[1] = v.y; if (nrem > 2) dst[2] = v.z; if (nrem > 3) dst[3] = v.w; }
         }
     }
 }
@@ -543,7 +541,7 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
     g.n_nt = cdiv(d.Nc, 32);
     g.n_btiles = g.bx * g.by * g.bi;
     g.cpx = cdiv(g.n_btiles, kNumXCD);
-    g.tab = nullptr;
+    g.tab = nullptr; g.ftab = nullptr; g.stab = g.ptab = nullptr;
     g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
     return true;
 }
@@ -629,10 +627,9 @@ const WinoPlan &cached_plan(const ConvDesc &d) {
     return it->second;
 }
 
-// DMA table of a plan for input row pitch ldx (floats): same arithmetic the kernel used to run per block
-// (piece g = 4 pixel pairs x 16 slots; slot = (pixel of the pair, 4-channel group) XOR-swizzled by the pair's key)
-std::vector<uint2> build_dma_table(const WinoGeom &g, int H, int W, int64_t ldx, int npieces) {
-    std::vector<uint2> t((size_t)npieces * 64);
+// ---- per-plan lane tables (host): the index arithmetic the kernel used to run per block, once per plan.
+// DMA: piece g = 4 pixel pairs x 16 slots; slot = (pixel of the pair, 4-channel group) XOR-swizzled by the pair's key
+void build_dma_table(const WinoGeom &g, int H, int W, int64_t ldx, int npieces, uint2 *t) {
     const int per = g.TY * g.TX;
     for (int gi = 0; gi < npieces; ++gi)
         for (int lane = 0; lane < 64; ++lane) {
@@ -648,25 +645,90 @@ std::vector<uint2> build_dma_table(const WinoGeom &g, int H, int W, int64_t ldx,
             if (2 * pp >= g.npix) e.y = 0xffffu;           // padding lane: masked on the edge path too
             t[(size_t)gi * 64 + lane] = e;
         }
-    return t;
 }
 
-// device copy per (geometry, row pitch, device); lives as long as the library
-int dma_table(const ConvDesc &d, const WinoPlan &p, const uint2 **out) {
+// fragment byte offsets of lane (tile fm, k-half fh) of wave (mt, a): rows rA / rB of B^T row a, column pairs tx, tx + 1
+void build_frag_table(const WinoGeom &g, int MT, int4 *t) {
+    const int per = g.TY * g.TX;
+    for (int wv = 0; wv < 4 * MT; ++wv)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int mt = MT == 2 ? (wv & 1) : 0, a = MT == 2 ? (wv >> 1) : wv;
+            const int fm = lane & 31, fh = lane >> 5;
+            const int rA = a == 0 ? 0 : a == 2 ? 2 : 1, rB = a == 3 ? 3 : a == 2 ? 1 : 2;
+            int tl = mt * 32 + fm;
+            if (tl >= g.ntiles) tl = 0;
+            const int im = tl / per, rem = tl % per, ty = rem / g.TX, tx = rem % g.TX;
+            int o[2][2];
+            for (int r = 0; r < 2; ++r)
+                for (int c = 0; c < 2; ++c) {
+                    const int py = 2 * ty + (r == 0 ? rA : rB), pxh = tx + c;
+                    const int pp = (im * g.PH + py) * (g.PW / 2) + pxh;
+                    const int key = (pxh + (py >> 1) * g.TX + im * per) & 15;
+                    o[r][c] = pp * 256 + ((fh ^ key) << 4);
+                }
+            t[wv * 64 + lane] = make_int4(o[0][0], o[0][1], o[1][0], o[1][1]);
+        }
+}
+
+// output side: thread tid stores 16 B of (tile, pixel) = ((tid + q * NTHR) >> 5, ((tid + q * NTHR) >> 3) & 3) for q = 0..3 and
+// pools tile tid >> 3; offsets in floats relative to the block's output origin and 4-channel group 0
+void build_store_tables(const WinoGeom &g, int nthr, int OH, int OW, int64_t ldy, int Nc, uint2 *st, uint2 *pt) {
+    const int per = g.TY * g.TX, PHo = OH / 2, PWo = OW / 2;
+    for (int q = 0; q < 4; ++q)
+        for (int tid = 0; tid < nthr; ++tid) {
+            const int idx = tid + q * nthr, c4 = idx & 7, pl = idx >> 3, pix = pl & 3, tl = pl >> 2;
+            uint2 e = {0u, 0xffffffffu};
+            if (tl < g.ntiles) {
+                const int im = tl / per, rem = tl % per, ty = rem / g.TX, tx = rem % g.TX;
+                const int oy = 2 * ty + (pix >> 1), ox = 2 * tx + (pix & 1);
+                e.x = (unsigned)((((int64_t)im * OH + oy) * OW + ox) * ldy + c4 * 4);
+                e.y = (unsigned)oy | ((unsigned)ox << 8) | ((unsigned)im << 16);
+            }
+            st[q * nthr + tid] = e;
+        }
+    for (int tid = 0; tid < nthr; ++tid) {
+        const int c4 = tid & 7, tl = tid >> 3;
+        uint2 e = {0u, 0xffffffffu};
+        if (tl < g.ntiles) {
+            const int im = tl / per, rem = tl % per, ty = rem / g.TX, tx = rem % g.TX;
+            e.x = (unsigned)((((int64_t)im * PHo + ty) * PWo + tx) * Nc + c4 * 4);
+            e.y = (unsigned)ty | ((unsigned)tx << 8) | ((unsigned)im << 16);
+        }
+        pt[tid] = e;
+    }
+}
+
+// one device allocation per (geometry, pitches, device), living as long as the library
+struct WinoTables { const uint2 *tab; const int4 *ftab; const uint2 *stab, *ptab; };
+int plan_tables(const ConvDesc &d, const WinoPlan &p, WinoTables *out) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int, int64_t, int>, const uint2 *> cache;
+    static std::map<std::tuple<int, int, int, int, int, int64_t, int64_t, int>, WinoTables> cache;
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, d.ldx, dev);
+    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, d.ldx, d.ldy, dev);
     auto it = cache.find(key);
     if (it == cache.end()) {
-        const int npieces = p.c.ND * 4 * p.c.MT;
-        const std::vector<uint2> host = build_dma_table(p.g, d.H, d.W, d.ldx, npieces);
+        const int MT = p.c.MT, npieces = p.c.ND * 4 * MT, nthr = 256 * MT;
+        const size_t n_dma = (size_t)npieces * 64, n_frag = (size_t)4 * MT * 64, n_st = (size_t)4 * nthr, n_pt = nthr;
+        std::vector<char> host(n_dma * 8 + n_frag * 16 + (n_st + n_pt) * 8);
+        char *h = host.data();
+        uint2 *h_dma = reinterpret_cast<uint2 *>(h);
+        int4 *h_frag = reinterpret_cast<int4 *>(h + n_dma * 8);
+        uint2 *h_st = reinterpret_cast<uint2 *>(h + n_dma * 8 + n_frag * 16), *h_pt = h_st + n_st;
+        build_dma_table(p.g, d.H, d.W, d.ldx, npieces, h_dma);
+        build_frag_table(p.g, MT, h_frag);
+        build_store_tables(p.g, nthr, d.OH, d.OW, d.ldy, d.Nc, h_st, h_pt);
         void *dp = nullptr;
-        EVFLY_HIP(hipMalloc(&dp, host.size() * sizeof(uint2)));
-        EVFLY_HIP(hipMemcpy(dp, host.data(), host.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        it = cache.emplace(key, static_cast<const uint2 *>(dp)).first;
+        EVFLY_HIP(hipMalloc(&dp, host.size()));
+        EVFLY_HIP(hipMemcpy(dp, host.data(), host.size(), hipMemcpyHostToDevice));
+        char *b = static_cast<char *>(dp);
+        WinoTables t;
+        t.tab = reinterpret_cast<const uint2 *>(b);
+        t.ftab = reinterpret_cast<const int4 *>(b + n_dma * 8);
+        t.stab = reinterpret_cast<const uint2 *>(b + n_dma * 8 + n_frag * 16);
+        t.ptab = t.stab + n_st;
+        it = cache.emplace(key, t).first;
     }
     *out = it->second;
     return 0;
@@ -694,8 +756,9 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
                 d.NI, d.OH, d.OW, d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, lds, nb);
     }
     WinoGeom gg = g;
-    if (!ONE)
-        if (int rc = dma_table(d, p, &gg.tab)) return rc;
+    WinoTables tb;
+    if (int rc = plan_tables(d, p, &tb)) return rc;
+    gg.tab = tb.tab; gg.ftab = tb.ftab; gg.stab = tb.stab; gg.ptab = tb.ptab;
     hipLaunchKernelGGL(kern, dim3(kNumXCD * g.cpx * g.n_nt), dim3(256 * MT), lds, st, d, U, gg);
     EVFLY_LAUNCH_CHECK();
     return 0;
