@@ -66,6 +66,7 @@ struct WinoGeom {
     int bx, by, bi;             // blocks along x, y, image groups
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
+    unsigned u_nnt, u_bx, u_by;  // floor(2^32 / x) + 1 for x = n_nt, bx, by (unused for x = 1)
     double cost;                // plan cost (launched tile slots + weighted patch pixels)
     // per-plan DMA table (device memory, built once per plan / row pitch / device): entry (piece g, lane l) =
     // { byte offset of the lane's 16 B relative to the block's patch origin (0x7ffffff0: padding lane), py | px << 8 }
@@ -209,9 +210,14 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)patch;        // LDS byte address of buffer 0
 
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
-    const int bt = xcd * g.cpx + slot / g.n_nt, nt = slot % g.n_nt;
+    // (scalar magic-number divisions: floor(v / x) == umulhi(v, ceil(2^32 / x)) for every v the launcher admits; a
+    // run-time `/` costs ~25 VALU + SALU instructions each, at the head of the block's critical path)
+    auto udiv = [](int v, int x, unsigned m) { return x == 1 ? v : (int)__umulhi((unsigned)v, m); };
+    const int sq = udiv(slot, g.n_nt, g.u_nnt);
+    const int bt = xcd * g.cpx + sq, nt = slot - sq * g.n_nt;
     if (bt >= g.n_btiles) return;
-    const int bxi = bt % g.bx, byi = (bt / g.bx) % g.by, big = bt / (g.bx * g.by);
+    const int rowq = udiv(bt, g.bx, g.u_bx), bxi = bt - rowq * g.bx;
+    const int big = udiv(rowq, g.by, g.u_by), byi = rowq - big * g.by;
     const int img0 = big * g.IMGS, ty0 = byi * g.TY, tx0 = bxi * g.TX;
     const int n0 = nt * 32;
 
@@ -542,6 +548,10 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
     g.n_btiles = g.bx * g.by * g.bi;
     g.cpx = cdiv(g.n_btiles, kNumXCD);
     g.tab = nullptr; g.ftab = nullptr; g.stab = g.ptab = nullptr;
+    // umulhi(v, floor(2^32 / x) + 1) == v / x while v * x < 2^32 (v < 2^21, x < 2^11 here: block / slot indices against
+    // block counts; checked exhaustively for x < 2000 on the host); x = 1 would need 2^32: the kernel returns v itself
+    auto magic32 = [](int x) -> unsigned { return x <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)x + 1); };
+    g.u_nnt = magic32(g.n_nt); g.u_bx = magic32(g.bx); g.u_by = magic32(g.by);
     g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
     return true;
 }
@@ -780,6 +790,8 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
     EVFLY_REQUIRE(p.ok, "wino: no tile plan");
     EVFLY_REQUIRE(p.g.ngroups <= p.c.ND * 4 * p.c.MT, "wino: patch exceeds the DMA piece budget");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
+    EVFLY_REQUIRE((int64_t)p.g.n_btiles * p.g.n_nt < (1 << 21) && p.g.bx < 2048 && p.g.by < 2048 && p.g.n_nt < 2048,
+                  "wino: grid too large for the 32-bit magic divisions");
     EVFLY_REQUIRE((int64_t)d.OH * d.OW * d.ldy < (1 << 24) && (int64_t)d.H * d.W * d.ldx < (1 << 24),
                   "wino: image larger than 2^24 floats (24-bit index arithmetic)");
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
