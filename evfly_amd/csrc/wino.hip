@@ -42,7 +42,7 @@
 #include <vector>
 
 // Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 no patch DMA,
-// 4 no global stores, 8 no LDS fragment reads, 16 no U loads, 64 no chunk barrier. The shipped library is built with 0.
+// 4 no global stores, 8 no LDS fragment reads, 16 no U loads, 64 no chunk barrier, 512 no epilogue. The shipped library is built with 0.
 #ifndef EVFLY_WINO_ABL
 #define EVFLY_WINO_ABL 0
 #endif
@@ -401,6 +401,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     // drain the slack refills before their registers die
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
 
+    if constexpr (kAbl & 512) {      // ablation: no epilogue at all (keeps the accumulators alive through one store)
+        if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) d.y[0] = 1.f;
+        return;
+    }
     // ---- output transform. Lane-local along b: s0 = M_a0 + M_a1 + M_a2, s1 = M_a1 - M_a2 - M_a3. Along a the four
     // waves of an M-tile trade through LDS; wave a owns output pixel (i, x) = (a >> 1, a & 1) of every tile:
     //   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
