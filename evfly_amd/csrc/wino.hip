@@ -117,6 +117,10 @@ __device__ __forceinline__ void chunk_barrier() {
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NKEEP) : "memory");
 }
 
+// workgroup barrier for LDS hand-offs inside the epilogue: LDS operations only -- the epilogue's operand loads (bias, store
+// tables) keep flying across it (`__syncthreads()` would drain them: its fence waits for every outstanding memory operation)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // input formation of learner_models.py:476-494 (identical to ops.hip form_value; kept local so the fused producer
 // below is bitwise the arithmetic of k_e11)
 __device__ __forceinline__ float wino_form_value(float x, int form_bev, int apply_form, float cutoff) {
@@ -409,7 +413,15 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     // waves of an M-tile trade through LDS; wave a owns output pixel (i, x) = (a >> 1, a & 1) of every tile:
     //   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
     // sets in LDS: k0 = s_01, k1 = s_10, k2 = s_11, k3 = s_20, k4 = s_21, k5 = s_30
-    __syncthreads();
+    // The epilogue's global operands are requested first and land under the transform (the vector-memory queue is empty
+    // here, so hipcc's own waits are exact again): bias, and this thread's store / pool table entries.
+    const bool nokl = n0 + fm < d.Nc;
+    const float bias = (d.bias && nokl) ? d.bias[n0 + fm] : 0.f;
+    uint2 se[4], pe = {0u, 0xffffffffu};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) se[q] = g.stab[q * NTHR + tid];
+    if (d.y_pool) pe = g.ptab[tid];
+    lds_barrier();
     float4 *xch = reinterpret_cast<float4 *>(smem);   // [mt MT][set 6][r / 4][lane 64] float4 (r % 4)  = MT x 24 KB
     auto at4 = [&](int k, int q) -> float4 & { return xch[((mt * 6 + k) * 4 + q) * 64 + lane]; };   // 16-B LDS accesses
     float own[16];
@@ -430,11 +442,9 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
 #pragma unroll
         for (int i = 0; i < 4; ++i) own[4 * q + i] = a == 0 ? s0[i] : a == 1 ? s1[i] : a == 2 ? -s0[i] : -s1[i];
     }
-    __syncthreads();
+    lds_barrier();
     const int kA = a == 0 ? 1 : a == 1 ? 0 : a == 2 ? 1 : 2, kB = a == 0 ? 3 : a == 1 ? 4 : a == 2 ? 5 : 4;
     const float sB = a < 2 ? 1.f : -1.f;
-    const bool nokl = n0 + fm < d.Nc;
-    const float bias = (d.bias && nokl) ? d.bias[n0 + fm] : 0.f;
     // finished pixels go to LDS as [tile 64][pixel 4][channel 32] so that the global stores are 16-B vectors and the
     // index arithmetic runs once per four channels instead of once per value
     float *ot = smem + MT * 6 * 16 * 64;               // MT x 16 KB behind the exchange sets
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             ot[(tl * 4 + a) * 32 + fm] = apply_act(y, ACT >= 0 ? ACT : d.act);
         }
     }
-    __syncthreads();
+    lds_barrier();
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
     // output origin of the block (wave-uniform); per-thread offsets and coordinates come from the plan's tables
     const int oy0 = 2 * ty0, ox0 = 2 * tx0;
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const int hrem = d.OH - oy0, wrem = d.OW - ox0, irem = d.NI - img0, nrem = d.Nc - n0 - (tid & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint2 e = g.stab[q * NTHR + tid];
+        const uint2 e = se[q];
         const bool ok = e.y != 0xffffffffu && (int)(e.y & 0xffu) < hrem && (int)((e.y >> 8) & 0xffu) < wrem && (int)(e.y >> 16) < irem &&
                         nrem > 0 && !(kAbl & 4);
         if (!ok) continue;
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     }
     if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): the window is the Winograd tile; NaN wins like in torch
         const int PHo = d.OH / 2, PWo = d.OW / 2;
-        const uint2 e = g.ptab[tid];
+        const uint2 e = pe;
         const bool ok = e.y != 0xffffffffu && (int)(e.y & 0xffu) < PHo - ty0 && (int)((e.y >> 8) & 0xffu) < PWo - tx0 && (int)(e.y >> 16) < irem &&
                         nrem > 0 && !(kAbl & 4);
         if (ok) {
