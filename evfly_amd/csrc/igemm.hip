@@ -14,6 +14,8 @@
 // shared by neighbouring pixel tiles are re-read from that XCD's L2, not from HBM.
 #include "igemm.h"
 
+#include <atomic>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -600,11 +602,15 @@ int launch_cfg(const ConvDesc &d, hipStream_t st) {
     const int cpx = cdiv(n_mt, kNumXCD);
     const int lds = NBUF * (BM + BN) * BK * (PREC == 1 ? 2 : 4);
     auto kern = k_igemm<BM, BN, WAVES_M, WAVES_N, VEC, PREC, NBUF>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
+    // per instantiation and per device (the > 64 KB dynamic-LDS opt-in is a per-device function attribute)
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     static const int dbg = getenv("EVFLY_IGEMM_DBG") ? atoi(getenv("EVFLY_IGEMM_DBG")) : 0;
     // few tiles but a long K loop (ViT reduction convs, decoder Linear, small-batch deep layers): split K so that

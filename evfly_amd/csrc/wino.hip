@@ -34,6 +34,7 @@
 #include "igemm.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -767,10 +768,14 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
     if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
         lds = std::max(lds, buf + (d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
     auto kern = k_wino9<MT, ND, ONE, ACT>;
-    static bool lds_set = false;
-    if (!lds_set) {
+    // the > 64 KB dynamic-LDS opt-in is per device (one process may drive several GPUs)
+    static std::atomic<bool> lds_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!lds_set[dev].load(std::memory_order_acquire)) {
         EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        lds_set = true;
+        lds_set[dev].store(true, std::memory_order_release);
     }
     static const bool dbg = getenv("EVFLY_WINO_DBG") != nullptr;
     if (dbg) {
