@@ -1,4 +1,4 @@
-# usage: bash tools/scripts/abl_sweep.sh <reps> <layer ...>  -- Winograd kernel ablation builds (libevfly_abl<bits>.so, see EVFLY_WINO_ABL in wino.hip)
+# usage: bash tools/scripts/abl_sweep.sh <reps> <layer ...>  -- times every ablation build present (tools/scripts/build_abl.sh; EVFLY_WINO_ABL in wino.hip)
 cd $GRAFT_REPO_ROOT
 R=$1; shift
 for a in $(ls evfly_amd/libevfly_abl*.so | sed 's/.*libevfly_//; s/.so//'); do
