@@ -343,6 +343,27 @@ def test_multi_stream_matches_per_stream_oracle(gpu_device):
     assert rel_err(vp.reshape(S, T, 3).cpu(), v.reshape(S, T, 3)[perm].cpu()) < 1e-6
 
 
+def test_full_batch_is_bitwise_reproducible(gpu_device):
+    """C2-sized call (64 streams x 5 windows) three times on the same input: depth, velocity and states bit-identical.
+    The Winograd kernel counts its own vector-memory queue and hands tiles over through LDS with raw barriers; a missing
+    wait or barrier shows up as run-to-run differences long before it shows up as a tolerance failure."""
+    net, sd = _composite(gpu_device)
+    S, T = 64, 5
+    base = cond_frames(97, 8 * T)
+    idx = torch.arange(S) % 8
+    x = base.reshape(8, T, 1, 260, 346)[idx].reshape(S * T, 1, 260, 346).to(gpu_device)
+    desvel = torch.full((S * T, 1), 4.0, device=gpu_device)
+    outs = []
+    for _ in range(3):
+        v, (d, up, ((hu, _), (lh, lc))) = net.forward_streams([x, desvel, [None, None], None], S, T)
+        outs.append((v.clone(), d.clone(), up.clone(), hu[0][0].clone(), lh.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+    v = outs[0][0].reshape(S, T, 3)
+    assert torch.equal(v[:8], v[8:16]) and torch.equal(v[:8], v[56:64])      # tiled streams: identical rows, wherever they sit
+
+
 def test_stream_chunking_matches_unchunked(gpu_device):
     """More than 320 frames in one call: the library walks the streams in chunks (model.hip kChunkFrames) with state
     slices per chunk. 66 streams x 5 steps = 64 + 2 streams; every stream must equal the same stream run in a small
