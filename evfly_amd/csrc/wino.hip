@@ -132,6 +132,15 @@ __device__ __forceinline__ float wino_form_value(float x, int form_bev, int appl
     return x > 0.0f ? x : 0.0f;
 }
 
+// ---- phase timestamps (developer build: -DEVFLY_WINO_TS; tools/wino_ts.py). Every wave of the first 16384 blocks records
+// s_memtime at eight phase boundaries; read back with evfly_debug_wino_ts.
+#ifdef EVFLY_WINO_TS
+__device__ unsigned long long g_wino_ts[16384 * 8 * 8];
+#define WINO_TS(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_[i] = t_; } while (0)
+#else
+#define WINO_TS(i) do { } while (0)
+#endif
+
 // ---- fused first U-Net conv (learner_models.py:476-494,533): stage the formed (PH + 2) x (PW + 2) frame patch and
 // the 9 * CIN x 32 weights in LDS behind the patch buffer, then every thread computes (pixel pair, 4-channel chunk)
 // items of the swizzled patch directly. Same fmaf order as k_e11 (ky, kx, ci): bitwise the unfused result.
@@ -203,7 +212,7 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
 // <= 168 registers per wave (room to fetch the next quarter's fragments under the current quarter's MFMAs); MT = 2
 // blocks two per CU and single-chunk MT = 1 blocks four per CU with <= 128.
 // ACT = the activation compiled in (ACT_RELU: every U-Net layer) or -1 = d.act at run time.
-template <int MT, int ND, bool ONE, int ACT>
+template <int MT, int ND, bool ONE, bool PRE, int ACT>
 __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT == 2 || ONE) ? 4 : 3, (MT == 2 || ONE) ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
     constexpr int NW = 4 * MT, NTHR = 256 * MT;
     // next quarter's fragments fetched under the current quarter's second half-step: only where 168 registers allow it
@@ -214,6 +223,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     float *patch = smem;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)patch;        // LDS byte address of buffer 0
 
+#ifdef EVFLY_WINO_TS
+    unsigned long long ts_[8] = {};
+#endif
+    WINO_TS(0);
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
     // (scalar magic-number divisions: floor(v / x) == umulhi(v, ceil(2^32 / x)) for every v the launcher admits; a
     // run-time `/` costs ~25 VALU + SALU instructions each, at the head of the block's critical path)
@@ -244,8 +257,13 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     // B^T row a: t = d[rA] + sg * d[rB]   (a = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
     // (rows rA = 0, 1, 2, 1 and rB = 2, 2, 1, 3 of the patch: in the plan's fragment table)
     const float sg = a == 1 ? 1.f : -1.f;
+    // (single-chunk kernels request it behind the patch DMA instead: in front of it, hipcc's wait for this load -- it cannot
+    // see the asm loads around it -- sat before the DMA issue, one L2 round trip on the block's critical path)
+    // There the load is inline asm as well (an ordinary load behind the asm DMA makes hipcc drain the whole queue before
+    // issuing it); it lands under the chunk-0 barrier's vmcnt(0) and is named again below that barrier.
     int off0[2][2];
-    {
+    i32x4 ftv = {0, 0, 0, 0};
+    if constexpr (TABLE) {
         const int4 f = g.ftab[wv * 64 + lane];          // (row rA / rB) x (column pair 0 / 1) of this lane's tile
         off0[0][0] = f.x; off0[0][1] = f.y; off0[1][0] = f.z; off0[1][1] = f.w;
     }
@@ -255,19 +273,31 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const int nchunks = d.C / 32;
     const int iy0 = 2 * ty0, ix0 = 2 * tx0;
 
+    // U stream: [nt][cc][j][hg][pos pair 8][lane 64][pos 2][2]; this wave reads pairs 2a, 2a + 1 (positions 4a .. 4a+3):
+    // two 16-B loads 1 KiB apart per half-step, 8 KiB per half-step
+    const float *ub = U + (((int64_t)nt * nchunks * 8 * 8 + 2 * a) * 64) * 4;
+    const unsigned ulane = lane * 16;
+    f32x4 bcur[2] = {};
+    auto u_first = [&]() {
+        u_load<0>(bcur[0], ulane, ub); u_load<1024>(bcur[1], ulane, ub);
+        ub += 16 * 64 * 2;
+    };
+
     // ---- patch: either produced from the raw frame (fused first conv, single-chunk layers only) or DMA'd. Descriptor
     // over the block's images, per-lane byte offsets of this wave's ND pieces.
     i32x4 srd = {0, 0, 0, 0};
     unsigned voff[ND] = {};
-    bool produced = false;
-    if constexpr (ONE) {
-        if (d.pre_frames) {
-            if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
-            else produce_patch<2, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
-            produced = true;
-        }
+    constexpr bool produced = PRE;      // PRE (with ONE): the fused first conv writes the patch; its own kernel variant, so that
+                                        // the DMA variants carry neither its code nor hipcc's conservative waits at the join
+    if constexpr (PRE) {
+        if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
+        else produce_patch<2, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
     }
-    if (!produced) {
+    // single-chunk kernels: the first U loads go out BEFORE the patch offsets are computed (their L2 round trip runs under
+    // that arithmetic and the DMA); the chunk-0 barrier then waits for everything (the DMA is the youngest operation)
+    constexpr bool u_early = ONE && !produced;
+    if constexpr (u_early) u_first();
+    if constexpr (!produced) {
         // descriptor from the block's patch origin (img0, iy0, ix0) to the end of its image group: images past the batch
         // and rows past the last image fall out of range by themselves; what is left to mask is the patch hanging over the
         // right / bottom edge of an image -- edge blocks only. The per-lane offsets come from the plan's table (the mul-shift
@@ -307,21 +337,18 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     auto dma = [&](int cc, bool live) {
         if constexpr (kAbl & 1) return;
         const unsigned dst = lds0 + (unsigned)((cc & 1) * BUF_FLOATS * 4) + (unsigned)wv * 1024u;
+        i32x4 sd = srd;
+        sd[2] = live ? srd[2] : 0;       // behind the last chunk: an empty descriptor (scalar select; a per-lane one is ND v_cndmask)
 #pragma unroll
         for (int i = 0; i < ND; ++i)
-            dma_piece(live ? voff[i] : 0x7ffffff0u, srd, __builtin_amdgcn_readfirstlane(cc * 128),
-                      __builtin_amdgcn_readfirstlane(dst + (unsigned)(i * NW) * 1024u));
+            dma_piece(voff[i], sd, __builtin_amdgcn_readfirstlane(cc * 128), __builtin_amdgcn_readfirstlane(dst + (unsigned)(i * NW) * 1024u));
     };
 
-    // U stream: [nt][cc][j][hg][pos pair 8][lane 64][pos 2][2]; this wave reads pairs 2a, 2a + 1 (positions 4a .. 4a+3):
-    // two 16-B loads 1 KiB apart per half-step, 8 KiB per half-step
-    const float *ub = U + (((int64_t)nt * nchunks * 8 * 8 + 2 * a) * 64) * 4;
-    const unsigned ulane = lane * 16;
-    f32x4 bcur[2] = {};
-
-    if (!produced) dma(0, true);
-    u_load<0>(bcur[0], ulane, ub); u_load<1024>(bcur[1], ulane, ub);
-    ub += 16 * 64 * 2;
+    if constexpr (!produced) dma(0, true);
+    if constexpr (!u_early) u_first();
+    if constexpr (!TABLE)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ftv) : "v"((unsigned)(wv * 64 + lane) * 16u), "s"(g.ftab));
+    WINO_TS(1);
 
     f32x4 fu[4], fv[4];           // raw fragment rows rA / rB of the four patch columns
     // fragment addresses of the current chunk: off0 + buffer offset, passed through `opaque` ONCE per chunk (LICM would
@@ -385,7 +412,14 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     // (FIRST): its first half-step initialises the accumulators.
     auto chunk = [&](int cc, auto first) {
         constexpr bool FIRST = decltype(first)::value;
-        chunk_barrier<2>();          // chunk cc has landed; everyone is done reading the other buffer
+        // chunk cc has landed; everyone is done reading the other buffer
+        if constexpr (ONE) {
+            // (the fragment-table load sits behind the U loads: produced patch -> queue U0 U1 T, else U0 U1 DMA.. T)
+            chunk_barrier<0>();
+            asm volatile("" : "+v"(ftv));
+            off0[0][0] = ftv[0]; off0[0][1] = ftv[1]; off0[1][0] = ftv[2]; off0[1][1] = ftv[3];
+        } else chunk_barrier<2>();
+        if constexpr (FIRST) WINO_TS(2);
         set_frag_base((cc & 1) * BUF_FLOATS * 4);
         if constexpr (!ONE) dma(cc + 1, cc + 1 < nchunks);
         read_frag(0);
@@ -404,7 +438,9 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     if constexpr (!ONE)
         for (int cc = 1; cc < nchunks; ++cc) chunk(cc, std::false_type{});
     // drain the slack refills before their registers die
+    WINO_TS(3);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
+    WINO_TS(4);
 
     if constexpr (kAbl & 512) {      // ablation: no epilogue at all (keeps the accumulators alive through one store)
         if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) d.y[0] = 1.f;
@@ -423,6 +459,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     for (int q = 0; q < 4; ++q) se[q] = g.stab[q * NTHR + tid];
     if (d.y_pool) pe = g.ptab[tid];
     lds_barrier();
+    WINO_TS(5);
     float4 *xch = reinterpret_cast<float4 *>(smem);   // [mt MT][set 6][r / 4][lane 64] float4 (r % 4)  = MT x 24 KB
     auto at4 = [&](int k, int q) -> float4 & { return xch[((mt * 6 + k) * 4 + q) * 64 + lane]; };   // 16-B LDS accesses
     float own[16];
@@ -461,21 +498,35 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         }
     }
     lds_barrier();
+    WINO_TS(6);
+    // the table entries landed long ago; name them all here so that hipcc's wait for them sits in front of the first
+    // store -- placed per entry between the stores, its (in-order) vmcnt arithmetic makes store q wait for the
+    // acknowledgement of stores 0 .. q-2 (measured: 3.5 k of a single-chunk block's 28 k cycles)
+    asm volatile("" : "+v"(se[0].x), "+v"(se[0].y), "+v"(se[1].x), "+v"(se[1].y), "+v"(se[2].x), "+v"(se[2].y), "+v"(se[3].x), "+v"(se[3].y),
+                 "+v"(pe.x), "+v"(pe.y));
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
     // output origin of the block (wave-uniform); per-thread offsets and coordinates come from the plan's tables
     const int oy0 = 2 * ty0, ox0 = 2 * tx0;
     float *ybase = d.y + ((int64_t)img0 * d.OH * d.OW + (int64_t)oy0 * d.OW + ox0) * d.ldy + n0;
     const int hrem = d.OH - oy0, wrem = d.OW - ox0, irem = d.NI - img0, nrem = d.Nc - n0 - (tid & 7) * 4;
+    // (two copies of the loop: with the vector / scalar choice inside it hipcc merges the two into a dwordx3 + a
+    // conditional dword store per entry)
+    auto store_ok = [&](uint2 e) {
+        return e.y != 0xffffffffu && (int)(e.y & 0xffu) < hrem && (int)((e.y >> 8) & 0xffu) < wrem && (int)(e.y >> 16) < irem && nrem > 0 &&
+               !(kAbl & 4);
+    };
+    if (vec) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint2 e = se[q];
-        const bool ok = e.y != 0xffffffffu && (int)(e.y & 0xffu) < hrem && (int)((e.y >> 8) & 0xffu) < wrem && (int)(e.y >> 16) < irem &&
-                        nrem > 0 && !(kAbl & 4);
-        if (!ok) continue;
-        const float4 v = *reinterpret_cast<const float4 *>(ot + (tid + q * NTHR) * 4);
-        float *dst = ybase + e.x;
-        if (vec) *reinterpret_cast<float4 *>(dst) = v;
-        else { dst[0] = v.x; if (nrem > 1) dst[1] = v.y; if (nrem > 2) dst[2] = v.z; if (nrem > 3) dst[3] = v.w; }
+        for (int q = 0; q < 4; ++q)
+            if (store_ok(se[q])) *reinterpret_cast<float4 *>(ybase + se[q].x) = *reinterpret_cast<const float4 *>(ot + (tid + q * NTHR) * 4);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!store_ok(se[q])) continue;
+            const float4 v = *reinterpret_cast<const float4 *>(ot + (tid + q * NTHR) * 4);
+            float *dst = ybase + se[q].x;
+            dst[0] = v.x; if (nrem > 1) dst[1] = v.y; if (nrem > 2) dst[2] = v.z; if (nrem > 3) dst[3] = v.w;
+        }
     }
     if (d.y_pool) {   // fused nn.MaxPool2d(2, 2): the window is the Winograd tile; NaN wins like in torch
         const int PHo = d.OH / 2, PWo = d.OW / 2;
@@ -497,7 +548,20 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             else { dst[0] = v.x; if (nrem > 1) dst[1] = v.y; if (nrem > 2) dst[2] = v.z; if (nrem > 3) dst[3] = v.w; }
         }
     }
+#ifdef EVFLY_WINO_TS
+    WINO_TS(7);
+    if (lane == 0 && blockIdx.x < 16384) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_wino_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_[i];
+    }
+#endif
 }
+
+#ifdef EVFLY_WINO_TS
+extern "C" int evfly_debug_wino_ts(unsigned long long *out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_ts), n * sizeof(unsigned long long));
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------- weights
 // U_ab = (G g G^T)[a][b], G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]; evaluated in double, rounded once.
@@ -759,7 +823,7 @@ int plan_tables(const ConvDesc &d, const WinoPlan &p, WinoTables *out) {
     return 0;
 }
 
-template <int MT, int ND, bool ONE, int ACT>
+template <int MT, int ND, bool ONE, bool PRE, int ACT>
 int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
     const WinoGeom &g = p.g;
     // patch buffer(s); the epilogue reuses them for the exchange sets (MT x 24 KB) + the transposed tile (MT x 16 KB)
@@ -767,7 +831,7 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
     int lds = std::max((ONE ? 1 : 2) * buf, MT * 40 * 1024);
     if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
         lds = std::max(lds, buf + (d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
-    auto kern = k_wino9<MT, ND, ONE, ACT>;
+    auto kern = k_wino9<MT, ND, ONE, PRE, ACT>;
     // the > 64 KB dynamic-LDS opt-in is per device (one process may drive several GPUs)
     static std::atomic<bool> lds_set[64];
     int dev = 0;
@@ -793,9 +857,9 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
     return 0;
 }
 
-template <int MT, int ND, bool ONE>
+template <int MT, int ND, bool ONE, bool PRE>
 int launch(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
-    return d.act == ACT_RELU ? launch_act<MT, ND, ONE, ACT_RELU>(d, U, p, st) : launch_act<MT, ND, ONE, -1>(d, U, p, st);
+    return d.act == ACT_RELU ? launch_act<MT, ND, ONE, PRE, ACT_RELU>(d, U, p, st) : launch_act<MT, ND, ONE, PRE, -1>(d, U, p, st);
 }
 
 }  // namespace
@@ -815,9 +879,10 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
                   "wino: image larger than 2^24 floats (24-bit index arithmetic)");
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
                   "wino: the fused first-conv producer needs C == 32 and 1 or 2 frame channels");
-    const bool one = d.C == 32;
-    if (p.c.MT == 2) return one ? launch<2, 5, true>(d, U, p, st) : launch<2, 5, false>(d, U, p, st);
-    return one ? launch<1, 6, true>(d, U, p, st) : launch<1, 6, false>(d, U, p, st);
+    const bool one = d.C == 32, pre = d.pre_frames != nullptr;
+    if (p.c.MT == 2)
+        return !one ? launch<2, 5, false, false>(d, U, p, st) : pre ? launch<2, 5, true, true>(d, U, p, st) : launch<2, 5, true, false>(d, U, p, st);
+    return !one ? launch<1, 6, false, false>(d, U, p, st) : pre ? launch<1, 6, true, true>(d, U, p, st) : launch<1, 6, true, false>(d, U, p, st);
 }
 
 }  // namespace evfly

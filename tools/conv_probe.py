@@ -5,14 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from evfly_amd import _lib
 
-LAYERS = {  # n, h, w, cin, cout
-    "e12": (320, 258, 344, 32, 32), "e21": (320, 128, 171, 32, 64), "e22": (320, 126, 169, 64, 64),
-    "e32": (320, 60, 81, 128, 128), "e42": (320, 27, 37, 256, 256), "e52": (320, 10, 15, 512, 512),
-    "d11": (320, 16, 26, 512, 256), "d41": (320, 72, 152, 64, 32), "d42": (320, 70, 150, 32, 32),
-    "d32": (320, 38, 78, 64, 64), "d31": (320, 40, 80, 128, 64),
-    "e31": (320, 62, 83, 64, 128), "e41": (320, 29, 39, 128, 256), "e51": (320, 12, 17, 256, 512),
-    "d12": (320, 14, 24, 256, 256), "d21": (320, 24, 44, 256, 128), "d22": (320, 22, 42, 128, 128),
-}
+from tools.conv_probe_layers import LAYERS
 name = sys.argv[1] if len(sys.argv) > 1 else "e32"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dtype = 1 if len(sys.argv) > 3 and sys.argv[3] == "bf16" else 0
