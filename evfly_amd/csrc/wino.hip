@@ -133,9 +133,9 @@ __device__ __forceinline__ float wino_form_value(float x, int form_bev, int appl
 }
 
 // ---- phase timestamps (developer build: -DEVFLY_WINO_TS; tools/wino_ts.py). Every wave of the first 16384 blocks records
-// s_memtime at eight phase boundaries; read back with evfly_debug_wino_ts.
+// s_memtime at twelve phase boundaries; read back with evfly_debug_wino_ts.
 #ifdef EVFLY_WINO_TS
-__device__ unsigned long long g_wino_ts[16384 * 8 * 8];
+__device__ unsigned long long g_wino_ts[16384 * 8 * 12];
 #define WINO_TS(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_[i] = t_; } while (0)
 #else
 #define WINO_TS(i) do { } while (0)
@@ -201,6 +201,50 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
     }
 }
 
+// ---- output transform of position row A (compile-time): lane-local sums along b, exchange along a through LDS, bias +
+// activation, finished pixels to LDS as [tile][pixel 4][channel 32] (the caller's stores read 16-B vectors from there).
+// Along b: s0 = M_a0 + M_a1 + M_a2, s1 = M_a1 - M_a2 - M_a3. Wave a owns output pixel (i, x) = (a >> 1, a & 1):
+//   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
+// sets in LDS: k0 = s_01, k1 = s_10, k2 = s_11, k3 = s_20, k4 = s_21, k5 = s_30
+template <int MT, int A>
+__device__ __forceinline__ void out_transform(const f32x16 (&acc)[4], float *smem, int mt, int lane, float bias, int act) {
+    float4 *xch = reinterpret_cast<float4 *>(smem);   // [mt MT][set 6][r / 4][lane 64] float4 (r % 4)  = MT x 24 KB
+    auto at4 = [&](int k, int q) -> float4 & { return xch[((mt * 6 + k) * 4 + q) * 64 + lane]; };   // 16-B LDS accesses
+    const int fm = lane & 31, fh = lane >> 5;
+    float own[16];          // s0 (A = 0, 2) or s1 (A = 1, 3) of this wave
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * q + i;
+            s0[i] = acc[0][r] + acc[1][r] + acc[2][r];
+            s1[i] = acc[1][r] - acc[2][r] - acc[3][r];
+            own[r] = (A & 1) ? s1[i] : s0[i];
+        }
+        const float4 v0 = make_float4(s0[0], s0[1], s0[2], s0[3]), v1 = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        if (A == 0) at4(0, q) = v1;
+        else if (A == 1) { at4(1, q) = v0; at4(2, q) = v1; }
+        else if (A == 2) { at4(3, q) = v0; at4(4, q) = v1; }
+        else at4(5, q) = v0;
+    }
+    lds_barrier();
+    constexpr int kA = A == 0 ? 1 : A == 1 ? 0 : A == 2 ? 1 : 2, kB = A == 0 ? 3 : A == 1 ? 4 : A == 2 ? 5 : 4;
+    float *ot = smem + MT * 6 * 16 * 64;               // MT x 16 KB behind the exchange sets
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 pa = at4(kA, q), pb = at4(kB, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * q + i;
+            const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            // A < 2: own + pa + pb; A >= 2: -own + pa - pb (the rows with a minus sign in A^T), same association as before
+            const float y = (A < 2 ? (own[r] + f4e(pa, i)) + f4e(pb, i) : (f4e(pa, i) - own[r]) - f4e(pb, i)) + bias;
+            ot[(tl * 4 + A) * 32 + fm] = apply_act(y, act);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- kernel
 // Block tile = MT M-tiles of 32 Winograd tiles x 32 output channels over 4*MT waves: wave = (M-tile mt, position row
 // a in 0..3), four accumulator tiles (64 registers). Everything fits in 128 VGPRs: four waves per SIMD. MT = 2
@@ -224,9 +268,15 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)patch;        // LDS byte address of buffer 0
 
 #ifdef EVFLY_WINO_TS
-    unsigned long long ts_[8] = {};
+    unsigned long long ts_[12] = {};
 #endif
     WINO_TS(0);
+    // every kernel argument the prologue reads, requested in ONE batch: left to itself hipcc sinks each s_load next to its
+    // first use, behind the block-decode branches -- five dependent scalar-memory round trips (~2.4 k cycles of a
+    // single-chunk block's 27 k) in front of the patch DMA
+    asm volatile("" :: "s"(g.n_nt), "s"(g.u_nnt), "s"(g.cpx), "s"(g.n_btiles), "s"(g.bx), "s"(g.u_bx), "s"(g.by), "s"(g.u_by), "s"(g.IMGS),
+                 "s"(g.TY), "s"(g.TX), "s"(g.PH), "s"(g.PW), "s"(g.npix), "s"(g.mPWh), "s"(g.mPH), "s"(g.ftab), "s"(g.tab), "s"(d.NI),
+                 "s"(d.H), "s"(d.W), "s"(d.ldx), "s"(d.x), "s"(d.C), "s"(U));
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
     // (scalar magic-number divisions: floor(v / x) == umulhi(v, ceil(2^32 / x)) for every v the launcher admits; a
     // run-time `/` costs ~25 VALU + SALU instructions each, at the head of the block's critical path)
@@ -234,6 +284,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const int sq = udiv(slot, g.n_nt, g.u_nnt);
     const int bt = xcd * g.cpx + sq, nt = slot - sq * g.n_nt;
     if (bt >= g.n_btiles) return;
+    WINO_TS(8);
     const int rowq = udiv(bt, g.bx, g.u_bx), bxi = bt - rowq * g.bx;
     const int big = udiv(rowq, g.by, g.u_by), byi = rowq - big * g.by;
     const int img0 = big * g.IMGS, ty0 = byi * g.TY, tx0 = bxi * g.TX;
@@ -243,30 +294,29 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const int mt = MT == 2 ? (wv & 1) : 0, a = MT == 2 ? (wv >> 1) : wv;
     const int fm = lane & 31, fh = lane >> 5;
     const int per = g.TY * g.TX;
-    // this wave's DMA table entries, requested first: their L2 round trip runs under the index arithmetic below
-    // (multi-chunk kernels only: in a single-chunk block the patch's cold round trip is the critical path, and a table
-    // load in front of the DMA issue lengthens it -- measured +7..11 % there against -1..-5 % on the multi-chunk layers)
-    constexpr bool TABLE = !ONE;
+    // ---- prologue queue, hand-counted like the rest: [table entries, fragment table] -> block decode (scalar) -> [U0, U1]
+    // -> vmcnt(2) -> patch offsets from the table -> [DMA pieces of chunk 0] -> chunk-0 barrier at vmcnt(0).
+    // The lane tables do not depend on the block: they are requested before anything else, and their L2 round trip runs
+    // under the block decode. (As ordinary loads hipcc sank them below the decode and, unable to see the asm loads around
+    // them, drained the queue in front of each; as in-register arithmetic the offsets cost ~180 VALU instructions in front
+    // of the DMA issue of a single-chunk block.) PRE: the fused producer writes the patch, no DMA table.
+    constexpr bool TABLE = !PRE;
     uint2 te[TABLE ? ND : 1];
-    if constexpr (TABLE) {
-        const uint2 *tb = g.tab + wv * 64 + lane;
+    i32x4 ftv;
+    {
+        const unsigned tl8 = (unsigned)(wv * 64 + lane) * 8u;
+        if constexpr (TABLE) {
 #pragma unroll
-        for (int i = 0; i < ND; ++i) te[i] = tb[i * NW * 64];
+            for (int i = 0; i < ND; ++i)
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(te[i]) : "v"(tl8), "s"(g.tab + i * NW * 64));
+        }
+        if constexpr (TABLE) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ftv) : "v"(2u * tl8), "s"(g.ftab));
     }
 
     // B^T row a: t = d[rA] + sg * d[rB]   (a = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
     // (rows rA = 0, 1, 2, 1 and rB = 2, 2, 1, 3 of the patch: in the plan's fragment table)
     const float sg = a == 1 ? 1.f : -1.f;
-    // (single-chunk kernels request it behind the patch DMA instead: in front of it, hipcc's wait for this load -- it cannot
-    // see the asm loads around it -- sat before the DMA issue, one L2 round trip on the block's critical path)
-    // There the load is inline asm as well (an ordinary load behind the asm DMA makes hipcc drain the whole queue before
-    // issuing it); it lands under the chunk-0 barrier's vmcnt(0) and is named again below that barrier.
-    int off0[2][2];
-    i32x4 ftv = {0, 0, 0, 0};
-    if constexpr (TABLE) {
-        const int4 f = g.ftab[wv * 64 + lane];          // (row rA / rB) x (column pair 0 / 1) of this lane's tile
-        off0[0][0] = f.x; off0[0][1] = f.y; off0[1][0] = f.z; off0[1][1] = f.w;
-    }
+    int off0[2][2];         // fragment byte offsets (row rA / rB) x (column pair 0 / 1) of this lane's tile: from ftv
 
     f32x16 acc[4];          // not zero-filled: the first half-step of chunk 0 starts every accumulator from C = 0
 
@@ -293,10 +343,13 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
         else produce_patch<2, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
     }
-    // single-chunk kernels: the first U loads go out BEFORE the patch offsets are computed (their L2 round trip runs under
-    // that arithmetic and the DMA); the chunk-0 barrier then waits for everything (the DMA is the youngest operation)
-    constexpr bool u_early = ONE && !produced;
-    if constexpr (u_early) u_first();
+    WINO_TS(9);
+    if constexpr (!produced) {
+        u_first();
+        // the tables have landed (they are older than the two U loads, which stay in flight)
+        if constexpr (ND == 5) asm volatile("s_waitcnt vmcnt(2)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(ftv));
+        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(ftv));
+    }
     if constexpr (!produced) {
         // descriptor from the block's patch origin (img0, iy0, ix0) to the end of its image group: images past the batch
         // and rows past the last image fall out of range by themselves; what is left to mask is the patch hanging over the
@@ -310,19 +363,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         srd[2] = __builtin_amdgcn_readfirstlane((int)(((int64_t)nimg * d.H * d.W - ((int64_t)iy0 * d.W + ix0)) * d.ldx * 4));
         srd[3] = 0x00020000;
         const bool interior = iy0 + g.PH <= d.H && ix0 + g.PW <= d.W;       // wave-uniform
-        if constexpr (!TABLE) {
-            const int pl = lane >> 4, sp = lane & 15, hrem = d.H - iy0, wrem = d.W - ix0;
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                const int pp = (wv + i * NW) * 4 + pl;
-                const int Y = m24(pp, g.mPWh) >> 20, pxh = pp - m24(Y, g.PW >> 1);
-                const int im = m24(Y, g.mPH) >> 20, py = Y - m24(im, g.PH);
-                const int sl = sp ^ ((pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15);
-                const int px = 2 * pxh + (sl >> 3), ch = sl & 7;
-                const bool ok = 2 * pp < g.npix && py < hrem && px < wrem;
-                voff[i] = ok ? (unsigned)(m24(m24(m24(im, d.H) + py, d.W) + px, (int)d.ldx * 4) + ch * 16) : 0x7ffffff0u;
-            }
-        } else if (interior) {
+        if (interior) {
 #pragma unroll
             for (int i = 0; i < ND; ++i) voff[i] = te[i].x;
         } else {
@@ -344,10 +385,12 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             dma_piece(voff[i], sd, __builtin_amdgcn_readfirstlane(cc * 128), __builtin_amdgcn_readfirstlane(dst + (unsigned)(i * NW) * 1024u));
     };
 
+    WINO_TS(10);
     if constexpr (!produced) dma(0, true);
-    if constexpr (!u_early) u_first();
-    if constexpr (!TABLE)
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ftv) : "v"((unsigned)(wv * 64 + lane) * 16u), "s"(g.ftab));
+    else {      // (behind the producer's own loads and waits)
+        u_first();
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ftv) : "v"((unsigned)(wv * 64 + lane) * 16u), "s"(g.ftab));
+    }
     WINO_TS(1);
 
     f32x4 fu[4], fv[4];           // raw fragment rows rA / rB of the four patch columns
@@ -412,13 +455,12 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     // (FIRST): its first half-step initialises the accumulators.
     auto chunk = [&](int cc, auto first) {
         constexpr bool FIRST = decltype(first)::value;
-        // chunk cc has landed; everyone is done reading the other buffer
-        if constexpr (ONE) {
-            // (the fragment-table load sits behind the U loads: produced patch -> queue U0 U1 T, else U0 U1 DMA.. T)
+        if constexpr (FIRST) {
+            // everything requested so far has landed: U0 U1 [DMA of chunk 0] (PRE: U0 U1 T)
             chunk_barrier<0>();
-            asm volatile("" : "+v"(ftv));
+            if constexpr (PRE) asm volatile("" : "+v"(ftv));
             off0[0][0] = ftv[0]; off0[0][1] = ftv[1]; off0[1][0] = ftv[2]; off0[1][1] = ftv[3];
-        } else chunk_barrier<2>();
+        } else chunk_barrier<2>();       // chunk cc has landed (two U refills stay in flight); everyone is done reading the other buffer
         if constexpr (FIRST) WINO_TS(2);
         set_frag_base((cc & 1) * BUF_FLOATS * 4);
         if constexpr (!ONE) dma(cc + 1, cc + 1 < nchunks);
@@ -460,43 +502,16 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     if (d.y_pool) pe = g.ptab[tid];
     lds_barrier();
     WINO_TS(5);
-    float4 *xch = reinterpret_cast<float4 *>(smem);   // [mt MT][set 6][r / 4][lane 64] float4 (r % 4)  = MT x 24 KB
-    auto at4 = [&](int k, int q) -> float4 & { return xch[((mt * 6 + k) * 4 + q) * 64 + lane]; };   // 16-B LDS accesses
-    float own[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * q + i;
-            s0[i] = acc[0][r] + acc[1][r] + acc[2][r];
-            s1[i] = acc[1][r] - acc[2][r] - acc[3][r];
-        }
-        const float4 v0 = make_float4(s0[0], s0[1], s0[2], s0[3]), v1 = make_float4(s1[0], s1[1], s1[2], s1[3]);
-        if (a == 0) at4(0, q) = v1;
-        else if (a == 1) { at4(1, q) = v0; at4(2, q) = v1; }
-        else if (a == 2) { at4(3, q) = v0; at4(4, q) = v1; }
-        else at4(5, q) = v0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) own[4 * q + i] = a == 0 ? s0[i] : a == 1 ? s1[i] : a == 2 ? -s0[i] : -s1[i];
+    // (one straight-line copy per position row: with `a` a run-time scalar the set choices below compile into ~40 scalar
+    // branches, v_cndmask chains and 4-B LDS writes)
+    const int act = ACT >= 0 ? ACT : d.act;
+    switch (a) {
+    case 0: out_transform<MT, 0>(acc, smem, mt, lane, bias, act); break;
+    case 1: out_transform<MT, 1>(acc, smem, mt, lane, bias, act); break;
+    case 2: out_transform<MT, 2>(acc, smem, mt, lane, bias, act); break;
+    default: out_transform<MT, 3>(acc, smem, mt, lane, bias, act); break;
     }
-    lds_barrier();
-    const int kA = a == 0 ? 1 : a == 1 ? 0 : a == 2 ? 1 : 2, kB = a == 0 ? 3 : a == 1 ? 4 : a == 2 ? 5 : 4;
-    const float sB = a < 2 ? 1.f : -1.f;
-    // finished pixels go to LDS as [tile 64][pixel 4][channel 32] so that the global stores are 16-B vectors and the
-    // index arithmetic runs once per four channels instead of once per value
-    float *ot = smem + MT * 6 * 16 * 64;               // MT x 16 KB behind the exchange sets
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 pa = at4(kA, q), pb = at4(kB, q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * q + i;
-            const int tl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const float y = own[r] + f4e(pa, i) + sB * f4e(pb, i) + bias;
-            ot[(tl * 4 + a) * 32 + fm] = apply_act(y, ACT >= 0 ? ACT : d.act);
-        }
-    }
+    const float *ot = smem + MT * 6 * 16 * 64;         // the transposed tile: MT x 16 KB behind the exchange sets
     lds_barrier();
     WINO_TS(6);
     // the table entries landed long ago; name them all here so that hipcc's wait for them sits in front of the first
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     WINO_TS(7);
     if (lane == 0 && blockIdx.x < 16384) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g_wino_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_[i];
+        for (int i = 0; i < 12; ++i) g_wino_ts[((size_t)blockIdx.x * 8 + wv) * 12 + i] = ts_[i];
     }
 #endif
 }
