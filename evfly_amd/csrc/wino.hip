@@ -320,12 +320,12 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
 
     f32x16 acc[4];          // not zero-filled: the first half-step of chunk 0 starts every accumulator from C = 0
 
-    const int nchunks = d.C / 32;
+    const int nchunks = (int)((unsigned)d.C >> 5);
     const int iy0 = 2 * ty0, ix0 = 2 * tx0;
 
     // U stream: [nt][cc][j][hg][pos pair 8][lane 64][pos 2][2]; this wave reads pairs 2a, 2a + 1 (positions 4a .. 4a+3):
     // two 16-B loads 1 KiB apart per half-step, 8 KiB per half-step
-    const float *ub = U + (((int64_t)nt * nchunks * 8 * 8 + 2 * a) * 64) * 4;
+    const float *ub = U + (unsigned)((nt * nchunks * 64 + 2 * a) * 256);      // (32-bit: U holds < 2^24 floats)
     const unsigned ulane = lane * 16;
     f32x4 bcur[2] = {};
     auto u_first = [&]() {
@@ -356,11 +356,14 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         // right / bottom edge of an image -- edge blocks only. The per-lane offsets come from the plan's table (the mul-shift
         // divisions they replace cost 3-8 % of a layer: measured by executing them twice).
         const int nimg = min(g.IMGS, d.NI - img0);
-        const int64_t org = ((int64_t)img0 * d.H + iy0) * d.W + ix0;
-        const uint64_t xb = (uint64_t)(uintptr_t)(d.x + org * d.ldx);
+        // (32-bit products wherever the launcher's bounds allow: one image is < 2^26 bytes, a block spans <= 4 of them;
+        // the scalar multiplies of the 64-bit forms were a third of the block decode)
+        const unsigned rowb = (unsigned)d.W * (unsigned)d.ldx * 4u, imgb = (unsigned)d.H * rowb;
+        const unsigned intra = (unsigned)iy0 * rowb + (unsigned)ix0 * (unsigned)d.ldx * 4u;
+        const uint64_t xb = (uint64_t)(uintptr_t)d.x + (uint64_t)(unsigned)img0 * imgb + intra;
         srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
         srd[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
-        srd[2] = __builtin_amdgcn_readfirstlane((int)(((int64_t)nimg * d.H * d.W - ((int64_t)iy0 * d.W + ix0)) * d.ldx * 4));
+        srd[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)nimg * imgb - intra));
         srd[3] = 0x00020000;
         const bool interior = iy0 + g.PH <= d.H && ix0 + g.PW <= d.W;       // wave-uniform
         if (interior) {
@@ -425,9 +428,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             t[c] = f32x4{fmaf(sg, fv[c].x, fu[c].x), fmaf(sg, fv[c].y, fu[c].y), fmaf(sg, fv[c].z, fu[c].z), fmaf(sg, fv[c].w, fu[c].w)};
     };
     // one half-step: channel pair e, e + 1 of the four positions (8 MFMAs); KW = operations younger than bcur[q]'s load
-    auto half_step = [&](auto kw, auto first, int hg) {
+    auto half_step = [&](auto kw, auto first, int hg, auto last) {
         constexpr int KW = decltype(kw)::value;
         constexpr bool FIRST = decltype(first)::value;      // the very first half-step of the block: accumulate from zero
+        constexpr bool LAST = decltype(last)::value;        // the last half-step of a single-chunk block: nothing left to refill
         const int e = 2 * hg;
         // column combinations of the four positions first (8 VALU), then the 8 MFMAs
         float va[4], vb[4];
@@ -438,14 +442,17 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            u_wait<KW>(bcur[q]);
+            if (LAST && q == 1) u_wait<0>(bcur[q]);        // (no refill of bcur[0] behind it: nothing younger)
+            else u_wait<KW>(bcur[q]);
             acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q], bcur[q].x, FIRST ? zero : acc[2 * q], 0, 0, 0);
             acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q], bcur[q].y, acc[2 * q], 0, 0, 0);
             acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q + 1], bcur[q].z, FIRST ? zero : acc[2 * q + 1], 0, 0, 0);
             acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q + 1], bcur[q].w, acc[2 * q + 1], 0, 0, 0);
-            // refill (one half-step of slack behind the end of U: unconditional)
-            if (q == 0) u_load<0>(bcur[0], ulane, ub);
-            else u_load<1024>(bcur[1], ulane, ub);
+            // refill (multi-chunk: unconditional, one half-step of slack behind the end of U)
+            if constexpr (!LAST) {
+                if (q == 0) u_load<0>(bcur[0], ulane, ub);
+                else u_load<1024>(bcur[1], ulane, ub);
+            }
         }
         ub += 16 * 64 * 2;
     };
@@ -468,11 +475,14 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             combine();
-            if (j == 0) half_step(std::integral_constant<int, ONE ? 1 : KDMA>{}, std::integral_constant<bool, FIRST>{}, 0);
-            else half_step(std::integral_constant<int, 1>{}, std::false_type{}, 0);
+            if (j == 0) half_step(std::integral_constant<int, ONE ? 1 : KDMA>{}, std::integral_constant<bool, FIRST>{}, 0, std::false_type{});
+            else half_step(std::integral_constant<int, 1>{}, std::false_type{}, 0, std::false_type{});
             // the next quarter's fragments fly under the second half-step where the registers allow it (MT = 1)
             if constexpr (PREFETCH == 1) { if (j < 3) read_frag(j + 1); }
-            half_step(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+            // (the last half-step of a single-chunk block waits for bcur[0] with bcur[1]'s load as the only younger operation,
+            // for bcur[1] with none)
+            if (ONE && j == 3) half_step(std::integral_constant<int, 1>{}, std::false_type{}, 1, std::true_type{});
+            else half_step(std::integral_constant<int, 1>{}, std::false_type{}, 1, std::false_type{});
             if constexpr (PREFETCH == 0) { if (j < 3) read_frag(j + 1); }
         }
     };
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         for (int cc = 1; cc < nchunks; ++cc) chunk(cc, std::false_type{});
     // drain the slack refills before their registers die
     WINO_TS(3);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
+    if constexpr (!ONE) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
     WINO_TS(4);
 
     if constexpr (kAbl & 512) {      // ablation: no epilogue at all (keeps the accumulators alive through one store)
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     uint2 se[4], pe = {0u, 0xffffffffu};
 #pragma unroll
     for (int q = 0; q < 4; ++q) se[q] = g.stab[q * NTHR + tid];
-    if (d.y_pool) pe = g.ptab[tid];
+    pe = g.ptab[tid];       // (unconditional: under `if (d.y_pool)` hipcc merges the two values with a move right behind the load -- a drained queue)
     lds_barrier();
     WINO_TS(5);
     // (one straight-line copy per position row: with `a` a run-time scalar the set choices below compile into ~40 scalar
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
     // output origin of the block (wave-uniform); per-thread offsets and coordinates come from the plan's tables
     const int oy0 = 2 * ty0, ox0 = 2 * tx0;
-    float *ybase = d.y + ((int64_t)img0 * d.OH * d.OW + (int64_t)oy0 * d.OW + ox0) * d.ldy + n0;
+    float *ybase = d.y + ((uint64_t)(unsigned)img0 * (unsigned)(d.OH * d.OW * (int)d.ldy) + (unsigned)((oy0 * d.OW + ox0) * (int)d.ldy + n0));
     const int hrem = d.OH - oy0, wrem = d.OW - ox0, irem = d.NI - img0, nrem = d.Nc - n0 - (tid & 7) * 4;
     // (two copies of the loop: with the vector / scalar choice inside it hipcc merges the two into a dwordx3 + a
     // conditional dword store per entry)
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             const float4 v = make_float4(MX(MX(p0.x, p1.x), MX(p2.x, p3.x)), MX(MX(p0.y, p1.y), MX(p2.y, p3.y)),
                                          MX(MX(p0.z, p1.z), MX(p2.z, p3.z)), MX(MX(p0.w, p1.w), MX(p2.w, p3.w)));
 #undef MX
-            float *dst = d.y_pool + ((int64_t)img0 * PHo * PWo + (int64_t)ty0 * PWo + tx0) * d.Nc + n0 + e.x;
+            float *dst = d.y_pool + ((uint64_t)(unsigned)img0 * (unsigned)(PHo * PWo * d.Nc) + (unsigned)((ty0 * PWo + tx0) * d.Nc + n0)) + e.x;
             if ((d.Nc & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
             else { dst[0] = v.x; if (nrem > 1) dst[1] = v.y; if (nrem > 2) dst[2] = v.z; if (nrem > 3) dst[3] = v.w; }
         }
