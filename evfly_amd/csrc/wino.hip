@@ -68,6 +68,7 @@ struct WinoGeom {
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
     unsigned u_nnt, u_bx, u_by;  // floor(2^32 / x) + 1 for x = n_nt, bx, by (unused for x = 1)
+    unsigned u_fhw, u_fw;        // the same for (PH + 2) * (PW + 2) and PW + 2 (fused first conv: frame patch)
     double cost;                // plan cost (launched tile slots + weighted patch pixels)
     // per-plan DMA table (device memory, built once per plan / row pitch / device): entry (piece g, lane l) =
     // { byte offset of the lane's 16 B relative to the block's patch origin (0x7ffffff0: padding lane), py | px << 8 }
@@ -152,7 +153,9 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
     const int nfr = g.IMGS * FH * FW;
     float *wl = fr + CIN * nfr;                           // [9 * CIN][32] then bias [32]
     for (int i = tid; i < nfr; i += NTHR) {
-        const int im = i / (FH * FW), rem = i - im * (FH * FW), fy = rem / FW, fx = rem - fy * FW;
+        // (floor(v / x) == umulhi(v, floor(2^32 / x) + 1) while v * x < 2^32: v < 2^15, x < 2^13 here)
+        const int im = (int)__umulhi((unsigned)i, g.u_fhw), rem = i - im * (FH * FW);
+        const int fy = (int)__umulhi((unsigned)rem, g.u_fw), fx = rem - fy * FW;
         const int img = img0 + im, gy = iy0 + fy, gx = ix0 + fx;
         const float raw = (img < d.NI && gy < d.H + 2 && gx < d.W + 2) ? d.pre_frames[((int64_t)img * (d.H + 2) + gy) * (d.W + 2) + gx] : 0.f;
 #pragma unroll
@@ -169,27 +172,45 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
         const int key = (pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15;
         const int px = 2 * pxh;
         const bool row_ok = 2 * pp < g.npix && img0 + im < d.NI && iy0 + py < d.H;
-        float a0[4], a1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a0[c] = a1[c] = bl[ch * 4 + c];
-        const float *f0 = fr + (im * FH + py) * FW + px;
+        // accumulators of the pixel pair as register pairs: (channel 0, 1) and (2, 3) of pixel 0 / pixel 1. The 72 * CIN FMAs
+        // per item run as 36 * CIN v_pk_fma_f32 with the frame value broadcast from one half of its pair (op_sel): a packed
+        // f32 op costs the SIMD what one v_fma_f32 does (tools/ubench/mfma_valu.hip). Inline asm: hipcc scalarises packed IR
+        // whose results are read element-wise. Same operands, same order (ky, kx, ci) per lane as k_e11: bitwise identical.
+        const float4 b4 = *reinterpret_cast<const float4 *>(bl + ch * 4);
+        f32x2 a0l = {b4.x, b4.y}, a0h = {b4.z, b4.w}, a1l = a0l, a1h = a0h;
+        const float *f0 = fr + (im * FH + py) * FW + px;            // even index: FW, px and the row base are even -> 8-B aligned
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            float v[CIN][4];                                  // four frame columns of this row, per input channel
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci)
+            for (int ci = 0; ci < CIN; ++ci) {
+                // four frame columns of this row: pairs (0, 1) and (2, 3)
+                const f32x2 p0 = *reinterpret_cast<const f32x2 *>(f0 + ci * nfr + ky * FW);
+                const f32x2 p1 = *reinterpret_cast<const f32x2 *>(f0 + ci * nfr + ky * FW + 2);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[ci][k] = f0[ci * nfr + ky * FW + k];
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(wl + ((ky * 3 + kx) * CIN + ci) * 32 + ch * 4);
-                    const float u0 = v[ci][kx], u1 = v[ci][kx + 1];
-                    a0[0] = fmaf(u0, w4.x, a0[0]); a0[1] = fmaf(u0, w4.y, a0[1]); a0[2] = fmaf(u0, w4.z, a0[2]); a0[3] = fmaf(u0, w4.w, a0[3]);
-                    a1[0] = fmaf(u1, w4.x, a1[0]); a1[1] = fmaf(u1, w4.y, a1[1]); a1[2] = fmaf(u1, w4.z, a1[2]); a1[3] = fmaf(u1, w4.w, a1[3]);
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((ky * 3 + kx) * CIN + ci) * 32 + ch * 4);
+                    const f32x2 wl2 = w4.xy, wh2 = w4.zw;
+                    // pixel 0 takes column kx, pixel 1 column kx + 1
+                    if (kx == 0) {
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0l) : "v"(p0), "v"(wl2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0h) : "v"(p0), "v"(wh2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1l) : "v"(p0), "v"(wl2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1h) : "v"(p0), "v"(wh2));
+                    } else if (kx == 1) {
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a0l) : "v"(p0), "v"(wl2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a0h) : "v"(p0), "v"(wh2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a1l) : "v"(p1), "v"(wl2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a1h) : "v"(p1), "v"(wh2));
+                    } else {
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0l) : "v"(p1), "v"(wl2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0h) : "v"(p1), "v"(wh2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1l) : "v"(p1), "v"(wl2));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1h) : "v"(p1), "v"(wh2));
+                    }
                 }
+            }
         }
+        const float a0[4] = {a0l.x, a0l.y, a0h.x, a0h.y}, a1[4] = {a1l.x, a1l.y, a1h.x, a1h.y};
         // NaN-propagating ReLU like torch.relu; pixels outside the (virtual) e11 map are zeros
         const bool ok0 = row_ok && ix0 + px < d.W, ok1 = row_ok && ix0 + px + 1 < d.W;
         const float4 o0 = ok0 ? make_float4(a0[0] < 0.f ? 0.f : a0[0], a0[1] < 0.f ? 0.f : a0[1], a0[2] < 0.f ? 0.f : a0[2], a0[3] < 0.f ? 0.f : a0[3])
@@ -656,6 +677,7 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
     // block counts; checked exhaustively for x < 2000 on the host); x = 1 would need 2^32: the kernel returns v itself
     auto magic32 = [](int x) -> unsigned { return x <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)x + 1); };
     g.u_nnt = magic32(g.n_nt); g.u_bx = magic32(g.bx); g.u_by = magic32(g.by);
+    g.u_fhw = magic32((g.PH + 2) * (g.PW + 2)); g.u_fw = magic32(g.PW + 2);
     g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
     return true;
 }

@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+for rep in 1 2; do for l in ${LIBS:-r2d hip}; do EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_$l.so timeout 600 python tools/conv_sweep.py 200 2>&1 | grep -v amdgpu | awk -v l=$l '{printf "%s %s %s\n", l, $1, $2}' ; done; done
