@@ -1,6 +1,6 @@
 // Frame conditioning (gfx950): uint8 decode, centre crop, exact per-frame quantile of |v| by
 // LDS radix select (no sort), scale + clip. One 1024-thread block per frame; the frame is
-// re-read from L2 for each of the four 8-bit select passes (360 KB at 260x346).
+// re-read from L2 for each of the three select passes (11 + 11 + 10 key bits; 360 KB at 260x346).
 //
 // Replaces evfly_ros/run.py:334-336,345-350,247-253 (twins envtest/ros/run_competition.py:485-495,
 // learner/dataloading.py:512-523).
@@ -11,6 +11,7 @@ namespace evfly {
 namespace {
 
 constexpr int kCondThreads = 1024;
+constexpr int kCondBins = 2048;     // 11 key bits per select pass (three passes over the frame instead of four 8-bit ones)
 constexpr int kBatch = 6;   // columns fetched per lane before binning (6 x 64 >= 346)
 
 struct CondArgs {
@@ -28,8 +29,8 @@ __device__ __forceinline__ float cond_load(const CondArgs &a, int frame, int r, 
 }
 
 __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
-    __shared__ unsigned hist[2][256];
-    __shared__ unsigned prefix[2], kth[2];
+    __shared__ __attribute__((aligned(16))) unsigned hist[2][kCondBins];
+    __shared__ unsigned prefix[2], kth[2], wsum[16];
     const int frame = blockIdx.x;
     const int n_px = a.out_h * a.out_w;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -44,9 +45,10 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
             kth[0] = (unsigned)below;
             kth[1] = (unsigned)ceilf(rank);
         }
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            for (int i = threadIdx.x; i < 512; i += kCondThreads) (&hist[0][0])[i] = 0u;
+        for (int pass = 0; pass < 3; ++pass) {
+            // key bits [31:21], [20:10], [9:0] of |v| (bit 31 is 0)
+            const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0, bits = pass == 2 ? 10 : 11;
+            for (int i = threadIdx.x; i < 2 * kCondBins; i += kCondThreads) (&hist[0][0])[i] = 0u;
             __syncthreads();
             const unsigned p0 = prefix[0], p1 = prefix[1];
             // wave w walks rows w, w+16, ...; lanes walk the columns (no per-element division). Trip counts are
@@ -65,12 +67,12 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
                 for (int k = 0; k < kBatch; ++k) {
                     const bool live = c0 + 64 * k + lane < a.out_w;
                     const unsigned key = live ? __float_as_uint(fabsf(vals[k])) : 0u;
-                    unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
+                    unsigned hi = pass == 0 ? 0u : key >> (shift + bits);
                     if (!live) hi = 0xffffffffu;                     // matches no prefix (prefixes have < 32 bits)
-                    const unsigned byte = (key >> shift) & 0xffu;
+                    const unsigned byte = (key >> shift) & ((1u << bits) - 1u);
                     // wave-aggregated histogram update: event frames have few distinct values (k * 0.2), so most
                     // lanes of a wave hit the same bin; one atomic per distinct (target, byte), not one per lane
-                    unsigned tag = (hi == p0 ? 0x100u : 0u) | (hi == p1 ? 0x200u : 0u);
+                    unsigned tag = (hi == p0 ? 0x800u : 0u) | (hi == p1 ? 0x1000u : 0u);
                     tag = tag ? (tag | byte) : 0u;
                     unsigned long long todo = __ballot(tag != 0u);
                     while (todo) {
@@ -79,25 +81,40 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
                         const unsigned long long same = __ballot(tag == t);
                         if (lane == leader) {
                             const unsigned c = (unsigned)__popcll(same);
-                            if (t & 0x100u) atomicAdd(&hist[0][t & 0xffu], c);
-                            if (t & 0x200u) atomicAdd(&hist[1][t & 0xffu], c);
+                            if (t & 0x800u) atomicAdd(&hist[0][t & 0x7ffu], c);
+                            if (t & 0x1000u) atomicAdd(&hist[1][t & 0x7ffu], c);
                         }
                         todo &= ~same;
                     }
                 }
               }
             __syncthreads();
-            if (threadIdx.x < 2) {   // two lanes: one per target rank
-                const int j = threadIdx.x;
-                unsigned k = kth[j], acc = 0;
-                int bin = 0;
-                for (; bin < 256; ++bin) {
-                    const unsigned c = hist[j][bin];
-                    if (acc + c > k) break;
-                    acc += c;
+            // locate the bin holding rank kth[j] of each target j: 512 threads per target, four bins each, wave-level
+            // inclusive scan + the eight wave totals through LDS (a single lane walking the bins was a 25 k-cycle dependent
+            // chain of LDS reads per pass with the other 1022 threads parked at the barrier)
+            const int j = threadIdx.x >> 9, b4 = (threadIdx.x & 511) * 4;
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(&hist[j][b4]);
+            const unsigned kk = kth[j], mine = c4.x + c4.y + c4.z + c4.w;
+            unsigned incl = mine;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const unsigned t = __shfl_up(incl, dlt);
+                if (lane >= dlt) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            {
+                const int w = wave & 7;
+                for (int i = 0; i < w; ++i) incl += wsum[j * 8 + i];
+                unsigned excl = incl - mine;
+                if (excl <= kk && kk < incl) {       // the rank falls into this thread's four bins: exactly one thread per target
+                    int bin = b4;
+                    if (excl + c4.x <= kk) { excl += c4.x; ++bin;
+                        if (excl + c4.y <= kk) { excl += c4.y; ++bin;
+                            if (excl + c4.z <= kk) { excl += c4.z; ++bin; } } }
+                    kth[j] = kk - excl;
+                    prefix[j] = (prefix[j] << bits) | (unsigned)bin;
                 }
-                kth[j] = k - acc;
-                prefix[j] = (prefix[j] << 8) | (unsigned)bin;
             }
             __syncthreads();
         }
