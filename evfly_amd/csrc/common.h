@@ -43,6 +43,19 @@ int scratch_get(size_t bytes, void **out, hipStream_t stream, int slot = 0);
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 constexpr int kNumXCD = 8;   // MI355X: 8 XCDs, block b is observed on XCD b % 8 (speed only)
+
+// ATen upsample_bilinear2d source index and lambdas (aten/src/ATen/native/UpSample.h area_pixel_compute_*): shared by the
+// resize kernel (ops.hip) and the Winograd epilogue's fused skip resampling (wino.hip) -- the same arithmetic, so a skip
+// pixel gets the same bits whichever of the two writes it.
+__device__ __forceinline__ void bilinear_src_index(int dst, int in_size, int out_size, float scale, int align, int &i0, int &i1,
+                                                   float &l0, float &l1) {
+    if (in_size == out_size) { i0 = i1 = dst; l0 = 1.f; l1 = 0.f; return; }
+    float real = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = min((int)floorf(real), in_size - 1);
+    l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l0 = 1.f - l1;
+}
 constexpr int kNumCU = 256;
 constexpr int kMaxLds = 160 * 1024;
 

@@ -46,6 +46,16 @@ struct ConvDesc {
     // optional second output of the Winograd 3x3 kernel: 2x2/stride-2 max pool (floor) of the activated output,
     // NHWC [NI][OH/2][OW/2][Nc] contiguous (nn.MaxPool2d(2, 2) fused into the producer)
     float *y_pool = nullptr;
+    // optional third output of the Winograd 3x3 kernel (U-Net 'interp' skip, learner_models.py:514): the bilinear resample
+    // (align_corners = False) of the activated output to skip_h x skip_w, channel n of pixel (img, sy, sx) at
+    // skip_y[((img * skip_h + sy) * skip_w + sx) * skip_ld + n]. The kernel writes the pixels whose four taps lie inside
+    // one block's output region (wino_block_region); launch_bilinear(..., excl_h, excl_w) writes the others from y.
+    float *skip_y = nullptr;
+    int skip_h = 0, skip_w = 0;
+    int64_t skip_ld = 0;
+    // with skip_y: write y only along the borders of each block's region (first / last row and column) -- all that the
+    // resize of the remaining skip pixels reads. For callers whose only other reader of y is the fused pool.
+    int skip_bands = 0;
     // optional fused producer (Winograd kernel, C == 32 only): x is not read; input pixel (iy, ix) is
     // relu(conv3x3(form(pre_frames))[iy][ix]) of the FIRST U-Net conv (learner_models.py:476-494,533), computed on
     // the fly while the patch is staged. pre_frames (NI, H + 2, W + 2) raw conditioned frames, pre_w [9 * cin][32],
@@ -87,6 +97,9 @@ bool wino_applicable(const ConvDesc &d);
 double wino_efficiency(const ConvDesc &d);      // useful tile slots / launched tile slots of the chosen plan
 int wino_launch(const ConvDesc &d, const float *U, hipStream_t st);
 double wino_exec_flops(const ConvDesc &d);     // MFMA flops one launch issues (its algorithmic count is igemm_flops)
+// output pixels (rows, columns) one block of the plan covers; (0, 0) when d.skip_y is set but that skip geometry cannot be
+// resampled in the kernel (the caller then clears skip_y and lets launch_bilinear write everything)
+void wino_block_region(const ConvDesc &d, int *rh, int *rw);
 
 // algorithmic work of one launch (for the profile / roofline accounting)
 inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }

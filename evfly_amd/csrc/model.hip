@@ -470,7 +470,8 @@ struct Ctx {
 // y[N,OH,OW,Cout] = act(conv(x) + b (+res))
 int conv(evfly_model *m, const char *pname, const std::string &wname, const float *x, int n, int H, int W, int C,
          int64_t ldx, int cout, int kh, int kw, int stride, int pad, int act, const float *res, int64_t ldres, float *y,
-         int64_t ldy, float *y_pool = nullptr, bool *pool_fused = nullptr) {
+         int64_t ldy, float *y_pool = nullptr, bool *pool_fused = nullptr, float *skip_y = nullptr, int skip_h = 0, int skip_w = 0,
+         int64_t skip_ld = 0, int *skip_region = nullptr) {
     ConvDesc d;
     d.x = x; d.ldx = ldx; d.NI = n; d.H = H; d.W = W; d.C = C;
     d.w = m->W(wname + ".w"); d.ldw = m->planning ? round_up(kh * kw * C, 32) : m->wld[wname];
@@ -491,6 +492,14 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     if (wino_applicable(d) && m->has(wname + ".u")) {          // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
         d.y_pool = y_pool;                                     // nn.MaxPool2d(2,2): one window per Winograd tile
         if (pool_fused) *pool_fused = y_pool != nullptr;
+        if (skip_y && skip_region) {                           // 'interp' skip: resampled from the tile in LDS where the taps allow
+            d.skip_y = skip_y; d.skip_h = skip_h; d.skip_w = skip_w; d.skip_ld = skip_ld;
+            wino_block_region(d, &skip_region[0], &skip_region[1]);
+            if (skip_region[0] == 0) d.skip_y = nullptr;
+            // the map's other readers: the 2x2 pool (fused above) and the debug taps "e1".."e4"
+            static const bool full_maps = getenv("EVFLY_FULL_ENCODER_OUTPUTS") != nullptr;
+            d.skip_bands = d.skip_y && y_pool && !full_maps;
+        }
         if (!m->planning && m->profiling) m->next_exec = wino_exec_flops(d);   // only a profiled launch consumes it
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;
@@ -531,6 +540,16 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     RUN(m, "e11_direct", 2.0 * F * 258 * 344 * 32 * 9 * cin, 4.0 * F * (260.0 * 346 + 258.0 * 344 * 32),
         launch_e11(frames, F, 260, 346, cin, c.form_bev, apply_form, c.evs_min_cutoff, m->W("e11.w"), m->W("e11.b"), e11, st));
     struct Lvl { int H, W, C; float *y; } lv[5];
+    // 'interp' skips: the concat buffers of the decoder are allocated up front so that the encoder's Winograd kernels can
+    // write the resampled skip straight into them (every pixel whose taps lie inside one block's tile; the resize
+    // kernel in the decoder loop below writes the rest). EVFLY_NO_SKIP_FUSION: the resize kernel writes everything.
+    static const int small[4][2] = {{16, 26}, {24, 44}, {40, 80}, {72, 152}};
+    static const bool no_skip_fuse = getenv("EVFLY_NO_SKIP_FUSION") != nullptr;
+    const bool run_decoder = !(c.is_deployment && !(c.velpred == 1 || c.velpred == 11));
+    float *cats[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // by decoder level 1..4
+    int skip_region[5][2] = {};                                            // block region of the fused producer (0: not fused)
+    if (run_decoder && c.skip_type == EVFLY_SKIP_INTERP && !no_skip_fuse)
+        for (int l = 1; l <= 4; ++l) cats[l] = m->alloc((int64_t)F * small[l - 1][0] * small[l - 1][1] * 2 * (512 >> l));
     const float *cur = e11;
     int H = 258, W = 344, C = 32;
     const char *names[5][2] = {{nullptr, "e12"}, {"e21", "e22"}, {"e31", "e32"}, {"e41", "e42"}, {"e51", "e52"}};
@@ -553,8 +572,11 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             m->pre.frames = frames; m->pre.w = m->W("e11.w"); m->pre.b = m->W("e11.b"); m->pre.cin = cin;
             m->pre.form_bev = c.form_bev; m->pre.apply_form = apply_form; m->pre.cutoff = c.evs_min_cutoff;
         }
+        const int dl = 4 - l;       // the decoder level this output is the skip of (levels 0..3)
+        float *skip_dst = l < 4 ? cats[dl] : nullptr;
         if (int rc = conv(m, "conv3x3", names[l][1], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, chans[l],
-                          pooled, &pool_done)) return rc;
+                          pooled, &pool_done, skip_dst, skip_dst ? small[dl - 1][0] : 0, skip_dst ? small[dl - 1][1] : 0, 2 * chans[l],
+                          skip_dst ? skip_region[dl] : nullptr)) return rc;
         cur = b; H -= 2; W -= 2; C = chans[l];
         lv[l] = Lvl{H, W, C, b};
         static const char *tn[5] = {"e1", "e2", "e3", "e4", "e5"};
@@ -592,12 +614,11 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         m->tap("e5_lstm", hseq, F, 8, 13, 512);
     }
     // ---- decoder (learner_models.py:553-583); is_deployment skips it unless a velpred head reads its output
-    if (c.is_deployment && !(c.velpred == 1 || c.velpred == 11)) {
+    if (!run_decoder) {
         if (depth_dev) *depth_dev = nullptr;
         if (c.velpred == 2 && yvel_out) return velpred_chunk(m, y5, S, T, vp_h, vp_c, yvel_out);
         return 0;
     }
-    static const int small[4][2] = {{16, 26}, {24, 44}, {40, 80}, {72, 152}};
     const float *dcur = y5;
     int dh = 8, dw = 13, dc = 512;
     for (int l = 1; l <= 4; ++l) {
@@ -605,10 +626,11 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         const int co = dc / 2, uh = 2 * dh, uw = 2 * dw;
         EVFLY_REQUIRE(uh == small[l - 1][0] && uw == small[l - 1][1], "decoder geometry");
         const int ccat = c.skip_type == EVFLY_SKIP_NONE ? co : 2 * co;
-        float *cat = m->alloc((int64_t)F * uh * uw * ccat);
+        float *cat = cats[l] ? cats[l] : m->alloc((int64_t)F * uh * uw * ccat);
         float *up_dst = cat + (ccat - co);
         if (c.skip_type == EVFLY_SKIP_INTERP)       // F.interpolate(y, size=small, bilinear, align_corners=False) (:514)
-            RUN(m, "skip_bilinear", 0, 4.0 * F * uh * uw * co * 5, launch_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, 0, st));
+            RUN(m, "skip_bilinear", 0, 4.0 * F * uh * uw * co * 5,
+                launch_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, 0, st, skip_region[l][0], skip_region[l][1]));
         else if (c.skip_type == EVFLY_SKIP_CROP)    // centre crop (:512)
             RUN(m, "skip_crop", 0, 4.0 * F * uh * uw * co * 2,
                 launch_crop(enc.y, F, enc.H, enc.W, enc.C, enc.H / 2 - uh / 2, enc.W / 2 - uw / 2, cat, uh, uw, ccat, st));

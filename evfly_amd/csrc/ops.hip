@@ -133,17 +133,7 @@ __global__ __launch_bounds__(256) void k_velpred_vec(const float *__restrict__ y
 
 // ------------------------------------------------------------------------------------------ bilinear
 // ATen upsample_bilinear2d (aten/src/ATen/native/UpSample.h area_pixel_compute_* + cpu/UpSampleKernel.cpp):
-// fp32 scale, source index, lambdas; result = wh0*(ww0*v00 + ww1*v01) + wh1*(ww0*v10 + ww1*v11).
-__device__ __forceinline__ void src_index(int dst, int in_size, int out_size, float scale, int align, int &i0, int &i1,
-                                          float &l0, float &l1) {
-    if (in_size == out_size) { i0 = i1 = dst; l0 = 1.f; l1 = 0.f; return; }
-    float real = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
-    i0 = min((int)floorf(real), in_size - 1);
-    l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
-    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-    l0 = 1.f - l1;
-}
-
+// fp32 scale, source index, lambdas (bilinear_src_index, common.h); result = wh0*(ww0*v00 + ww1*v01) + wh1*(ww0*v10 + ww1*v11).
 __device__ __forceinline__ float pre_op(float v, int pre) {
     if (pre == 1) { v = v * 2.0f; v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }   // torch.clip(x*2, 0, 1)
     return v;
@@ -152,7 +142,7 @@ __device__ __forceinline__ float pre_op(float v, int pre) {
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, int n, int Hi, int Wi, int C, int64_t ldx,
                                                   float *__restrict__ y, int Ho, int Wo, int64_t ldy, int align, int pre,
-                                                  float sh, float sw) {
+                                                  float sh, float sw, int excl_h, int excl_w) {
     const int CV = C / VEC;
     const int64_t total = (int64_t)n * Ho * Wo * CV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -163,8 +153,11 @@ __global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, i
         const int img = (int)(p / Ho);
         int y0, y1, x0, x1;
         float hy0, hy1, wx0, wx1;
-        src_index(oy, Hi, Ho, sh, align, y0, y1, hy0, hy1);
-        src_index(ox, Wi, Wo, sw, align, x0, x1, wx0, wx1);
+        bilinear_src_index(oy, Hi, Ho, sh, align, y0, y1, hy0, hy1);
+        bilinear_src_index(ox, Wi, Wo, sw, align, x0, x1, wx0, wx1);
+        // excl_h x excl_w: the producer's block regions tile the source from (0, 0); it already wrote every pixel whose
+        // taps lie inside one of them (y1 - y0, x1 - x0 in {0, 1}: the taps split iff the second one starts a region)
+        if (excl_h && (y1 == y0 || y1 % excl_h != 0) && (x1 == x0 || x1 % excl_w != 0)) continue;
         const float *b = x + (int64_t)img * Hi * Wi * ldx + c;
         const float *p00 = b + ((int64_t)y0 * Wi + x0) * ldx, *p01 = b + ((int64_t)y0 * Wi + x1) * ldx;
         const float *p10 = b + ((int64_t)y1 * Wi + x0) * ldx, *p11 = b + ((int64_t)y1 * Wi + x1) * ldx;
@@ -551,7 +544,7 @@ int launch_velpred_vec(const float *y, int64_t rows, int64_t ldy, float *vel, hi
 }
 
 int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, float *y, int Ho, int Wo, int64_t ldy,
-                    int align_corners, int pre, hipStream_t st) {
+                    int align_corners, int pre, hipStream_t st, int excl_h, int excl_w) {
     // area_pixel_compute_scale<float>
     float sh, sw;
     if (align_corners) {
@@ -564,11 +557,11 @@ int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, f
     if (C % 4 == 0) {
         const int64_t work = (int64_t)n * Ho * Wo * (C / 4);
         hipLaunchKernelGGL(k_bilinear<4>, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy,
-                           align_corners, pre, sh, sw);
+                           align_corners, pre, sh, sw, excl_h, excl_w);
     } else {
         const int64_t work = (int64_t)n * Ho * Wo * C;
         hipLaunchKernelGGL(k_bilinear<1>, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy,
-                           align_corners, pre, sh, sw);
+                           align_corners, pre, sh, sw, excl_h, excl_w);
     }
     EVFLY_LAUNCH_CHECK();
     return 0;

@@ -545,21 +545,49 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const float *ot = smem + MT * 6 * 16 * 64;         // the transposed tile: MT x 16 KB behind the exchange sets
     lds_barrier();
     WINO_TS(6);
+    const int oy0 = 2 * ty0, ox0 = 2 * tx0;            // output origin of the block (wave-uniform)
+    if (d.skip_y) {     // fused 'interp' skip, part 1 (the rest is at the end of the kernel): wave 0 lists the rows / columns
+        const int RH = 2 * g.TY, RW = 2 * g.TX;
+        const float sh = (float)d.OH / (float)d.skip_h, sw = (float)d.OW / (float)d.skip_w;      // area_pixel_compute_scale
+        float4 *ent = reinterpret_cast<float4 *>(smem);            // [0 .. 31] rows, [32 .. 63] columns: {index, tap0 | tap1 << 8, l0, l1}
+        int *cnt = reinterpret_cast<int *>(smem + 64 * 4);         // [0] rows, [1] columns
+        if (wv == 0) {
+            const bool is_col = lane >= 32;
+            const int o0 = is_col ? ox0 : oy0, R = is_col ? RW : RH, in_size = is_col ? d.OW : d.OH, out_size = is_col ? d.skip_w : d.skip_h;
+            const float sc = is_col ? sw : sh;
+            const int lo = max(0, (int)(((float)o0 + 0.5f) / sc - 0.5f) - 1);
+            const int s_idx = lo + (lane & 31);
+            int i0 = 0, i1 = 0;
+            float l0 = 0.f, l1 = 0.f;
+            bool ok = s_idx < out_size;
+            if (ok) {
+                bilinear_src_index(s_idx, in_size, out_size, sc, 0, i0, i1, l0, l1);
+                ok = i0 >= o0 && i1 < o0 + R;
+            }
+            const unsigned long long m = __ballot(ok);
+            const unsigned half = is_col ? (unsigned)(m >> 32) : (unsigned)m;
+            if (ok) {
+                const int rank = __popc(half & ((1u << (lane & 31)) - 1u));
+                ent[(is_col ? 32 : 0) + rank] = make_float4(__int_as_float(s_idx), __int_as_float((i0 - o0) | ((i1 - o0) << 8)), l0, l1);
+            }
+            if ((lane & 31) == 0) cnt[is_col ? 1 : 0] = __popc(half);
+        }
+    }
     // the table entries landed long ago; name them all here so that hipcc's wait for them sits in front of the first
     // store -- placed per entry between the stores, its (in-order) vmcnt arithmetic makes store q wait for the
     // acknowledgement of stores 0 .. q-2 (measured: 3.5 k of a single-chunk block's 28 k cycles)
     asm volatile("" : "+v"(se[0].x), "+v"(se[0].y), "+v"(se[1].x), "+v"(se[1].y), "+v"(se[2].x), "+v"(se[2].y), "+v"(se[3].x), "+v"(se[3].y),
                  "+v"(pe.x), "+v"(pe.y));
     const bool vec = (d.ldy & 3) == 0 && (d.Nc & 3) == 0 && (((uintptr_t)d.y) & 15) == 0;
-    // output origin of the block (wave-uniform); per-thread offsets and coordinates come from the plan's tables
-    const int oy0 = 2 * ty0, ox0 = 2 * tx0;
+    // per-thread offsets and coordinates come from the plan's tables
     float *ybase = d.y + ((uint64_t)(unsigned)img0 * (unsigned)(d.OH * d.OW * (int)d.ldy) + (unsigned)((oy0 * d.OW + ox0) * (int)d.ldy + n0));
     const int hrem = d.OH - oy0, wrem = d.OW - ox0, irem = d.NI - img0, nrem = d.Nc - n0 - (tid & 7) * 4;
     // (two copies of the loop: with the vector / scalar choice inside it hipcc merges the two into a dwordx3 + a
     // conditional dword store per entry)
+    const bool bands = d.skip_bands != 0;      // the full-resolution map is only read by the resize of the straddling skip pixels
     auto store_ok = [&](uint2 e) {
-        return e.y != 0xffffffffu && (int)(e.y & 0xffu) < hrem && (int)((e.y >> 8) & 0xffu) < wrem && (int)(e.y >> 16) < irem && nrem > 0 &&
-               !(kAbl & 4);
+        return e.y != 0xffffffffu && (int)(e.y & 0xffu) < hrem && (int)((e.y >> 8) & 0xffu) < wrem && (int)((e.y >> 16) & 0xffu) < irem && nrem > 0 &&
+               (!bands || (e.y & (1u << 24))) && !(kAbl & 4);
     };
     if (vec) {
 #pragma unroll
@@ -592,6 +620,44 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             float *dst = d.y_pool + ((uint64_t)(unsigned)img0 * (unsigned)(PHo * PWo * d.Nc) + (unsigned)((ty0 * PWo + tx0) * d.Nc + n0)) + e.x;
             if ((d.Nc & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
             else { dst[0] = v.x; if (nrem > 1) dst[1] = v.y; if (nrem > 2) dst[2] = v.z; if (nrem > 3) dst[3] = v.w; }
+        }
+    }
+    if (d.skip_y) {
+        // ---- fused 'interp' skip (learner_models.py:514): bilinear resample (align_corners = False) of the activated output.
+        // Every skip pixel whose four taps lie inside this block's output region is computed from the transposed tile in LDS
+        // (the resize kernel then reads only the pixels whose taps straddle two regions: ~20 % of them).
+        // Wave 0 lists the skip rows (lanes 0..31) and columns (lanes 32..63) that qualify -- candidates from the inverse
+        // map widened by one on either side, decided by the exact forward index, the arithmetic of k_bilinear
+        // (bilinear_src_index) -- compacted into the dead exchange sets; then items = (row entry, column entry, 4-channel
+        // group), eight threads per pixel.
+        float4 *ent = reinterpret_cast<float4 *>(smem);
+        int *cnt = reinterpret_cast<int *>(smem + 64 * 4);
+        lds_barrier();
+        const int nrow = cnt[0], ncol = cnt[1], npix = nrow * ncol;
+        if (npix > 0) {
+            const float inv_ncol = 1.0f / (float)ncol;
+            const int c4 = tid & 7, nimg = min(g.IMGS, irem);
+            if (n0 + c4 * 4 < d.Nc)                              // (Nc % 4 == 0: whole 4-channel groups)
+                for (int im = 0; im < nimg; ++im)
+                    for (int i = tid >> 3; i < npix; i += NTHR / 8) {
+                        const int iy = (int)(((float)i + 0.5f) * inv_ncol), ix = i - iy * ncol;      // exact: i < 2^10, margin 0.5 / ncol
+                        const float4 er = ent[iy], ec = ent[32 + ix];
+                        const int sy = __float_as_int(er.x), sx = __float_as_int(ec.x);
+                        const int ty = __float_as_int(er.y), tx = __float_as_int(ec.y);
+                        const float hy0 = er.z, hy1 = er.w, wx0 = ec.z, wx1 = ec.w;
+                        auto px = [&](int ry, int rx) {
+                            const int tl = (im * g.TY + (ry >> 1)) * g.TX + (rx >> 1);
+                            return *reinterpret_cast<const float4 *>(ot + ((tl * 4 + (ry & 1) * 2 + (rx & 1)) * 32 + c4 * 4));
+                        };
+                        const float4 p00 = px(ty & 0xff, tx & 0xff), p01 = px(ty & 0xff, tx >> 8), p10 = px(ty >> 8, tx & 0xff), p11 = px(ty >> 8, tx >> 8);
+                        float4 o;
+                        { const float t0 = p00.x * wx0 + p01.x * wx1, t1 = p10.x * wx0 + p11.x * wx1; o.x = t0 * hy0 + t1 * hy1; }
+                        { const float t0 = p00.y * wx0 + p01.y * wx1, t1 = p10.y * wx0 + p11.y * wx1; o.y = t0 * hy0 + t1 * hy1; }
+                        { const float t0 = p00.z * wx0 + p01.z * wx1, t1 = p10.z * wx0 + p11.z * wx1; o.z = t0 * hy0 + t1 * hy1; }
+                        { const float t0 = p00.w * wx0 + p01.w * wx1, t1 = p10.w * wx0 + p11.w * wx1; o.w = t0 * hy0 + t1 * hy1; }
+                        float *dst = d.skip_y + ((uint64_t)(unsigned)(img0 + im) * (unsigned)(d.skip_h * d.skip_w) + (unsigned)(sy * d.skip_w + sx)) * (uint64_t)d.skip_ld + n0 + c4 * 4;
+                        *reinterpret_cast<float4 *>(dst) = o;
+                    }
         }
     }
 #ifdef EVFLY_WINO_TS
@@ -821,6 +887,9 @@ void build_store_tables(const WinoGeom &g, int nthr, int OH, int OW, int64_t ldy
                 const int oy = 2 * ty + (pix >> 1), ox = 2 * tx + (pix & 1);
                 e.x = (unsigned)((((int64_t)im * OH + oy) * OW + ox) * ldy + c4 * 4);
                 e.y = (unsigned)oy | ((unsigned)ox << 8) | ((unsigned)im << 16);
+                // bit 24: first / last row or column of the block's region -- the only output pixels a resize of this map can
+                // need from TWO blocks (ConvDesc::skip_bands)
+                if (oy == 0 || oy == 2 * g.TY - 1 || ox == 0 || ox == 2 * g.TX - 1) e.y |= 1u << 24;
             }
             st[q * nthr + tid] = e;
         }
@@ -917,6 +986,15 @@ double wino_efficiency(const ConvDesc &d) { return cached_plan(d).efficiency; }
 
 double wino_exec_flops(const ConvDesc &d) { return cached_plan(d).exec_flops; }
 
+void wino_block_region(const ConvDesc &d, int *rh, int *rw) {
+    const WinoPlan &p = cached_plan(d);
+    *rh = 2 * p.g.TY; *rw = 2 * p.g.TX;
+    // the kernel lists at most 32 candidate skip rows and 32 columns per block (one half-wave each)
+    if (d.skip_y && (d.skip_h <= 0 || d.skip_w <= 0 || *rh * (double)d.skip_h / d.OH + 4 > 32 || *rw * (double)d.skip_w / d.OW + 4 > 32 ||
+                     d.skip_ld % 4 != 0 || ((uintptr_t)d.skip_y) % 16 != 0 || d.Nc % 4 != 0 || (int64_t)d.skip_h * d.skip_w * d.skip_ld >= ((int64_t)1 << 31)))
+        *rh = *rw = 0;
+}
+
 int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
     const WinoPlan &p = cached_plan(d);
     EVFLY_REQUIRE(p.ok, "wino: no tile plan");
@@ -928,6 +1006,11 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
                   "wino: image larger than 2^24 floats (24-bit index arithmetic)");
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
                   "wino: the fused first-conv producer needs C == 32 and 1 or 2 frame channels");
+    if (d.skip_y) {
+        int rh = 0, rw = 0;
+        wino_block_region(d, &rh, &rw);
+        EVFLY_REQUIRE(rh > 0, "wino: this skip geometry cannot be fused (ask wino_block_region first)");
+    }
     const bool one = d.C == 32, pre = d.pre_frames != nullptr;
     if (p.c.MT == 2)
         return !one ? launch<2, 5, false, false>(d, U, p, st) : pre ? launch<2, 5, true, true>(d, U, p, st) : launch<2, 5, true, false>(d, U, p, st);

@@ -420,3 +420,38 @@ def test_errors_are_loud(gpu_device):
     sd.pop("unet_e22.bias")
     with pytest.raises(RuntimeError):
         net.load_state_dict(sd)                                      # torch's own missing-key error
+
+
+_SKIP_PROBE = r"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, sys.argv[1])
+from _util import cond_frames
+from test_gpu_models import _composite
+net, sd = _composite("cuda")
+S, T = 6, 3                         # 18 frames: the 3- and 4-image blocks of the deep layers see a ragged last group
+x = cond_frames(123, S * T).to("cuda")
+desvel = torch.full((S * T, 1), 4.0, device="cuda")
+v, (d, up, ((hu, _), (lh, lc))) = net.forward_streams([x, desvel, [None, None], None], S, T)
+np.savez(sys.argv[2], v=v.cpu().numpy(), d=d.cpu().numpy(), up=up.cpu().numpy(), hu=hu[0][0].cpu().numpy(), lh=lh.cpu().numpy())
+"""
+
+
+def test_fused_skip_equals_resize_kernel_bitwise(gpu_device, tmp_path):
+    """U-Net 'interp' skips: the Winograd epilogue writes the skip pixels whose taps lie inside one block and keeps only the
+    block borders of the full-resolution map for the resize kernel's share. Both switches off (EVFLY_NO_SKIP_FUSION: the
+    resize kernel writes every skip pixel from a complete map) must give the same bits: same arithmetic, one writer per
+    pixel, no pixel lost at a block, image or batch edge. The switches are read once per process, hence subprocesses."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("fused", {}), ("fullmaps", {"EVFLY_FULL_ENCODER_OUTPUTS": "1"}), ("resize", {"EVFLY_NO_SKIP_FUSION": "1"})):
+        path = str(tmp_path / f"{tag}.npz")
+        e = {k: v for k, v in os.environ.items() if k not in ("EVFLY_NO_SKIP_FUSION", "EVFLY_FULL_ENCODER_OUTPUTS")}
+        e.update(env)
+        subprocess.run([sys.executable, "-c", _SKIP_PROBE, repo, path], check=True, env=e, timeout=600)
+        outs[tag] = np.load(path)
+    for tag in ("fullmaps", "resize"):
+        for k in ("v", "d", "up", "hu", "lh"):
+            assert np.array_equal(outs["fused"][k], outs[tag][k], equal_nan=True), (tag, k)
