@@ -629,8 +629,25 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         float *cat = cats[l] ? cats[l] : m->alloc((int64_t)F * uh * uw * ccat);
         float *up_dst = cat + (ccat - co);
         if (c.skip_type == EVFLY_SKIP_INTERP)       // F.interpolate(y, size=small, bilinear, align_corners=False) (:514)
-            RUN(m, "skip_bilinear", 0, 4.0 * F * uh * uw * co * 5,
+        {
+            // share of the skip pixels left to the resize kernel (taps in two producer blocks): rows / columns whose second tap
+            // starts a block region, counted with the resize's own index arithmetic (for the bytes figure of the profile only)
+            auto straddling = [](int in, int out, int region) {
+                if (region <= 0) return out;
+                const float sc = (float)in / (float)out;
+                int cnt = 0;
+                for (int o = 0; o < out; ++o) {
+                    const float real = std::max(sc * ((float)o + 0.5f) - 0.5f, 0.f);
+                    const int i0 = std::min((int)std::floor(real), in - 1), i1 = i0 + (i0 < in - 1 ? 1 : 0);
+                    cnt += i1 != i0 && i1 % region == 0;
+                }
+                return cnt;
+            };
+            const int rs = straddling(enc.H, uh, skip_region[l][0]), cs = straddling(enc.W, uw, skip_region[l][1]);
+            const double rest = (double)uh * uw - (double)(uh - rs) * (uw - cs);
+            RUN(m, "skip_bilinear", 0, 4.0 * F * rest * co * 5,
                 launch_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, 0, st, skip_region[l][0], skip_region[l][1]));
+        }
         else if (c.skip_type == EVFLY_SKIP_CROP)    // centre crop (:512)
             RUN(m, "skip_crop", 0, 4.0 * F * uh * uw * co * 2,
                 launch_crop(enc.y, F, enc.H, enc.W, enc.C, enc.H / 2 - uh / 2, enc.W / 2 - uw / 2, cat, uh, uw, ccat, st));

@@ -139,34 +139,38 @@ __device__ __forceinline__ float pre_op(float v, int pre) {
     return v;
 }
 
+// One block per output row (img, oy): the row's source rows and weights are computed once (wave-uniform), the threads walk
+// (ox, channel group) with one multiply-shift division -- the flat-index form spent three 64-bit divisions per item.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, int n, int Hi, int Wi, int C, int64_t ldx,
                                                   float *__restrict__ y, int Ho, int Wo, int64_t ldy, int align, int pre,
-                                                  float sh, float sw, int excl_h, int excl_w) {
+                                                  float sh, float sw, int excl_h, int excl_w, unsigned cv_magic) {
     const int CV = C / VEC;
-    const int64_t total = (int64_t)n * Ho * Wo * CV;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % CV) * VEC;
-        int64_t p = i / CV;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int img = (int)(p / Ho);
-        int y0, y1, x0, x1;
-        float hy0, hy1, wx0, wx1;
+    for (int row = blockIdx.x; row < n * Ho; row += gridDim.x) {
+        const int img = row / Ho, oy = row - img * Ho;
+        int y0, y1;
+        float hy0, hy1;
         bilinear_src_index(oy, Hi, Ho, sh, align, y0, y1, hy0, hy1);
-        bilinear_src_index(ox, Wi, Wo, sw, align, x0, x1, wx0, wx1);
         // excl_h x excl_w: the producer's block regions tile the source from (0, 0); it already wrote every pixel whose
         // taps lie inside one of them (y1 - y0, x1 - x0 in {0, 1}: the taps split iff the second one starts a region)
-        if (excl_h && (y1 == y0 || y1 % excl_h != 0) && (x1 == x0 || x1 % excl_w != 0)) continue;
-        const float *b = x + (int64_t)img * Hi * Wi * ldx + c;
-        const float *p00 = b + ((int64_t)y0 * Wi + x0) * ldx, *p01 = b + ((int64_t)y0 * Wi + x1) * ldx;
-        const float *p10 = b + ((int64_t)y1 * Wi + x0) * ldx, *p11 = b + ((int64_t)y1 * Wi + x1) * ldx;
-        float *o = y + (((int64_t)img * Ho + oy) * Wo + ox) * ldy + c;
+        const bool row_inside = excl_h && (y1 == y0 || y1 % excl_h != 0);
+        const float *b0 = x + ((int64_t)img * Hi + y0) * Wi * ldx, *b1 = x + ((int64_t)img * Hi + y1) * Wi * ldx;
+        float *orow = y + (int64_t)row * Wo * ldy;
+        for (int i = threadIdx.x; i < Wo * CV; i += 256) {
+            const int ox = CV == 1 ? i : (int)__umulhi((unsigned)i, cv_magic), c = (i - ox * CV) * VEC;     // i / CV (i * CV < 2^32)
+            int x0, x1;
+            float wx0, wx1;
+            bilinear_src_index(ox, Wi, Wo, sw, align, x0, x1, wx0, wx1);
+            if (row_inside && (x1 == x0 || x1 % excl_w != 0)) continue;
+            const float *p00 = b0 + (int64_t)x0 * ldx + c, *p01 = b0 + (int64_t)x1 * ldx + c;
+            const float *p10 = b1 + (int64_t)x0 * ldx + c, *p11 = b1 + (int64_t)x1 * ldx + c;
+            float *o = orow + (int64_t)ox * ldy + c;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float t0 = pre_op(p00[e], pre) * wx0 + pre_op(p01[e], pre) * wx1;
-            const float t1 = pre_op(p10[e], pre) * wx0 + pre_op(p11[e], pre) * wx1;
-            o[e] = t0 * hy0 + t1 * hy1;
+            for (int e = 0; e < VEC; ++e) {
+                const float t0 = pre_op(p00[e], pre) * wx0 + pre_op(p01[e], pre) * wx1;
+                const float t1 = pre_op(p10[e], pre) * wx0 + pre_op(p11[e], pre) * wx1;
+                o[e] = t0 * hy0 + t1 * hy1;
+            }
         }
     }
 }
@@ -554,15 +558,16 @@ int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, f
         sh = (float)Hi / (float)Ho;
         sw = (float)Wi / (float)Wo;
     }
-    if (C % 4 == 0) {
-        const int64_t work = (int64_t)n * Ho * Wo * (C / 4);
-        hipLaunchKernelGGL(k_bilinear<4>, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy,
-                           align_corners, pre, sh, sw, excl_h, excl_w);
-    } else {
-        const int64_t work = (int64_t)n * Ho * Wo * C;
-        hipLaunchKernelGGL(k_bilinear<1>, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy,
-                           align_corners, pre, sh, sw, excl_h, excl_w);
-    }
+    const int CV = C % 4 == 0 ? C / 4 : C;
+    EVFLY_REQUIRE((int64_t)n * Ho < ((int64_t)1 << 31) && (int64_t)Wo * CV * CV < ((int64_t)1 << 32), "bilinear: map too large");
+    const unsigned cv_magic = CV <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)CV + 1);      // floor(i / CV) == umulhi(i, magic) while i * CV < 2^32
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)n * Ho, 1 << 20);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(k_bilinear<4>, dim3(grid), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy, align_corners, pre, sh, sw,
+                           excl_h, excl_w, cv_magic);
+    else
+        hipLaunchKernelGGL(k_bilinear<1>, dim3(grid), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy, align_corners, pre, sh, sw,
+                           excl_h, excl_w, cv_magic);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
