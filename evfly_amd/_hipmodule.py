@@ -37,7 +37,8 @@ class HipHandle:
             pass
 
     def tap(self, name, max_elems=1 << 26):
-        """Copy a named intermediate of the last forward to host (parity tests)."""
+        """Copy a named intermediate of the last forward to host (parity tests). "e1".."e4" are complete only with
+        EVFLY_FULL_ENCODER_OUTPUTS=1 in the environment (include/evfly_hip.h, evfly_model_tap)."""
         buf = torch.empty(max_elems, dtype=torch.float32)
         shape = (C.c_int64 * 4)()
         n = _lib.check(self._L.evfly_model_tap(self.h, name.encode(), buf.data_ptr(), max_elems, shape,
