@@ -43,7 +43,8 @@
 #include <vector>
 
 // Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 no patch DMA,
-// 4 no global stores, 8 no LDS fragment reads, 16 no U loads, 64 no chunk barrier, 512 no epilogue. The shipped library is built with 0.
+// 4 no global stores, 8 no LDS fragment reads, 16 no U loads, 64 no chunk barrier, 512 no epilogue, 2048 no first-conv arithmetic
+// in the fused producer. The shipped library is built with 0.
 #ifndef EVFLY_WINO_ABL
 #define EVFLY_WINO_ABL 0
 #endif
@@ -69,6 +70,7 @@ struct WinoGeom {
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
     unsigned u_nnt, u_bx, u_by;  // floor(2^32 / x) + 1 for x = n_nt, bx, by (unused for x = 1)
     unsigned u_fhw, u_fw;        // the same for (PH + 2) * (PW + 2) and PW + 2 (fused first conv: frame patch)
+    int rpr, m_rpr;              // fused first conv: runs of three pixel pairs per patch row, floor(v / rpr) == (v * m_rpr) >> 16
     double cost;                // plan cost (launched tile slots + weighted patch pixels)
     // per-plan DMA table (device memory, built once per plan / row pitch / device): entry (piece g, lane l) =
     // { byte offset of the lane's 16 B relative to the block's patch origin (0x7ffffff0: padding lane), py | px << 8 }
@@ -147,7 +149,11 @@ __device__ unsigned long long g_wino_ts[16384 * 8 * 12];
 // items of the swizzled patch directly. Same fmaf order as k_e11 (ky, kx, ci): bitwise the unfused result.
 template <int CIN, int NTHR>
 __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom &g, float *patch, int buf_floats, int img0, int iy0,
-                                              int ix0, int tid) {
+                                              int ix0, int tid
+#ifdef EVFLY_WINO_TS_PRE
+                                              , unsigned long long *ts_staged
+#endif
+                                              ) {
     const int FW = g.PW + 2, FH = g.PH + 2, per = g.TY * g.TX;
     float *fr = patch + buf_floats;                       // [CIN][IMGS][FH][FW]
     const int nfr = g.IMGS * FH * FW;
@@ -163,62 +169,77 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
     }
     for (int i = tid; i < 9 * CIN * 32 + 32; i += NTHR) wl[i] = i < 9 * CIN * 32 ? d.pre_w[i] : d.pre_b[i - 9 * CIN * 32];
     __syncthreads();
+#ifdef EVFLY_WINO_TS_PRE
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_staged[0] = t_; }
+#endif
     const float *bl = wl + 9 * CIN * 32;
-    const int nitems = g.ngroups * 32;
-    for (int idx = tid; idx < nitems; idx += NTHR) {
-        const int pp = idx >> 3, ch = idx & 7;
-        const int Y = m24(pp, g.mPWh) >> 20, pxh = pp - m24(Y, g.PW >> 1);
+    // Work item = a run of three adjacent pixel pairs (six pixels) of one patch row x one 4-channel group: the eight frame
+    // columns of each of the three rows are read once per run (four 8-B LDS reads), the nine weight vectors once per run, the
+    // index arithmetic once per run -- per (pair, group) item they were two thirds of the producer's VALU instructions, and on
+    // this layer the SIMD is VALU + MFMA bound (tools/wino_ts_pre.py: the producer was 46 % of a wave's life). The
+    // 72 * CIN FMAs per pair run as 36 * CIN v_pk_fma_f32 on register pairs (channels (0, 1) and (2, 3) of a pixel) with the
+    // frame value broadcast from one half of its pair (op_sel): a packed f32 op costs the SIMD what one v_fma_f32 does
+    // (tools/ubench/mfma_valu.hip). Inline asm: hipcc scalarises packed IR whose results are read element-wise. Same
+    // operands, same order (ky, kx, ci) per lane as k_e11: bitwise identical.
+    const int ch = tid & 7, pairs_row = g.PW >> 1;
+    const int nruns = g.IMGS * g.PH * g.rpr;
+    for (int u = tid >> 3; u < ((kAbl & 2048) ? 0 : nruns); u += NTHR / 8) {        // (ablation 2048: no producer arithmetic)
+        const int Y = m24(u, g.m_rpr) >> 16, pxh0 = 3 * (u - m24(Y, g.rpr));
         const int im = m24(Y, g.mPH) >> 20, py = Y - m24(im, g.PH);
-        const int key = (pxh + m24(py >> 1, g.TX) + m24(im, per)) & 15;
-        const int px = 2 * pxh;
-        const bool row_ok = 2 * pp < g.npix && img0 + im < d.NI && iy0 + py < d.H;
-        // accumulators of the pixel pair as register pairs: (channel 0, 1) and (2, 3) of pixel 0 / pixel 1. The 72 * CIN FMAs
-        // per item run as 36 * CIN v_pk_fma_f32 with the frame value broadcast from one half of its pair (op_sel): a packed
-        // f32 op costs the SIMD what one v_fma_f32 does (tools/ubench/mfma_valu.hip). Inline asm: hipcc scalarises packed IR
-        // whose results are read element-wise. Same operands, same order (ky, kx, ci) per lane as k_e11: bitwise identical.
+        const bool row_ok = img0 + im < d.NI && iy0 + py < d.H;
         const float4 b4 = *reinterpret_cast<const float4 *>(bl + ch * 4);
-        f32x2 a0l = {b4.x, b4.y}, a0h = {b4.z, b4.w}, a1l = a0l, a1h = a0h;
-        const float *f0 = fr + (im * FH + py) * FW + px;            // even index: FW, px and the row base are even -> 8-B aligned
+        f32x2 al[6], ah[6];                 // pixel p: channels (0, 1) and (2, 3) of the group
+        const f32x2 bl2 = {b4.x, b4.y}, bh2 = {b4.z, b4.w};     // the bias is the addend of each accumulator's first FMA
+        const float *f0 = fr + (im * FH + py) * FW + 2 * pxh0;      // even index: FW, the row base and 2 pxh0 are even -> 8-B aligned
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
-                // four frame columns of this row: pairs (0, 1) and (2, 3)
-                const f32x2 p0 = *reinterpret_cast<const f32x2 *>(f0 + ci * nfr + ky * FW);
-                const f32x2 p1 = *reinterpret_cast<const f32x2 *>(f0 + ci * nfr + ky * FW + 2);
+                f32x2 fp[4];                // frame columns 0 .. 7 of this row as pairs (a ragged last run reads past the row: masked below)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fp[k] = *reinterpret_cast<const f32x2 *>(f0 + ci * nfr + ky * FW + 2 * k);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((ky * 3 + kx) * CIN + ci) * 32 + ch * 4);
                     const f32x2 wl2 = w4.xy, wh2 = w4.zw;
-                    // pixel 0 takes column kx, pixel 1 column kx + 1
-                    if (kx == 0) {
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0l) : "v"(p0), "v"(wl2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0h) : "v"(p0), "v"(wh2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1l) : "v"(p0), "v"(wl2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1h) : "v"(p0), "v"(wh2));
-                    } else if (kx == 1) {
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a0l) : "v"(p0), "v"(wl2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a0h) : "v"(p0), "v"(wh2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a1l) : "v"(p1), "v"(wl2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a1h) : "v"(p1), "v"(wh2));
-                    } else {
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0l) : "v"(p1), "v"(wl2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a0h) : "v"(p1), "v"(wh2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1l) : "v"(p1), "v"(wl2));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a1h) : "v"(p1), "v"(wh2));
+#pragma unroll
+                    for (int p6 = 0; p6 < 6; ++p6) {      // pixel p6 takes column p6 + kx
+                        const int col = p6 + kx;
+                        if (ky == 0 && ci == 0 && kx == 0) {      // first tap: accumulate from the bias (col = p6)
+                            if (col & 1) {
+                                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(al[p6]) : "v"(fp[col >> 1]), "v"(wl2), "v"(bl2));
+                                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(ah[p6]) : "v"(fp[col >> 1]), "v"(wh2), "v"(bh2));
+                            } else {
+                                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(al[p6]) : "v"(fp[col >> 1]), "v"(wl2), "v"(bl2));
+                                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(ah[p6]) : "v"(fp[col >> 1]), "v"(wh2), "v"(bh2));
+                            }
+                        } else if (col & 1) {
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(al[p6]) : "v"(fp[col >> 1]), "v"(wl2));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(ah[p6]) : "v"(fp[col >> 1]), "v"(wh2));
+                        } else {
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(al[p6]) : "v"(fp[col >> 1]), "v"(wl2));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(ah[p6]) : "v"(fp[col >> 1]), "v"(wh2));
+                        }
                     }
                 }
             }
         }
-        const float a0[4] = {a0l.x, a0l.y, a0h.x, a0h.y}, a1[4] = {a1l.x, a1l.y, a1h.x, a1h.y};
-        // NaN-propagating ReLU like torch.relu; pixels outside the (virtual) e11 map are zeros
-        const bool ok0 = row_ok && ix0 + px < d.W, ok1 = row_ok && ix0 + px + 1 < d.W;
-        const float4 o0 = ok0 ? make_float4(a0[0] < 0.f ? 0.f : a0[0], a0[1] < 0.f ? 0.f : a0[1], a0[2] < 0.f ? 0.f : a0[2], a0[3] < 0.f ? 0.f : a0[3])
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 o1 = ok1 ? make_float4(a1[0] < 0.f ? 0.f : a1[0], a1[1] < 0.f ? 0.f : a1[1], a1[2] < 0.f ? 0.f : a1[2], a1[3] < 0.f ? 0.f : a1[3])
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(patch + pp * 64 + ((ch ^ key) << 2)) = o0;             // slot of (pixel 0, ch)
-        *reinterpret_cast<float4 *>(patch + pp * 64 + (((8 | ch) ^ key) << 2)) = o1;       // slot of (pixel 1, ch)
+        const int key0 = pxh0 + m24(py >> 1, g.TX) + m24(im, per);
+        float *prow = patch + (m24(Y, pairs_row) + pxh0) * 64;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (pxh0 + q >= pairs_row) break;       // ragged last run of a row
+            const int key = (key0 + q) & 15, px = 2 * (pxh0 + q);
+            // NaN-propagating ReLU like torch.relu; pixels outside the (virtual) e11 map are zeros
+            const bool ok0 = row_ok && ix0 + px < d.W, ok1 = row_ok && ix0 + px + 1 < d.W;
+            const f32x2 l0 = al[2 * q], h0 = ah[2 * q], l1 = al[2 * q + 1], h1 = ah[2 * q + 1];
+            const float4 o0 = ok0 ? make_float4(l0.x < 0.f ? 0.f : l0.x, l0.y < 0.f ? 0.f : l0.y, h0.x < 0.f ? 0.f : h0.x, h0.y < 0.f ? 0.f : h0.y)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 o1 = ok1 ? make_float4(l1.x < 0.f ? 0.f : l1.x, l1.y < 0.f ? 0.f : l1.y, h1.x < 0.f ? 0.f : h1.x, h1.y < 0.f ? 0.f : h1.y)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(prow + q * 64 + ((ch ^ key) << 2)) = o0;             // slot of (pixel 0, ch)
+            *reinterpret_cast<float4 *>(prow + q * 64 + (((8 | ch) ^ key) << 2)) = o1;       // slot of (pixel 1, ch)
+        }
     }
 }
 
@@ -361,8 +382,19 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     constexpr bool produced = PRE;      // PRE (with ONE): the fused first conv writes the patch; its own kernel variant, so that
                                         // the DMA variants carry neither its code nor hipcc's conservative waits at the join
     if constexpr (PRE) {
+        // the first U loads and the fragment table fly under the producer (requested behind it, the chunk-0 barrier waited a
+        // whole L2 round trip for them: 3 k of the block's 32 k cycles). The producer's own staging wait (vmcnt(0), hipcc's)
+        // lands them long before its registers see any pressure.
+        u_first();
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ftv) : "v"((unsigned)(wv * 64 + lane) * 16u), "s"(g.ftab));
+        WINO_TS(11);
+#ifdef EVFLY_WINO_TS_PRE
+        if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid, &ts_[10]);
+        else produce_patch<2, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid, &ts_[10]);
+#else
         if (d.pre_cin == 1) produce_patch<1, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
         else produce_patch<2, NTHR>(d, g, patch, BUF_FLOATS, img0, iy0, ix0, tid);
+#endif
     }
     WINO_TS(9);
     if constexpr (!produced) {
@@ -409,12 +441,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             dma_piece(voff[i], sd, __builtin_amdgcn_readfirstlane(cc * 128), __builtin_amdgcn_readfirstlane(dst + (unsigned)(i * NW) * 1024u));
     };
 
+#ifndef EVFLY_WINO_TS_PRE
     WINO_TS(10);
+#endif
     if constexpr (!produced) dma(0, true);
-    else {      // (behind the producer's own loads and waits)
-        u_first();
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ftv) : "v"((unsigned)(wv * 64 + lane) * 16u), "s"(g.ftab));
-    }
     WINO_TS(1);
 
     f32x4 fu[4], fv[4];           // raw fragment rows rA / rB of the four patch columns
@@ -484,7 +514,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     auto chunk = [&](int cc, auto first) {
         constexpr bool FIRST = decltype(first)::value;
         if constexpr (FIRST) {
-            // everything requested so far has landed: U0 U1 [DMA of chunk 0] (PRE: U0 U1 T)
+            // everything requested so far has landed: U0 U1 [DMA of chunk 0] (PRE: U0 U1 T, in front of the producer)
             chunk_barrier<0>();
             if constexpr (PRE) asm volatile("" : "+v"(ftv));
             off0[0][0] = ftv[0]; off0[0][1] = ftv[1]; off0[1][0] = ftv[2]; off0[1][1] = ftv[3];
@@ -662,7 +692,11 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     }
 #ifdef EVFLY_WINO_TS
     WINO_TS(7);
+#ifdef EVFLY_WINO_TS_PRE
+    if (PRE && lane == 0 && blockIdx.x < 16384) {
+#else
     if (lane == 0 && blockIdx.x < 16384) {
+#endif
 #pragma unroll
         for (int i = 0; i < 12; ++i) g_wino_ts[((size_t)blockIdx.x * 8 + wv) * 12 + i] = ts_[i];
     }
@@ -744,6 +778,7 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
     auto magic32 = [](int x) -> unsigned { return x <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)x + 1); };
     g.u_nnt = magic32(g.n_nt); g.u_bx = magic32(g.bx); g.u_by = magic32(g.by);
     g.u_fhw = magic32((g.PH + 2) * (g.PW + 2)); g.u_fw = magic32(g.PW + 2);
+    g.rpr = cdiv(g.PW / 2, 3); g.m_rpr = 65536 / g.rpr + 1;       // exact for v < 2^12 (v < IMGS * PH * rpr <= 4 * 66 * 11)
     g.mPWh = 1048576 / (g.PW / 2) + 1; g.mPH = 1048576 / g.PH + 1; g.mTX = 1048576 / g.TX + 1; g.mPer = 1048576 / (g.TY * g.TX) + 1;
     return true;
 }
