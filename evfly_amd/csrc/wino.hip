@@ -18,7 +18,13 @@
 // Wave w = (mt, a): M-tile mt x position row a x all four b: 4 accumulator tiles = 64 registers, 128 VGPRs in all.
 // The output transform is lane-local along b; along a the four waves of an M-tile trade partial sums through LDS,
 // then the finished tile is transposed through LDS for 16-B global stores. nn.MaxPool2d(2, 2) fuses trivially (a
-// Winograd tile IS one pooling window), and the first U-Net conv can be fused in as the patch producer.
+// Winograd tile IS one pooling window), the first U-Net conv can be fused in as the patch producer (PRE), and the
+// U-Net's bilinear 'interp' skip of the output is resampled from the same tile in LDS for every skip pixel whose four
+// taps lie inside the block's region (ConvDesc::skip_y; the resize kernel writes the rest, and with skip_bands only
+// the region borders of the full-resolution map are stored).
+//
+// Prologue (hand counted as well): all kernel arguments in one scalar batch, then [lane tables] -> block decode ->
+// [U0 U1] -> vmcnt(2) -> [patch DMA of chunk 0] -> chunk-0 barrier at vmcnt(0).
 //
 // Memory pipeline (hand counted). hipcc (ROCm 7.2) drains the whole vector-memory queue (s_waitcnt vmcnt(0)) at
 // every use of an ordinary load result while an LDS-DMA is outstanding, and before every ds_read that follows one,
