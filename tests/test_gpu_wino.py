@@ -85,3 +85,20 @@ def test_wino_nan_and_inf_propagate(gpu_device):
     assert ys.min() >= 6 and ys.max() <= 9 and xs.min() >= 8 and xs.max() <= 11     # confined to the touching 2x2 tiles
     ok = ~got_nan
     assert ((got - want)[0][:, ok].abs().max() / want[0][:, ok].abs().max()).item() < 2e-5
+
+
+@pytest.mark.parametrize("mt", ["", "1", "2"])
+def test_wino_random_shapes(gpu_device, mt):
+    """tools/wino_fuzz.py: random maps / batches / channel counts against torch (ragged tile rows and columns, image groups
+    that do not divide the batch, partial N slices, maps smaller than a block), with the plan's own block variant and
+    with each one forced. The lane tables, the counted prologue and the descriptor-bounded DMA have no other shape sweep."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "EVFLY_WINO_MT"}
+    if mt:
+        env["EVFLY_WINO_MT"] = mt
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "wino_fuzz.py"), "80", str(7 + len(mt) + (int(mt) if mt else 0))],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
