@@ -41,8 +41,8 @@ PMC_TRAFFIC = "r2_pmc_traffic.json"       # rocprofv3 --pmc FETCH_SIZE / WRITE_S
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU (C2: 64)")
     ap.add_argument("--windows", type=int, default=5, help="time windows per stream (C2: 5)")
     ap.add_argument("--events-per-window", type=int, default=60_000)
