@@ -524,6 +524,34 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 }
             __syncthreads();
             constexpr int C4 = BN / 4;
+            if (d.res) {
+                // the addend is folded into the tile FIRST, all of a thread's 16-B pieces requested back to back: inside the
+                // store loop each load was followed by `s_waitcnt vmcnt(0)` -- a full memory round trip per piece, and the
+                // acknowledgement of the previous piece's store on top (16 pieces per thread; ConvLSTM h-GEMM, ViT residuals).
+                // A thread adds into the pieces it stores itself below: no barrier in between. Same sum: (acc + bias) + res.
+                constexpr int NP = BM * C4 / 256;
+                float4 rq[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int idx = tid + k * 256, row = idx / C4, c4 = idx - row * C4;
+                    const int64_t m = m0 + row;
+                    const int n = n0 + c4 * 4;
+                    rq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < d.M && n < d.Nc) {
+                        int64_t rrow = m;
+                        if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
+                        rq[k] = *reinterpret_cast<const float4 *>(d.res + rrow * d.ldres + n);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int idx = tid + k * 256, row = idx / C4, c4 = idx - row * C4;
+                    float4 *o = reinterpret_cast<float4 *>(ot + row * BN + c4 * 4);
+                    float4 v = *o;
+                    v.x += rq[k].x; v.y += rq[k].y; v.z += rq[k].z; v.w += rq[k].w;
+                    *o = v;
+                }
+            }
 #pragma unroll 4
             for (int idx = tid; idx < BM * C4; idx += 256) {
                 const int row = idx / C4, c4 = idx - row * C4;
@@ -531,12 +559,6 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 const int n = n0 + c4 * 4;
                 if (m >= d.M || n >= d.Nc) continue;
                 float4 v = *reinterpret_cast<const float4 *>(ot + row * BN + c4 * 4);
-                if (d.res) {
-                    int64_t rrow = m;
-                    if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
-                    const float4 q = *reinterpret_cast<const float4 *>(d.res + rrow * d.ldres + n);
-                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-                }
                 if (act == ACT_RELU) {
                     v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                 } else if (act != ACT_NONE) {
