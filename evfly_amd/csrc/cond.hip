@@ -125,16 +125,28 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
         q = (fabsf(w) < 0.5f) ? fmaf(w, d, v_lo) : fmaf(-d, 1.0f - w, v_hi);
         if (threadIdx.x == 0 && a.q_out) a.q_out[frame] = q;
     }
+    // scale + clip: a batch of columns is fetched before any of it is stored (written as one load / divide / store per
+    // iteration, hipcc waits for every load -- and with it for the previous store's acknowledgement: ~90 serialised memory
+    // round trips per thread and frame)
     float *dst = a.dst + (int64_t)frame * n_px;
     for (int r = wave; r < a.out_h; r += kCondThreads / 64)
-#pragma unroll 6
-        for (int c = lane; c < a.out_w; c += 64) {
-            float v = cond_load(a, frame, r, c);
-            if (a.quantile > 0.0f) {
-                v = v / q;                                   // run.py:253; IEEE division (0/0 = NaN survives)
-                v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);  // torch.clip keeps NaN
+        for (int c0 = 0; c0 < a.out_w; c0 += 64 * kBatch) {
+            float vals[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int c = c0 + 64 * k + lane;
+                vals[k] = c < a.out_w ? cond_load(a, frame, r, c) : 0.f;
             }
-            dst[r * a.out_w + c] = v;
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int c = c0 + 64 * k + lane;
+                float v = vals[k];
+                if (a.quantile > 0.0f) {
+                    v = v / q;                                   // run.py:253; IEEE division (0/0 = NaN survives)
+                    v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);  // torch.clip keeps NaN
+                }
+                if (c < a.out_w) dst[r * a.out_w + c] = v;
+            }
         }
 }
 
