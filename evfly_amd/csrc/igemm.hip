@@ -529,27 +529,30 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 // store loop each load was followed by `s_waitcnt vmcnt(0)` -- a full memory round trip per piece, and the
                 // acknowledgement of the previous piece's store on top (16 pieces per thread; ConvLSTM h-GEMM, ViT residuals).
                 // A thread adds into the pieces it stores itself below: no barrier in between. Same sum: (acc + bias) + res.
-                constexpr int NP = BM * C4 / 256;
-                float4 rq[NP];
+                constexpr int NP = BM * C4 / 256, GRP = NP < 8 ? NP : 8;      // eight pieces (32 registers) in flight per thread
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const int idx = tid + k * 256, row = idx / C4, c4 = idx - row * C4;
-                    const int64_t m = m0 + row;
-                    const int n = n0 + c4 * 4;
-                    rq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < d.M && n < d.Nc) {
-                        int64_t rrow = m;
-                        if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
-                        rq[k] = *reinterpret_cast<const float4 *>(d.res + rrow * d.ldres + n);
+                for (int k0 = 0; k0 < NP; k0 += GRP) {
+                    float4 rq[GRP];
+#pragma unroll
+                    for (int k = 0; k < GRP; ++k) {
+                        const int idx = tid + (k0 + k) * 256, row = idx / C4, c4 = idx - row * C4;
+                        const int64_t m = m0 + row;
+                        const int n = n0 + c4 * 4;
+                        rq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (m < d.M && n < d.Nc) {
+                            int64_t rrow = m;
+                            if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
+                            rq[k] = *reinterpret_cast<const float4 *>(d.res + rrow * d.ldres + n);
+                        }
                     }
-                }
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const int idx = tid + k * 256, row = idx / C4, c4 = idx - row * C4;
-                    float4 *o = reinterpret_cast<float4 *>(ot + row * BN + c4 * 4);
-                    float4 v = *o;
-                    v.x += rq[k].x; v.y += rq[k].y; v.z += rq[k].z; v.w += rq[k].w;
-                    *o = v;
+                    for (int k = 0; k < GRP; ++k) {
+                        const int idx = tid + (k0 + k) * 256, row = idx / C4, c4 = idx - row * C4;
+                        float4 *o = reinterpret_cast<float4 *>(ot + row * BN + c4 * 4);
+                        float4 v = *o;
+                        v.x += rq[k].x; v.y += rq[k].y; v.z += rq[k].z; v.w += rq[k].w;
+                        *o = v;
+                    }
                 }
             }
 #pragma unroll 4
