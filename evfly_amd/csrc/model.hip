@@ -166,18 +166,21 @@ namespace {
 
 // ============================================================================ packing (host)
 // Conv2d weight (O, I, kh, kw) -> [O][kh][kw][I], k padded with zeros to a multiple of 32
-int pack_conv(evfly_model *m, const char *prefix, const std::string &key, const std::string &name, bool need = true) {
+// pad_cin: lay the weights out for an input whose channel count is padded to a multiple of 32 with zero channels (the
+// vectorised / DMA K walk of the GEMM kernel needs C % 32 == 0; the generic gather is an order of magnitude slower)
+int pack_conv(evfly_model *m, const char *prefix, const std::string &key, const std::string &name, bool need = true, bool pad_cin = false) {
     const HostTensor *t = m->find(key + ".weight", prefix);
     if (!t) { if (need) return fail(-4, "missing tensor %s%s.weight", prefix, key.c_str()); return 1; }
     EVFLY_REQUIRE(t->shape.size() == 4, "%s.weight: expected 4 dims", key.c_str());
     const int O = (int)t->shape[0], I = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
-    const int K = kh * kw * I, ld = round_up(K, 32);
-    float *dst = m->stage(name + ".w", (size_t)O * ld);
+    const int Ip = pad_cin ? round_up(I, 32) : I;
+    const int K = kh * kw * Ip, ld = round_up(K, 32);
+    float *dst = m->stage(name + ".w", (size_t)O * ld);        // (staged zero-filled)
     for (int o = 0; o < O; ++o)
         for (int i = 0; i < I; ++i)
             for (int y = 0; y < kh; ++y)
                 for (int x = 0; x < kw; ++x)
-                    dst[(size_t)o * ld + conv_k_index(y * kw + x, i, I, kh * kw)] = t->v[(((size_t)o * I + i) * kh + y) * kw + x];
+                    dst[(size_t)o * ld + conv_k_index(y * kw + x, i, Ip, kh * kw)] = t->v[(((size_t)o * I + i) * kh + y) * kw + x];
     m->wld[name] = ld;
     const HostTensor *b = m->find(key + ".bias", prefix);
     if (b) std::memcpy(m->stage(name + ".b", b->v.size()), b->v.data(), b->v.size() * 4);
@@ -419,7 +422,7 @@ int pack_vit(evfly_model *m) {
         }
     }
     if (c.head == EVFLY_HEAD_NONE) return 0;
-    if (int rc = pack_conv(m, kVitP, "down_sample", "ds")) return rc;
+    if (int rc = pack_conv(m, kVitP, "down_sample", "ds", true, true)) return rc;
     // decoder consumes out.flatten(1) of a (12,16,24) CHW tensor (vitfly_models.py:143); ours is HWC
     std::vector<int> perm(4608);
     for (int ch = 0; ch < 12; ++ch)
@@ -822,8 +825,11 @@ static int vit_chunk(evfly_model *m, const float *img, int ih, int iw, int clip2
     m->tap("s2", s2, F, h2, w2, c.vit_width[1]);
     EVFLY_REQUIRE(2 * h2 == 16 && 2 * w2 == 24, "ViT head expects a 16x24 map (got %dx%d)", 2 * h2, 2 * w2);
     // cat[PixelShuffle(2)(s2), Upsample(s1 -> 16x24, align_corners=True)]   (vitfly_models.py:141)
-    const int c_ps = c.vit_width[1] / 4, ccat = c_ps + c.vit_width[0];
+    // (pixel pitch padded to a multiple of 32 channels, the padding zero: the head conv then takes the GEMM kernel's
+    // vectorised K walk -- with 48 channels it fell back to the per-element gather, 0.14 ms for 2.5 GFLOP)
+    const int c_ps = c.vit_width[1] / 4, ccat_real = c_ps + c.vit_width[0], ccat = round_up(ccat_real, 32);
     float *cat = m->alloc((int64_t)F * 16 * 24 * ccat);
+    if (ccat != ccat_real && !m->planning) EVFLY_HIP(hipMemsetAsync(cat, 0, (size_t)F * 16 * 24 * ccat * 4, st));
     RUN(m, "vit_pixel_shuffle", 0, 8.0 * F * 384 * c_ps, launch_pixel_shuffle2(s2, F, h2, w2, c.vit_width[1], cat, ccat, st));
     RUN(m, "vit_upsample", 0, 8.0 * F * 384 * c.vit_width[0],
         launch_bilinear(s1, F, h1, w1, c.vit_width[0], c.vit_width[0], cat + c_ps, 16, 24, ccat, 1, 0, st));
