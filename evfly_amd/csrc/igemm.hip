@@ -27,6 +27,17 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;
 
+// ---- K-loop timestamps (developer build: -DEVFLY_IGEMM_TS; tools/igemm_ts.py): wave 0 of the first 4096 blocks stamps
+// s_memtime after the barrier, after the fragment reads, behind the MFMA burst and behind the closing barrier of K-steps 4..7
+#ifdef EVFLY_IGEMM_TS
+__device__ unsigned long long g_igemm_ts[4096 * 20];
+#define IGEMM_TSX(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_[slot] = t_; } while (0)
+#define IGEMM_TS(slot) do { if (kt >= kt0 + 4 && kt < kt0 + 7) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_[(kt - kt0 - 4) * 4 + (slot)] = t_; } } while (0)
+#else
+#define IGEMM_TS(slot) do { } while (0)
+#define IGEMM_TSX(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even, NaN kept
     unsigned u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
@@ -65,6 +76,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, int PREC, int NBUF>
 __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, int cpx, int dbg, int splits, float *slab) {
+#ifdef EVFLY_IGEMM_TS
+    unsigned long long ts_[20] = {};
+    IGEMM_TSX(16);
+#endif
     constexpr bool BF16 = PREC != 0;      // bf16 LDS tiles (PREC 1: plain bf16 operands, PREC 2: hi + lo tiles)
     constexpr bool X3 = PREC == 2;
     using elem_t = typename LdsElem<PREC>::type;
@@ -78,6 +93,11 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     elem_t *Bs = X3 ? Al + NBUF * BM * BK : Al;                     // [NBUF][BN][BK]
     elem_t *Bl = Bs + NBUF * BN * BK;                               // X3 only: low halves of W
 
+    // every kernel argument the prologue reads, requested in ONE batch (left alone hipcc sinks each s_load next to its first
+    // use: seven dependent scalar-memory round trips in front of the first tile request; tools/igemm_ts.py measured the
+    // prologue at 16.6 k cycles -- four K-steps' worth)
+    asm volatile("" :: "s"(d.x), "s"(d.w), "s"(d.ldx), "s"(d.ldw), "s"(d.NI), "s"(d.H), "s"(d.W), "s"(d.C), "s"(d.KH), "s"(d.KW), "s"(d.stride),
+                 "s"(d.pad), "s"(d.OH), "s"(d.OW), "s"(d.M), "s"(d.Nc), "s"(d.K), "s"(d.zeros), "s"(n_mt), "s"(n_nt), "s"(cpx), "s"(splits));
     // ---- XCD-contiguous tile mapping (placement only affects speed)
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
     const int mt = xcd * cpx + slot / n_nt, nt = slot % n_nt;
@@ -99,7 +119,18 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     const float *a_ptr[PA];
     int a_iy[PA], a_ix[PA];
     bool a_ok[PA];
-    {
+    if (d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1) {
+        // plain GEMM (1x1 conv, every Linear, the up-convolutions, the ConvLSTM projections): input pixel == output row, no
+        // decode (the general path below costs two integer divisions and, on maps narrower than 32 pixels, a divergent wrap
+        // loop per row group)
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int64_t m = m0 + lrow + 32 * p;
+            a_ok[p] = m < d.M;
+            a_iy[p] = a_ix[p] = 0;
+            a_ptr[p] = d.x + (a_ok[p] ? m : 0) * d.ldx + gchunk * 4;
+        }
+    } else {
         const int ohw = d.OH * d.OW;
         const int mfirst = (int)min(m0 + lrow, d.M - 1);
         int img = mfirst / ohw;
@@ -309,14 +340,20 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     const int frow = lane & 31, fh = lane >> 5;
 
     if (DMA) {
+        IGEMM_TSX(19);
         dma_tiles(kt0, 0);
+        IGEMM_TSX(15);
     } else {
         load_tiles(kt0);
         store_tiles(0);
     }
     __syncthreads();
     int cur = 0;
+#ifdef EVFLY_IGEMM_TS
+#endif
+    IGEMM_TSX(17);
     for (int kt = kt0; kt < nk; ++kt) {
+        IGEMM_TS(0);
         const elem_t *as = As + cur * BM * BK + (wm * WM) * BK;
         const elem_t *bs = Bs + cur * BN * BK + (wn * WN) * BK;
         if (X3) {
@@ -378,6 +415,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                     b[jj][j] = *reinterpret_cast<const float4 *>(bs + lds_off<false>(j * 32 + frow, 2 * jj + fh));
             }
             __builtin_amdgcn_sched_barrier(0);
+            IGEMM_TS(1);
             // the next tile is requested AFTER the fragment reads in program order: hipcc orders an LDS-DMA
             // against every later ds_read with a vmcnt(0) (it cannot see that the buffers differ)
             const bool more = kt + 1 < nk && dbg != 1;
@@ -416,7 +454,9 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             // pin the barrier (and the vmcnt(0) hipcc attaches to it while an LDS-DMA is in flight) BELOW the
             // MFMAs: they are register-only, so the scheduler would otherwise sink them under the barrier
             __builtin_amdgcn_sched_barrier(0);
+            IGEMM_TS(2);
             __syncthreads();
+            IGEMM_TS(3);
             if (dbg == 0 || DMA) cur ^= 1;
         } else {   // one LDS buffer (half the LDS, one more resident block per CU): two barriers per K-step
             __syncthreads();
@@ -425,6 +465,13 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
         }
     }
 
+    IGEMM_TSX(18);
+#ifdef EVFLY_IGEMM_TS
+    if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) g_igemm_ts[blockIdx.x * 20 + i] = ts_[i];
+    }
+#endif
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int ncol0 = n0 + wn * WN + frow;
     if (slab) {   // split-K partial sums: raw accumulators, [split][M][Nc]
@@ -674,6 +721,14 @@ int launch_by_n(const ConvDesc &d, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef EVFLY_IGEMM_TS
+}  // namespace evfly
+extern "C" int evfly_debug_igemm_ts(unsigned long long *out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evfly::g_igemm_ts), n * sizeof(unsigned long long));
+}
+namespace evfly {
+#endif
 
 int igemm_zero_page(const float **out) {
     static const float *pages[64] = {};
