@@ -74,12 +74,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, int PREC, int NBUF>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VECM, int PREC, int NBUF>
 __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, int cpx, int dbg, int splits, float *slab) {
 #ifdef EVFLY_IGEMM_TS
     unsigned long long ts_[20] = {};
     IGEMM_TSX(16);
 #endif
+    // VECM: 0 generic gather (any C), 1 vectorised K walk (C % 32 == 0), 2 the same for a plain GEMM (1x1, stride 1, no
+    // padding: every Linear, the up-convolutions, the ConvLSTM projections) -- no tap cursor, no padding tests, no pixel decode
+    constexpr bool VEC = VECM != 0, PLAIN = VECM == 2;
     constexpr bool BF16 = PREC != 0;      // bf16 LDS tiles (PREC 1: plain bf16 operands, PREC 2: hi + lo tiles)
     constexpr bool X3 = PREC == 2;
     using elem_t = typename LdsElem<PREC>::type;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     const float *a_ptr[PA];
     int a_iy[PA], a_ix[PA];
     bool a_ok[PA];
-    if (d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1) {
+    if (PLAIN || (d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1)) {
         // plain GEMM (1x1 conv, every Linear, the up-convolutions, the ConvLSTM projections): input pixel == output row, no
         // decode (the general path below costs two integer divisions and, on maps narrower than 32 pixels, a divergent wrap
         // loop per row group)
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             }
         }
     }
-    const bool padded = d.pad > 0;
+    const bool padded = !PLAIN && d.pad > 0;
     const float *b_ptr[PB];
     bool b_ok[PB];
 #pragma unroll
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     const int kt0 = splits == 1 ? 0 : (int)((unsigned)nk_total * blockIdx.y / (unsigned)splits);
     const int nk = splits == 1 ? nk_total : (int)((unsigned)nk_total * (blockIdx.y + 1) / (unsigned)splits);
     int tc0 = 0, tkx = 0, tky = 0;
-    if (VEC && kt0 > 0) {
+    if (PLAIN) tc0 = kt0 * BK;
+    else if (VEC && kt0 > 0) {
         const int ntaps = d.KH * d.KW, cc = kt0 / ntaps, tap = kt0 - cc * ntaps;
         tc0 = cc * BK; tky = tap / d.KW; tkx = tap - tky * d.KW;
     }
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
         if (VEC) {   // C % 32 == 0: the whole K-step lies inside one (ky, kx) tap
-            const int64_t toff = ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
+            const int64_t toff = PLAIN ? (int64_t)tc0 : ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
             a_mask = 0;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -206,7 +210,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 ra[p] = *reinterpret_cast<const float4 *>(src);
                 a_mask |= (ok ? 1u : 0u) << p;
             }
-            if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } }   // taps fastest, channel chunk slowest
+            if (PLAIN) tc0 += BK;
+            else if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } }   // taps fastest, channel chunk slowest
         } else {     // generic gather: any C / K (tiny layers only)
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
     typedef const __attribute__((address_space(1))) void glb_void;
     auto dma_tiles = [&](int kt, int buf) {
         const int k0 = kt * BK;
-        const int64_t toff = ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
+        const int64_t toff = PLAIN ? (int64_t)tc0 : ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
         float *as = reinterpret_cast<float *>(As) + buf * BM * BK + (wv * 8) * BK;
         float *bs = reinterpret_cast<float *>(Bs) + buf * BN * BK + (wv * 8) * BK;
 #pragma unroll
@@ -254,13 +259,14 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             const float *src = b_ok[p] ? b_ptr[p] + k0 : d.zeros;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(bs + p * 32 * BK), 16, 0, 0);
         }
-        if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } }
+        if (PLAIN) tc0 += BK;
+        else if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } }
     };
     // one row group q of the next tile (q < PA: activations, else weights); used to spread the requests
     // between the MFMAs of a K-step instead of issuing them as one burst
     auto dma_one = [&](int q, int kt, int buf) {
         if (q < PA) {
-            const int64_t toff = ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
+            const int64_t toff = PLAIN ? (int64_t)tc0 : ((int64_t)tky * d.W + tkx) * d.ldx + tc0;
             float *as = reinterpret_cast<float *>(As) + buf * BM * BK + (wv * 8) * BK;
             bool ok = a_ok[q];
             if (padded) {
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(bs + p * 32 * BK), 16, 0, 0);
         }
     };
-    auto dma_advance = [&]() { if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } } };
+    auto dma_advance = [&]() { if (PLAIN) tc0 += BK; else if (++tkx == d.KW) { tkx = 0; if (++tky == d.KH) { tky = 0; tc0 += BK; } } };
     auto store_tiles = [&](int buf) {
         elem_t *as = As + buf * BM * BK, *bs = Bs + buf * BN * BK;
 #pragma unroll
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvDesc d, int splits, c
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, int PREC, int NBUF>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int PREC, int NBUF>
 int launch_cfg(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv(d.M, BM), n_nt = cdiv(d.Nc, BN);
     const int cpx = cdiv(n_mt, kNumXCD);
@@ -707,7 +713,7 @@ int launch_cfg(const ConvDesc &d, hipStream_t st) {
     return 0;
 }
 
-template <bool VEC, int PREC>
+template <int VEC, int PREC>
 int launch_by_n(const ConvDesc &d, hipStream_t st) {
     static const int nbuf = getenv("EVFLY_IGEMM_NBUF") ? atoi(getenv("EVFLY_IGEMM_NBUF")) : 2;
     if (nbuf == 2) {
@@ -757,9 +763,10 @@ int igemm_launch(const ConvDesc &d_in, hipStream_t st) {
                   "igemm: bad upconv epilogue");
     const bool vec = d.C % BK == 0;   // decides the K order: the packer applies the same rule
     EVFLY_REQUIRE(!vec || (d.ldx % 4 == 0 && ((uintptr_t)d.x) % 16 == 0), "igemm: input not 16-byte aligned");
-    if (d.dtype == EVFLY_DTYPE_BF16X3) return vec ? launch_by_n<true, 2>(d, st) : launch_by_n<false, 2>(d, st);
-    if (d.dtype == EVFLY_DTYPE_BF16) return vec ? launch_by_n<true, 1>(d, st) : launch_by_n<false, 1>(d, st);
-    return vec ? launch_by_n<true, 0>(d, st) : launch_by_n<false, 0>(d, st);
+    const bool plain = vec && d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1;
+    if (d.dtype == EVFLY_DTYPE_BF16X3) return !vec ? launch_by_n<0, 2>(d, st) : plain ? launch_by_n<2, 2>(d, st) : launch_by_n<1, 2>(d, st);
+    if (d.dtype == EVFLY_DTYPE_BF16) return !vec ? launch_by_n<0, 1>(d, st) : plain ? launch_by_n<2, 1>(d, st) : launch_by_n<1, 1>(d, st);
+    return !vec ? launch_by_n<0, 0>(d, st) : plain ? launch_by_n<2, 0>(d, st) : launch_by_n<1, 0>(d, st);
 }
 
 }  // namespace evfly
