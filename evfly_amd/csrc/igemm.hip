@@ -473,10 +473,9 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
 
     IGEMM_TSX(18);
 #ifdef EVFLY_IGEMM_TS
-    if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
-#pragma unroll
-        for (int i = 0; i < 20; ++i) g_igemm_ts[blockIdx.x * 20 + i] = ts_[i];
-    }
+#define IGEMM_TS_FLUSH() do { IGEMM_TSX(14); if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) { _Pragma("unroll") for (int i = 0; i < 20; ++i) g_igemm_ts[blockIdx.x * 20 + i] = ts_[i]; } } while (0)
+#else
+#define IGEMM_TS_FLUSH() do { } while (0)
 #endif
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int ncol0 = n0 + wn * WN + frow;
@@ -532,6 +531,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 float *dst = d.y + ((((int64_t)img * 2 * d.OH + 2 * iy + (q >> 1)) * (2 * d.OW)) + 2 * ix + (q & 1)) * d.ldy + co;
                 *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(ot + row * BN + c4 * 4);
             }
+            IGEMM_TS_FLUSH();
             return;
         }
 #pragma unroll
@@ -608,6 +608,22 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                     }
                 }
             }
+            if (act == ACT_NONE && m0 + BM <= d.M && n0 + BN <= d.Nc) {
+                // whole tile inside the matrix, nothing to apply (every GEMM of the ConvLSTM, most ViT linears): a thread's
+                // pieces sit 256 / C4 rows apart -- one running pointer, no per-piece index arithmetic or bounds tests
+                constexpr int RSTEP = 256 / C4;
+                const int row0 = tid / C4, c4 = tid - row0 * C4;
+                float *dst = d.y + (m0 + row0) * d.ldy + n0 + c4 * 4;
+                const float *src = ot + row0 * BN + c4 * 4;
+                const int64_t dstep = (int64_t)RSTEP * d.ldy;
+#pragma unroll
+                for (int k = 0; k < BM * C4 / 256; ++k) {
+                    *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src + k * RSTEP * BN);
+                    dst += dstep;
+                }
+                IGEMM_TS_FLUSH();
+                return;
+            }
 #pragma unroll 4
             for (int idx = tid; idx < BM * C4; idx += 256) {
                 const int row = idx / C4, c4 = idx - row * C4;
@@ -622,6 +638,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 }
                 *reinterpret_cast<float4 *>(d.y + m * d.ldy + n) = v;
             }
+            IGEMM_TS_FLUSH();
             return;
         }
 #pragma unroll

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from evfly_amd import _lib
-SHAPES = {"lstm_x": (320, 8, 13, 512, 2048), "lstm_h": (64, 8, 13, 512, 2048), "up1": (320, 8, 13, 512, 1024), "up2": (320, 12, 22, 256, 512)}
+SHAPES = {"lstm_x": (320, 8, 13, 512, 2048), "lstm_h": (64, 8, 13, 512, 2048), "up1": (320, 8, 13, 512, 1024), "up2": (320, 12, 22, 256, 512),
+          "up3": (320, 20, 40, 128, 256), "up4": (320, 36, 76, 64, 128), "vit_fc": (320, 17, 22, 64, 512)}
 name = sys.argv[1] if len(sys.argv) > 1 else "lstm_x"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n, h, w, cin, cout = SHAPES[name]
@@ -30,4 +31,4 @@ print(f"{name}: {len(t)} blocks; per K-step (64 MFMAs = 4096 cycles alone): tota
       f"MFMA burst + DMA requests {np.median(burst):.0f}  barrier wait (vmcnt(0) + s_barrier) {np.median(bar):.0f}")
 pro = raw[:, 17] - raw[:, 16]; loop = raw[:, 18] - raw[:, 17]
 print(f"  entry -> first tile request {np.median(raw[:, 19] - raw[:, 16]):.0f}  issuing it {np.median(raw[:, 15] - raw[:, 19]):.0f}  -> first barrier passed {np.median(raw[:, 17] - raw[:, 15]):.0f}")
-print(f"  prologue (entry -> K loop) {np.median(pro):.0f}  K loop {np.median(loop):.0f} cycles ({cin // 32} steps); the epilogue ends the block (not stamped: stores are asynchronous)")
+print(f"  prologue (entry -> K loop) {np.median(pro):.0f}  K loop {np.median(loop):.0f} cycles ({cin // 32} steps);  epilogue (loop end -> last store issued) {np.median(raw[:, 14] - raw[:, 18]):.0f}")
