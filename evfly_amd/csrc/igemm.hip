@@ -519,6 +519,27 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                 }
             __syncthreads();
             constexpr int C4 = BN / 4;
+            if (m0 + BM <= d.M && n0 + BN <= d.Nc) {
+                // whole tile inside the matrix: a thread's pieces share their column group (quadrant q, channel co) and sit
+                // 256 / C4 input pixels apart -- one pixel decode per thread, then the raster position is advanced
+                constexpr int RSTEP = 256 / C4;
+                const int row0 = tid / C4, c4 = tid - row0 * C4;
+                const int n = n0 + c4 * 4, q = n / d.up_cout, co = n - q * d.up_cout;
+                const int mi = (int)m0 + row0;
+                int img = mi / hw, rem = mi - img * hw;
+                int iy = rem / d.OW, ix = rem - iy * d.OW;
+                const float *src = ot + row0 * BN + c4 * 4;
+                float *ybase = d.y + ((int64_t)(q >> 1) * (2 * d.OW) + (q & 1)) * d.ldy + co;
+#pragma unroll
+                for (int k = 0; k < BM * C4 / 256; ++k) {
+                    float *dst = ybase + (((int64_t)img * 2 * d.OH + 2 * iy) * (2 * d.OW) + 2 * ix) * d.ldy;
+                    *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src + k * RSTEP * BN);
+                    ix += RSTEP;
+                    while (ix >= d.OW) { ix -= d.OW; if (++iy == d.OH) { iy = 0; ++img; } }
+                }
+                IGEMM_TS_FLUSH();
+                return;
+            }
 #pragma unroll 2
             for (int idx = tid; idx < BM * C4; idx += 256) {
                 const int row = idx / C4, c4 = idx - row * C4;
