@@ -366,10 +366,16 @@ __global__ __launch_bounds__(256) void k_grouped_conv_gelu(const float *__restri
     }
 }
 
-// LDS-tiled variant for small maps (H*W*32*4 B <= 64 KB; both ViT stages): one block = one frame x a slab
-// of 32 channels (4 groups). The slab is staged once; thread = (output channel of the slab, pixel lane),
-// its 72 weights live in registers, the 8 threads of a group read identical LDS addresses (broadcast).
-__global__ __launch_bounds__(256) void k_grouped_conv_gelu_lds(const float *__restrict__ x, int H, int W, int Ce,
+// LDS-tiled variant for small maps (H*W*32*4 B <= 64 KB; both ViT stages): one block = one frame x a slab of 32 channels
+// (4 groups). The slab is staged once; thread = (PAIR of adjacent output channels of one group, pixel lane): the two
+// channels read the same eight inputs per tap, so their 2 x 72 FMAs run as 72 v_pk_fma_f32 on the accumulator pair with
+// the input broadcast from one half of its register pair (op_sel) and the weight pair (w[co][k][t], w[co + 1][k][t]) in
+// registers -- a packed f32 op costs the SIMD what one v_fma_f32 does (tools/ubench/mfma_valu.hip). Inline asm: hipcc
+// scalarises packed IR whose results are read element-wise. Per output the operands and their order are those of the
+// untiled kernel (k fastest, then the taps): the same bits.
+typedef float gc_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gc_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_grouped_conv_gelu_lds(const float *__restrict__ x, int H, int W, int Ce,
                                                                const float *__restrict__ w, const float *__restrict__ bias,
                                                                float *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [H*W][32]
@@ -380,16 +386,16 @@ __global__ __launch_bounds__(256) void k_grouped_conv_gelu_lds(const float *__re
         const int p = i >> 3, c4 = i & 7;
         reinterpret_cast<float4 *>(tile)[i] = *reinterpret_cast<const float4 *>(src + (int64_t)p * Ce + c4 * 4);
     }
-    const int col = threadIdx.x & 31, plane = threadIdx.x >> 5;
-    const int co = slab * 32 + col, g8 = (col >> 3) << 3;
-    float wr[72];
+    const int cp = threadIdx.x & 15, plane = threadIdx.x >> 4;          // channel pair 0..15 of the slab, 16 pixel lanes
+    const int co = slab * 32 + 2 * cp, g8 = (cp >> 2) << 3;
+    gc_f32x2 wp[72];                                                     // (w[co][k][t], w[co + 1][k][t]) at k * 9 + t
 #pragma unroll
-    for (int k = 0; k < 72; ++k) wr[k] = w[(int64_t)co * 72 + k];
-    const float b = bias[co];
+    for (int k = 0; k < 72; ++k) wp[k] = gc_f32x2{w[(int64_t)co * 72 + k], w[(int64_t)(co + 1) * 72 + k]};
+    const gc_f32x2 b2 = {bias[co], bias[co + 1]};
     __syncthreads();
-    for (int p = plane; p < hw; p += 8) {
+    for (int p = plane; p < hw; p += 16) {
         const int oy = p / W, ox = p - oy * W;
-        float acc = b;
+        gc_f32x2 acc = b2;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy + ky - 1;
@@ -398,16 +404,24 @@ __global__ __launch_bounds__(256) void k_grouped_conv_gelu_lds(const float *__re
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox + kx - 1;
                 if (ix < 0 || ix >= W) continue;
-                const float4 *sp = reinterpret_cast<const float4 *>(tile + (iy * W + ix) * 32 + g8);
-                const float4 v0 = sp[0], v1 = sp[1];
+                const gc_f32x4 *sp = reinterpret_cast<const gc_f32x4 *>(tile + (iy * W + ix) * 32 + g8);
+                const gc_f32x4 v0 = sp[0], v1 = sp[1];
+                const gc_f32x2 i01 = v0.xy, i23 = v0.zw, i45 = v1.xy, i67 = v1.zw;
                 const int t = ky * 3 + kx;
-                acc = fmaf(v0.x, wr[0 * 9 + t], acc); acc = fmaf(v0.y, wr[1 * 9 + t], acc);
-                acc = fmaf(v0.z, wr[2 * 9 + t], acc); acc = fmaf(v0.w, wr[3 * 9 + t], acc);
-                acc = fmaf(v1.x, wr[4 * 9 + t], acc); acc = fmaf(v1.y, wr[5 * 9 + t], acc);
-                acc = fmaf(v1.z, wr[6 * 9 + t], acc); acc = fmaf(v1.w, wr[7 * 9 + t], acc);
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(i01), "v"(wp[0 * 9 + t]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(i01), "v"(wp[1 * 9 + t]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(i23), "v"(wp[2 * 9 + t]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(i23), "v"(wp[3 * 9 + t]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(i45), "v"(wp[4 * 9 + t]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(i45), "v"(wp[5 * 9 + t]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(i67), "v"(wp[6 * 9 + t]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(i67), "v"(wp[7 * 9 + t]));
             }
         }
-        y[((int64_t)img * hw + p) * Ce + co] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
+        float2 o;
+        o.x = 0.5f * acc.x * (1.0f + erff(acc.x * 0.70710678118654752440f));
+        o.y = 0.5f * acc.y * (1.0f + erff(acc.y * 0.70710678118654752440f));
+        *reinterpret_cast<float2 *>(y + ((int64_t)img * hw + p) * Ce + co) = o;
     }
 }
 
