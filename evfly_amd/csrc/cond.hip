@@ -13,6 +13,7 @@ namespace {
 constexpr int kCondThreads = 1024;
 constexpr int kCondBins = 2048;     // 11 key bits per select pass (three passes over the frame instead of four 8-bit ones)
 constexpr int kBatch = 6;   // columns fetched per lane before binning (6 x 64 >= 346)
+constexpr int kRows = 2;    // rows fetched per wave before binning
 
 struct CondArgs {
     const uint8_t *u8;
@@ -53,20 +54,27 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
             const unsigned p0 = prefix[0], p1 = prefix[1];
             // wave w walks rows w, w+16, ...; lanes walk the columns (no per-element division). Trip counts are
             // wave-uniform: the ballots below need the whole wave.
-            for (int r = wave; r < a.out_h; r += kCondThreads / 64)
+            // two rows (kRows x kBatch loads) are in flight per iteration: the walk is L2-latency bound
+            for (int r0 = wave; r0 < a.out_h; r0 += kRows * (kCondThreads / 64))
               for (int c0 = 0; c0 < a.out_w; c0 += 64 * kBatch) {
-                // the loop is L2-latency bound (ballots / LDS atomics keep hipcc from pipelining it): fetch a
-                // batch of columns first, then bin them
-                float vals[kBatch];
+                // (ballots / LDS atomics keep hipcc from pipelining the loop: fetch the batch first, then bin it)
+                float vals[kRows][kBatch];
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) {
-                    const int c = c0 + 64 * k + lane;
-                    vals[k] = c < a.out_w ? cond_load(a, frame, r, c) : 0.f;
+                for (int rr = 0; rr < kRows; ++rr) {
+                    const int r = r0 + rr * (kCondThreads / 64);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const int c = c0 + 64 * k + lane;
+                        vals[rr][k] = (r < a.out_h && c < a.out_w) ? cond_load(a, frame, r, c) : 0.f;
+                    }
                 }
 #pragma unroll
+                for (int rr = 0; rr < kRows; ++rr) {
+                const bool row_live = r0 + rr * (kCondThreads / 64) < a.out_h;           // wave-uniform
+#pragma unroll
                 for (int k = 0; k < kBatch; ++k) {
-                    const bool live = c0 + 64 * k + lane < a.out_w;
-                    const unsigned key = live ? __float_as_uint(fabsf(vals[k])) : 0u;
+                    const bool live = row_live && c0 + 64 * k + lane < a.out_w;
+                    const unsigned key = live ? __float_as_uint(fabsf(vals[rr][k])) : 0u;
                     unsigned hi = pass == 0 ? 0u : key >> (shift + bits);
                     if (!live) hi = 0xffffffffu;                     // matches no prefix (prefixes have < 32 bits)
                     const unsigned byte = (key >> shift) & ((1u << bits) - 1u);
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
                         }
                         todo &= ~same;
                     }
+                }
                 }
               }
             __syncthreads();
