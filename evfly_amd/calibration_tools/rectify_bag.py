@@ -50,47 +50,59 @@ def init_undistort_rectify_map(K, D, R, P, size):
     return u.astype(np.float32), v.astype(np.float32)
 
 
+def _rotation_of(entry):
+    """Rotation block of a Kalibr camchain entry: `T_cn_cnm1` is the 4x4 transform from the previous camera of the
+    chain into this one; the first camera of a chain has none and is the chain's origin."""
+    T = entry.get("T_cn_cnm1")
+    return np.eye(3) if T is None else np.asarray(T, dtype=np.float64)[:3, :3].copy()
+
+
 class Camera:
-    """rectify_bag.py:7-26."""
+    """One camera of a Kalibr camchain entry (the fields rectify_bag.py:7-26 exposes: `K` / `intrinsics`,
+    `distortion_coeffs`, `distortion_model`, `resolution`, `R`, `num_pixels`)."""
 
     def __init__(self, data):
-        self.intrinsics = np.eye(3)
-        self.intrinsics[[0, 1, 0, 1], [0, 1, 2, 2]] = data["intrinsics"]
-        self.distortion_coeffs = np.array(data["distortion_coeffs"])
+        fx, fy, cx, cy = (float(v) for v in data["intrinsics"])
+        self.K = np.array([[fx, 0.0, cx],
+                           [0.0, fy, cy],
+                           [0.0, 0.0, 1.0]])
+        self.intrinsics = self.K                        # the reference keeps both names for one matrix
         self.distortion_model = data["distortion_model"]
-        self.resolution = data["resolution"]
-        if "T_cn_cnm1" not in data:
-            self.R = np.eye(3)
-        else:
-            self.R = np.array(data['T_cn_cnm1'])[:3, :3]
-        self.K = self.intrinsics
+        self.distortion_coeffs = np.asarray(data["distortion_coeffs"], dtype=np.float64)
+        self.resolution = list(data["resolution"])      # [width, height]
+        self.R = _rotation_of(data)
 
     @property
     def num_pixels(self):
-        return np.prod(self.resolution)
+        width, height = self.resolution[0], self.resolution[1]
+        return int(width) * int(height)
 
 
 class CameraSystem:
-    """rectify_bag.py:28-89."""
+    """Frame camera + event camera of a two-camera camchain and the common rectified model (`newK`, `newR`,
+    `newres`) both are mapped onto (rectify_bag.py:28-55). The camera with more pixels is the frame camera `cam`,
+    the other one the event camera `event_cam`; the rectified intrinsics and resolution are the event camera's.
+    fix_rotation=True (what `Aligner` uses, :121) keeps the frame camera's orientation; otherwise the new x axis is
+    laid along the stereo baseline (the translation of cam1's `T_cn_cnm1`), y = z_cam x baseline direction and
+    z completes the right-handed frame; the baseline in pixels is reported like the reference does."""
 
     def __init__(self, data, fix_rotation=False):
-        T = np.array(data['cam1']['T_cn_cnm1'])
-        cam0 = Camera(data['cam0'])
-        cam1 = Camera(data['cam1'])
-        self.cam, self.event_cam = (cam0, cam1) if cam0.num_pixels > cam1.num_pixels else (cam1, cam0)
-        if not fix_rotation:
-            self.newK = self.event_cam.K
-            self.t = T[:3, 3]
-            r3_cam0 = self.cam.R[:, 2]
-            r1 = self.t / np.linalg.norm(self.t)
-            r2 = np.cross(r3_cam0, r1)
-            r3 = np.cross(r1, r2)
-            self.newR = np.stack([r1, r2, r3], -1)
-            print("distance: %s" % (np.linalg.norm(self.t) * self.newK[0, 0]))
-        else:
+        cams = sorted((Camera(data[name]) for name in ("cam0", "cam1")), key=lambda c: c.num_pixels)
+        if cams[0].num_pixels == cams[1].num_pixels:    # a tie leaves cam1 as the frame camera (:36)
+            cams = [Camera(data["cam0"]), Camera(data["cam1"])]
+        self.event_cam, self.cam = cams
+        self.newK = self.event_cam.K
+        self.newres = (self.event_cam.resolution[0], self.event_cam.resolution[1])
+        if fix_rotation:
             self.newR = self.cam.R
-            self.newK = self.event_cam.K
-        self.newres = tuple(self.event_cam.resolution)
+            return
+        self.t = np.asarray(data["cam1"]["T_cn_cnm1"], dtype=np.float64)[:3, 3]
+        baseline = float(np.linalg.norm(self.t))
+        x_axis = self.t / baseline
+        y_axis = np.cross(self.cam.R[:, 2], x_axis)     # not re-normalised (neither does the reference)
+        z_axis = np.cross(x_axis, y_axis)
+        self.newR = np.column_stack((x_axis, y_axis, z_axis))
+        print("distance: %s" % (baseline * self.newK[0, 0]))
 
     def getRemapping(self):
         img_mapx, img_mapy = init_undistort_rectify_map(self.cam.K, self.cam.distortion_coeffs, None,

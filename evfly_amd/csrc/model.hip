@@ -68,6 +68,10 @@ struct evfly_model {
     std::vector<ProfAgg> agg;
     hipStream_t st = nullptr;
     int vp_hidden = 0;   // lstm_velpred hidden size = flattened conv features (set at finalize)
+    // full-resolution encoder maps: kept complete when EVFLY_FULL_ENCODER_OUTPUTS is set at evfly_model_create time (debug
+    // taps "e1".."e4"); otherwise the fused-skip Winograd launches store only the block-border pixels (`skip_bands`)
+    bool full_encoder_outputs = false;
+    bool bands_used = false;   // the last forward left "e1".."e4" partial
 
     ~evfly_model() {
         if (wdev) (void)hipFree(wdev);
@@ -500,8 +504,8 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
             wino_block_region(d, &skip_region[0], &skip_region[1]);
             if (skip_region[0] == 0) d.skip_y = nullptr;
             // the map's other readers: the 2x2 pool (fused above) and the debug taps "e1".."e4"
-            static const bool full_maps = getenv("EVFLY_FULL_ENCODER_OUTPUTS") != nullptr;
-            d.skip_bands = d.skip_y && y_pool && !full_maps;
+            d.skip_bands = d.skip_y && y_pool && !m->full_encoder_outputs;
+            if (d.skip_bands && !m->planning) m->bands_used = true;
         }
         if (!m->planning && m->profiling) m->next_exec = wino_exec_flops(d);   // only a profiled launch consumes it
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes, wino_launch(d, m->W(wname + ".u"), m->st));
@@ -529,6 +533,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
                       float *vp_c = nullptr) {
     const auto &c = m->cfg;
     const int F = S * T;
+    if (!m->planning) m->bands_used = false;
     const int cin = (c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels;
     const int apply_form = (c.num_in_channels == 2 || c.form_bev > 0) ? 1 : 0;   // learner_models.py:523
     hipStream_t st = m->st;
@@ -1017,6 +1022,7 @@ extern "C" int evfly_model_create(const evfly_model_config *cfg, evfly_model **o
     EVFLY_REQUIRE(cfg->compute_dtype >= EVFLY_DTYPE_F32 && cfg->compute_dtype <= EVFLY_DTYPE_BF16X3, "bad compute_dtype");
     auto *m = new evfly_model();
     m->cfg = *cfg;
+    m->full_encoder_outputs = getenv("EVFLY_FULL_ENCODER_OUTPUTS") != nullptr;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(-2, "hipGetDevice failed"); }
     *out = m;
     return 0;
@@ -1058,6 +1064,9 @@ extern "C" int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_
     EVFLY_REQUIRE(m && name && dst_host, "tap: null argument");
     auto it = m->taps.find(name);
     EVFLY_REQUIRE(it != m->taps.end(), "tap '%s' was not produced by the last forward", name);
+    EVFLY_REQUIRE(!(m->bands_used && name[0] == 'e' && name[1] >= '1' && name[1] <= '4' && name[2] == 0),
+                  "tap '%s' is partial: the last forward stored only the block-border pixels of the full-resolution encoder maps "
+                  "(fused 'interp' skip). Set EVFLY_FULL_ENCODER_OUTPUTS=1 before the handle is created to keep them complete", name);
     int64_t n = 1;
     for (int i = 0; i < 4; ++i) { n *= it->second.shape[i]; if (shape_out) shape_out[i] = it->second.shape[i]; }
     EVFLY_REQUIRE(n <= max_elems, "tap '%s' has %lld elements, buffer holds %lld", name, (long long)n, (long long)max_elems);

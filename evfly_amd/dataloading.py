@@ -101,9 +101,13 @@ def _condition_events(evs, rescale_evs, evs_min_cutoff, logger):
         if rescale_evs > 0.0:
             x = torch.clamp(x / rescale_evs, -1.0, 1.0)
         elif rescale_evs == -1.0:
-            n, h, w = x.shape
-            x, q = voxelizer.condition_frames(x, out_hw=(h, w), quantile=0.97, return_q=True)
-            x = x.reshape(n, h, w)
+            # A one-frame trajectory arrives 2-D (`_resize_list` squeezes like the reference does). Deviation, on purpose:
+            # the reference then takes the quantile per image ROW (`ev.view(ev.shape[0], -1)`, dataloading.py:518) and its
+            # `(h,1,1)` broadcast blows the frame up to (h, h, w); here the lone frame is conditioned as ONE frame.
+            shape = x.shape
+            h, w = shape[-2], shape[-1]
+            x, q = voxelizer.condition_frames(x.reshape(-1, h, w), out_hw=(h, w), quantile=0.97, return_q=True)
+            x = x.reshape(shape)
             pct.append(float(q.mean()))
         if evs_min_cutoff is not None:
             x[x.abs() < evs_min_cutoff] = 0.0

@@ -14,24 +14,33 @@ def shard_streams(n_streams, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-_COUNTS = {}      # (world, rank-local rows) -> per-rank row counts, exchanged once
+def shard_row_counts(n_streams, world, rows_per_stream):
+    """Velocity rows every rank contributes when `n_streams` streams of `rows_per_stream` steps are sharded with
+    `shard_streams`: the same list on every rank, computed without an exchange."""
+    return [(s1 - s0) * rows_per_stream for s0, s1 in (shard_streams(n_streams, r, world) for r in range(world))]
 
 
-def gather_velocities(vel, dist=None):
+def gather_velocities(vel, dist=None, counts=None):
     """all_gather of (rows, 3) velocity tensors in rank order; `dist` = torch.distributed or None.
-    The per-rank row counts are exchanged on the first call for a given local row count and cached (the
-    benchmark calls this once per step with fixed shapes: no count exchange or host sync inside the timed loop).
-    Contract: every rank keeps its own row count fixed between calls that share a cache entry."""
+
+    `counts` = the per-rank row counts (`shard_row_counts`), identical on every rank: with them the call issues exactly
+    one collective and no host synchronisation (the benchmark's per-step call). Without them the counts are exchanged
+    by an all_gather of one int64 first -- on EVERY call: nothing is cached, because whether a cache entry exists
+    could only be decided from rank-local data (this rank's own row count), and two ranks that decide differently
+    issue mismatched collectives."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return vel
     world = dist.get_world_size()
-    key = (world, vel.shape[0])
-    counts = _COUNTS.get(key)
     if counts is None:
         rows = torch.tensor([vel.shape[0]], device=vel.device, dtype=torch.int64)
         got = [torch.zeros_like(rows) for _ in range(world)]
         dist.all_gather(got, rows)
-        counts = _COUNTS[key] = [int(c.item()) for c in got]
+        counts = [int(c.item()) for c in got]
+    else:
+        counts = [int(c) for c in counts]
+        if len(counts) != world or counts[dist.get_rank()] != vel.shape[0]:
+            raise ValueError(f"gather_velocities: counts {counts} do not describe this call (world {world}, "
+                             f"rank {dist.get_rank()} holds {vel.shape[0]} rows)")
     if len(set(counts)) == 1:
         out = torch.empty(world * counts[0], vel.shape[1], device=vel.device, dtype=vel.dtype)
         dist.all_gather_into_tensor(out, vel.contiguous())

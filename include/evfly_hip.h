@@ -263,9 +263,10 @@ int evfly_e2v_forward(evfly_model *m, const float *frames, const float *desvel, 
  * `stream`). Writes up to 4 dims into shape_out and returns the element count (negative on error).
  * Names: "e1".."e5", "e5_lstm", "d1".."d4", "vit_in", "s1", "s2", "flat", "x517". NHWC.
  * "e1".."e4" (the full-resolution encoder maps) are complete only when the environment variable
- * EVFLY_FULL_ENCODER_OUTPUTS is set: in exact-fp32 mode with skip_type 'interp' the producing kernel
- * writes the pooled map and the resampled skip itself and keeps of the full map only the block-border
- * pixels the remaining skip pixels are resampled from. */
+ * EVFLY_FULL_ENCODER_OUTPUTS was set when the handle was created (read by evfly_model_create): in exact-fp32
+ * mode with skip_type 'interp' the producing kernel writes the pooled map and the resampled skip itself
+ * and keeps of the full map only the block-border pixels the remaining skip pixels are resampled from.
+ * Asking for one of them after such a forward is an error (-1), not a partly stale buffer. */
 int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_host, int64_t max_elems,
                         int64_t *shape_out, void *stream);
 

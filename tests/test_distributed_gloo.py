@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from _util import GOLDEN  # noqa: F401
-from evfly_amd.distributed import gather_velocities, shard_streams
+from evfly_amd.distributed import gather_velocities, shard_row_counts, shard_streams
 
 
 def _worker(rank, world, port, n_streams, T, q):
@@ -39,6 +39,53 @@ def test_shard_and_gather(n_streams):
     want = torch.tensor([[s, t, s * 100 + t] for s in range(n_streams) for t in range(T)], dtype=torch.float32)
     for r in range(world):
         assert torch.equal(torch.tensor(outs[r]), want)
+
+
+def _rows(s0, s1, T):
+    return torch.tensor([[s, t, s * 100 + t] for s in range(s0, s1) for t in range(T)], dtype=torch.float32).reshape(-1, 3)
+
+
+def _worker_twice(rank, world, port, T, q):
+    """Two gathers in ONE process group: even shards (64 streams), then ragged ones (65) in which rank 1 keeps the row
+    count it had before while rank 0's grows -- the case a cache keyed on rank-local data deadlocks on; then the same
+    two again with the counts supplied by the caller (the benchmark's form: one collective per call)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    for n_streams, explicit in ((64, False), (65, False), (64, True), (65, True)):
+        s0, s1 = shard_streams(n_streams, rank, world)
+        counts = shard_row_counts(n_streams, world, T) if explicit else None
+        res.append(gather_velocities(_rows(s0, s1, T), dist, counts=counts).tolist())
+    try:
+        gather_velocities(_rows(0, 3, T), dist, counts=[1] * world)
+        res.append("no error")
+    except ValueError:
+        res.append("ValueError")
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_twice_even_then_ragged_same_group():
+    world, T = 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_twice, args=(r, world, port, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for got, n_streams in zip(outs[r][:4], (64, 65, 64, 65)):
+            assert torch.equal(torch.tensor(got), _rows(0, n_streams, T))
+        assert outs[r][4] == "ValueError"
+
+
+def test_shard_row_counts():
+    assert shard_row_counts(65, 2, 5) == [165, 160] and shard_row_counts(2048, 8, 5) == [1280] * 8
 
 
 def test_shard_covers_all_streams():

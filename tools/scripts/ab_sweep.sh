@@ -1,4 +1,4 @@
-# usage: bash tools/scripts/r2_ab.sh <lib_a.so> <lib_b.so> [layer ...]   (on the GPU box through gpurun)
+# usage: bash tools/scripts/ab_sweep.sh <lib_a.so> <lib_b.so> [layer ...]   (on the GPU box through gpurun)
 # Same-box A/B of two builds of libevfly_hip.so on the Winograd layer shapes: tools/conv_sweep.py, 200 launches per layer
 # (short loops read the DVFS ramp, not the kernel: DESIGN.md §3), parity column included.
 cd $GRAFT_REPO_ROOT
