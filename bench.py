@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: event-frames/s of the event -> frame -> depth -> velocity hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]     (N > 1: launched by torch.distributed.run)
 
-One step = one pass of the whole path over one batch of synthetic event streams that are already
-resident in HBM: voxelize (B streams x T windows) -> q97 conditioning -> OrigUNet + ConvLSTM (depth)
--> LSTMNetVIT (velocity), batch-as-time inside every stream. Workload = BASELINE.json
-configs[1] ("C2"): B = 64 streams, T = 5 windows, 260x346, 60 000 events / window, fp32, the
-reference-size ("tiny") Mix-Transformer. With N GPUs every rank runs its own B streams (weak
-scaling, no data-path collective) and the ranks all_gather their velocity rows over RCCL.
+One step = one pass of the whole path over one batch of synthetic event streams that are already resident in HBM:
+voxelize (B streams x T windows) -> q97 conditioning (+ centre crop) -> OrigUNet + ConvLSTM (depth) -> LSTMNetVIT
+(velocity), batch-as-time inside every stream; the timed region ends with the velocity rows of all
+ranks in pinned HOST memory. With N GPUs every rank runs its own B streams (weak scaling, no data-path
+collective) and the ranks all_gather their velocity rows over RCCL.
 
-Prints ONE JSON line (contract in the task brief) with two extra objects:
-  roofline     -- the dominant kernel family (the 3x3 convolutions: Winograd F(2x2,3x3) on the fp32 matrix cores),
-                  timed with HIP events on the launch stream inside the timed region (evfly_model_set_profiling +
-                  evfly_model_set_profile_filter); `achieved` / `frac` count the flops the matrix cores EXECUTE
-                  (16/36 of the direct-convolution count plus tile padding), `algorithmic` the direct-conv flops
-                  (2*M*N*K) over the same time
-  cpu_baseline -- the CPU oracle (oracle/, a port) on a bounded sample of the same workload
+Workloads (BASELINE.json `configs`); the default, and the one `metric` is quoted on, is C2:
+  C2  64 streams x 5 windows x 60 000 events, 260x346, fp32, reference-size ("tiny") Mix-Transformer
+  C3  256 streams x 10 windows x 200 000 events at 480x640 -> centre crop 260x346, "ViT-base" trunk, bf16 pipeline
+  C4  one GPU's shard of the 8-GPU config: 256 streams x 5 windows, 260x346, "ViT-base", fp32 (run with --gpus N)
+  C5  OrigUNet + ConvLSTM only, 20 streams x 16 windows (seq_len 16, batch-as-time), bf16 pipeline; reports the serial
+      ConvLSTM critical path and the single-stream sequence latency beside the throughput
+
+Prints ONE JSON line (contract in the task brief) with these extra objects:
+  roofline       the dominant kernel family, timed with HIP events on the launch stream inside the timed region
+                 (evfly_model_set_profiling + _filter). `achieved` / `frac` = matrix-core flops ISSUED per second (for the
+                 fp32 Winograd kernel 16/36 of the direct-conv count plus tile padding); `frac_useful` = without the padding;
+                 `frac_algorithmic` = SURVEY.md §8d's 2*M*N*K over the same time (exceeds 1 for Winograd: it computes the
+                 convolution with 2.25x fewer multiplies); `hbm` = algorithmic bytes / time against the 8 TB/s peak
+  step_mfma_util matrix-core flops issued by EVERY kernel of a step / ms_per_step / peak
+  stage_rates    labelled V-only (voxelize + condition), D-only (U-Net + ConvLSTM), P-only (ViT + LSTM) frames/s
+  cpu_baseline   the CPU oracle (oracle/, a port) on a bounded sample of the same workload, at 1 thread and at nproc
 """
 import argparse
 import json
@@ -35,7 +43,15 @@ H, W = 260, 346
 # so its algorithmic-flop ceiling is a third of the bf16 peak.
 PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC = "r2_pmc_traffic.json"       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, summarised per kernel family
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, summarised per kernel family (first existing file wins)
+PMC_TRAFFIC = {"C2": ("r3_pmc_traffic.json", "r2_pmc_traffic.json"), "C5": ("r3_bf16_pmc_traffic.json",)}
+
+CONFIGS = {
+    "C2": dict(streams=64, windows=5, epw=60_000, sensor=(260, 346), vit="tiny", dtype="f32", model="composite"),
+    "C3": dict(streams=256, windows=10, epw=200_000, sensor=(480, 640), vit="base", dtype="bf16", model="composite"),
+    "C4": dict(streams=256, windows=5, epw=60_000, sensor=(260, 346), vit="base", dtype="f32", model="composite"),
+    "C5": dict(streams=20, windows=16, epw=60_000, sensor=(260, 346), vit="tiny", dtype="bf16", model="unet"),
+}
 
 
 def parse():
@@ -43,67 +59,93 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=64, help="streams per GPU (C2: 64)")
-    ap.add_argument("--windows", type=int, default=5, help="time windows per stream (C2: 5)")
-    ap.add_argument("--events-per-window", type=int, default=60_000)
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2", help="BASELINE.json workload (default C2, the headline)")
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (overrides the config)")
+    ap.add_argument("--windows", type=int, default=None, help="time windows per stream (overrides the config)")
+    ap.add_argument("--events-per-window", type=int, default=None)
+    ap.add_argument("--vit", choices=["tiny", "base"], default=None)
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x3 pass")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x3 pass (C2 only)")
+    ap.add_argument("--no-stage-rates", action="store_true", help="skip the V / D / P-only timings")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    for k, v in (("streams", a.streams), ("windows", a.windows), ("epw", a.events_per_window), ("vit", a.vit), ("dtype", a.dtype)):
+        if v is not None:
+            cfg[k] = v
+    a.cfg = cfg
+    return a
 
 
-def build_model(dtype):
+def build_model(cfg):
     from evfly_amd import synthetic as syn
     import evfly_amd.learner_models as lm
-    m = lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
-                                     input_shape=[1, 1, H, W], velpred=0, form_BEV=2, evs_min_cutoff=0.15,
-                                     skip_type="interp", logger=lambda *a: None)       # eval_config_real.txt
+    import evfly_amd.vitfly_models as vm
+    kw = dict(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, H, W], velpred=0, form_BEV=2,
+              evs_min_cutoff=0.15, skip_type="interp", logger=lambda *a: None)       # eval_config_real.txt
+    if cfg["model"] == "unet":
+        m = lm.OrigUNet(**kw)
+    else:
+        m = lm.OrigUNet_w_VITFLY_ViTLSTM(vit_trunk=vm.BASE if cfg["vit"] == "base" else None, **kw)
     sd = syn.fill_state_dict(m.state_dict())
     m.load_state_dict(sd)
-    m.set_compute_dtype(dtype)
+    m.set_compute_dtype(cfg["dtype"])
     return m.to("cuda").float().eval(), sd
 
 
-def cpu_baseline(sd, T, epw, budget_s):
-    """The oracle (CPU port of the reference path) on a bounded sample: streams of T windows through
-    C voxelizer port -> conditioning -> composite forward, all host cores torch may use."""
+def cpu_baseline(sd, cfg, budget_s):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same workload: streams of T windows through
+    the C voxelizer port -> (crop +) conditioning -> model forward, at ONE thread and at every core torch sees (§8d)."""
     from evfly_amd import synthetic as syn
+    import evfly_amd.vitfly_models as vm
     from oracle import accum as oaccum, conditioning as ocond, models as om, voxel as ovox
+    T, epw, (hs, ws) = cfg["windows"], cfg["epw"], cfg["sensor"]
+    if cfg["vit"] == "base":
+        om.use_trunk(heads=vm.BASE["heads"], layers=vm.BASE["layers"], reductions=vm.BASE["reductions"])
+
     def one_stream(s):
-        ev, edges = syn.make_stream(10_000 + s, T, H, W, epw)
+        ev, edges = syn.make_stream(10_000 + s, T, hs, ws, epw)
         tt = time.perf_counter()
-        c = oaccum.window_counts_c(ev["x"], ev["y"], ev["t"], ev["p"], edges, H, W, 0)
-        fr = ovox.signed_frame(c[:, 0], c[:, 1]).astype(np.float32)[:, None]
+        c = oaccum.window_counts_c(ev["x"], ev["y"], ev["t"], ev["p"], edges, hs, ws, 0)
+        fr = torch.from_numpy(ovox.signed_frame(c[:, 0], c[:, 1]).astype(np.float32)[:, None])
+        if (hs, ws) != (H, W):
+            fr = ocond.center_crop(fr)
         x, _ = ocond.q97_normalize(fr)
         with torch.no_grad():
-            om.composite_forward(sd, [x, torch.full((T, 1), 4.0), [None, None], None])
+            if cfg["model"] == "unet":
+                om.origunet_forward(sd, x, None)
+            else:
+                om.composite_forward(sd, [x, torch.full((T, 1), 4.0), [None, None], None])
         return time.perf_counter() - tt
 
-    # oneDNN on a many-core host is not fastest with every core on a 5-frame batch: try a few thread
-    # counts on one stream each (after a warm-up) and keep the best for the measured sample
     nproc = torch.get_num_threads()
-    one_stream(0)
-    best, threads = None, nproc
-    for th in sorted({nproc, min(nproc, 64), min(nproc, 32), min(nproc, 16)}, reverse=True):
-        torch.set_num_threads(th)
-        t = one_stream(1)
-        if best is None or t < best:
-            best, threads = t, th
-    torch.set_num_threads(threads)
-    frames_done, dt, s = 0, 0.0, 0
-    while dt < budget_s:
-        dt += one_stream(2 + s)           # synthetic-event generation is not charged
-        frames_done += T
-        s += 1
-    torch.set_num_threads(nproc)
-    return {"value": round(frames_done / dt, 3), "unit": "event-frames/s", "cores": threads, "kind": "port",
-            "sample": f"{s} stream(s) x {T} windows x {epw} events, 260x346, C voxelizer port + torch-CPU fp32 "
-                      f"oracle forward (batch-as-time), {dt:.1f} s"}
+    res = {}
+    try:
+        one_stream(0)                                          # warm-up (oneDNN primitive caches)
+        for label, th, share in (("threads_1", 1, 0.45), ("threads_nproc", nproc, 0.55)):
+            torch.set_num_threads(th)
+            frames_done, dt, s = 0, 0.0, 0
+            while dt < budget_s * share:
+                dt += one_stream(1 + s)                        # synthetic-event generation is not charged
+                frames_done += T
+                s += 1
+            res[label] = {"value": round(frames_done / dt, 3), "cores": th, "streams": s, "seconds": round(dt, 1)}
+    finally:
+        torch.set_num_threads(nproc)
+        om.use_trunk()
+    best = max(res.values(), key=lambda r: r["value"])
+    what = "U-Net + ConvLSTM" if cfg["model"] == "unet" else f"composite ({cfg['vit']} ViT)"
+    return {"value": best["value"], "unit": "event-frames/s", "cores": best["cores"], "kind": "port",
+            "threads_1": res["threads_1"], "threads_nproc": res["threads_nproc"],
+            "sample": f"streams of {T} windows x {epw} events at {hs}x{ws}: C voxelizer port + torch-CPU fp32 oracle forward of the {what}, "
+                      f"batch-as-time; {res['threads_1']['streams']} stream(s) at 1 thread ({res['threads_1']['seconds']} s), "
+                      f"{res['threads_nproc']['streams']} at {nproc} threads ({res['threads_nproc']['seconds']} s); `value` = the faster"}
 
 
 def main():
     a = parse()
+    cfg = a.cfg
     if a.gpus > 1 and "RANK" not in os.environ:
         # not under a launcher: start one rank per GPU as CHILD processes (nothing in this process has touched the
         # GPU yet) and leave with their exit code -- never silently measure one GPU when N were asked for
@@ -127,22 +169,31 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL over xGMI
 
     from evfly_amd import synthetic as syn, voxelizer
-    from evfly_amd.distributed import gather_velocities
-    B, T = a.streams, a.windows
-    model, sd = build_model(a.dtype)
-    batch = syn.make_batch(B, T, H, W, a.events_per_window, first_stream=rank * B)
+    from evfly_amd.distributed import gather_velocities, shard_row_counts
+    B, T, epw, (Hs, Ws), dtype = cfg["streams"], cfg["windows"], cfg["epw"], cfg["sensor"], cfg["dtype"]
+    composite = cfg["model"] == "composite"
+    model, sd = build_model(cfg)
+    batch = syn.make_batch(B, T, Hs, Ws, epw, first_stream=rank * B)
     ev = voxelizer.upload_events(batch)
     n_events = int(batch["offsets"][-1])
+    del batch
     desvel = torch.full((B * T, 1), 4.0, device="cuda")                            # run.py:255
-    frames = torch.empty(B, T, H, W, device="cuda")
+    frames = torch.empty(B, T, Hs, Ws, device="cuda")
+    counts = shard_row_counts(world * B, world, T)                                  # every rank: B streams (weak scaling)
+    vel_host = torch.empty(world * B * T, 3).pin_memory() if composite else None    # §8d: "velocity rows on host-visible memory"
     hip = model.hip()
     L = hip._L
 
     def step():
-        voxelizer.voxelize_windows(ev, H, W, out="f32", frames=frames)
-        x = voxelizer.condition_frames(frames.view(B * T, H, W))
+        voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames)
+        x = voxelizer.condition_frames(frames.view(B * T, Hs, Ws), out_hw=(H, W))    # centre crop when the sensor is larger
+        if not composite:                                                             # C5: depth maps stay in HBM
+            depth, _, _ = model.forward_streams(x, None, B, T)
+            return depth
         vel, _ = model.forward_streams([x, desvel, [None, None], None], B, T)
-        return gather_velocities(vel, dist)
+        vel_all = gather_velocities(vel, dist, counts=counts if dist is not None else None)
+        vel_host.copy_(vel_all, non_blocking=True)                                    # lands before the closing synchronize
+        return vel_all
 
     def sync():
         torch.cuda.synchronize()
@@ -152,7 +203,7 @@ def main():
 
     with torch.no_grad():
         for _ in range(a.warmup):
-            vel_all = step()
+            out_dev = step()
         # An untimed, fully bracketed step first: the per-kernel breakdown (`kernels`, `conv_layers`, `stages`) and the
         # name of the dominant family. Bracketing EVERY launch with HIP events costs ~1 ms per step (two
         # hipEventRecord serialise each of the ~150 launches), so the timed region brackets only that family.
@@ -172,7 +223,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            vel_all = step()
+            out_dev = step()
         sync()
         dt = time.perf_counter() - t0
         L.evfly_model_set_profiling(hip.h, 0)
@@ -181,7 +232,10 @@ def main():
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert vel_all.shape == (world * B * T, 3) and torch.isfinite(vel_all).all()
+    if composite:
+        assert out_dev.shape == (world * B * T, 3) and torch.isfinite(vel_host).all() and torch.equal(vel_host, out_dev.cpu())
+    else:
+        assert out_dev.shape == (B * T, 1, H, W) and torch.isfinite(out_dev).all()
 
     # stage timings outside the timed region (torch events see the current stream, which is the one
     # every evfly_amd launch uses)
@@ -194,92 +248,140 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     with torch.no_grad():
-        vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, H, W, out="f32", frames=frames))
-        cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, H, W)))
-    vox_bytes = 13.0 * n_events + 4.0 * B * T * H * W          # read events once, write frames once
+        vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames))
+        cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, Hs, Ws), out_hw=(H, W)))
+    vox_bytes = 13.0 * n_events + 4.0 * B * T * Hs * Ws        # read events once, write frames once
 
     def families(recs):
         fam = {}
         for p in recs:
-            f = fam.setdefault(p["name"].split("/")[0],
-                               dict(name=p["name"].split("/")[0], ms=0.0, flops=0.0, bytes=0.0, launches=0, exec_flops=0.0))
-            for k in ("ms", "flops", "bytes", "launches", "exec_flops"):
+            f = fam.setdefault(p["name"].split("/")[0], dict(name=p["name"].split("/")[0], ms=0.0, flops=0.0, bytes=0.0, launches=0,
+                                                              exec_flops=0.0, useful_flops=0.0))
+            for k in ("ms", "flops", "bytes", "launches", "exec_flops", "useful_flops"):
                 f[k] += p[k]
         return list(fam.values())
     timed = hip.profile()                          # dominant family only, bracketed inside the timed region
     dom = max(families(timed), key=lambda p: p["ms"])
     layers = layers_all                            # every launch site ("family/layer"), from the untimed step
     prof = families(layers)
-    n_untimed = 1
     frames_per_step = world * B * T
+    ms_per_step = 1e3 * dt / a.steps
+    trunk = "reference-size ViT" if cfg["vit"] == "tiny" else "ViT-base trunk (widths 128/256, heads 4/8, 4+4 layers)"
+    what = (f"OrigUNet+ConvLSTM -> LSTMNetVIT ({trunk})" if composite else "OrigUNet+ConvLSTM only (depth)")
+    crop = "" if (Hs, Ws) == (H, W) else f" voxelized at {Hs}x{Ws}, centre-cropped to 260x346,"
     out = {
         "metric": "event-frames/sec (260x346, 5 bins) event->depth->velocity fwd (voxelize + U-Net/ConvLSTM + ViT/LSTM)",
         "value": round(frames_per_step * a.steps / dt, 2), "unit": "event-frames/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"C2: {B} streams x {T} windows per GPU, 260x346, {a.events_per_window} events/window, "
-                               f"OrigUNet+ConvLSTM -> LSTMNetVIT (reference-size ViT), batch-as-time per stream",
-                   "streams_per_gpu": B, "windows": T, "events_per_step_per_gpu": n_events,
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"{a.config}: {B} streams x {T} windows per GPU,{crop} 260x346, {epw} events/window, {what}, "
+                               f"batch-as-time per stream; velocities end in pinned host memory" if composite else
+                               f"{a.config}: {B} streams x {T} windows per GPU (seq_len {T}), 260x346, {epw} events/window, {what}, "
+                               f"batch-as-time per stream; depth maps stay in HBM",
+                   "streams_per_gpu": B, "windows": T, "events_per_step_per_gpu": n_events, "sensor": [Hs, Ws], "vit_trunk": cfg["vit"] if composite else None,
                    "parallelism": f"streams sharded x{world}, all_gather of velocities" if world > 1 else "single GPU"},
     }
     if rank == 0:
-        tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["flops"] else 0.0
-        # HBM bytes per launch of the MFMA GEMM kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE, separate runs of this script at the C2 shape; FETCH doubled per the gfx950 calibration in
-        # profiles/README.md). PMC counters cannot be read inside this process, so the figure is null for other shapes.
+        peak = PEAK[dtype]
+        sec = dom["ms"] * 1e-3
+        # HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE, separate runs of this script at this config's default shape; FETCH doubled per the gfx950
+        # calibration in profiles/README.md). PMC counters cannot be read inside this process, so the figure is null for other shapes.
         traffic, tnote = None, "no PMC summary for this shape/dtype"
-        pmc = os.path.join(REPO, "profiles", PMC_TRAFFIC)
-        if os.path.exists(pmc) and a.dtype == "f32" and (B, T, a.events_per_window) == (64, 5, 60_000):
-            g = json.load(open(pmc))["kernels"]["wino_conv3x3"]
-            traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
-            tnote = ("HBM bytes per launch, mean over the %d conv3x3 (k_wino9) launches of a step: (2 x FETCH_SIZE + "
-                     "WRITE_SIZE) from profiles/%s; algorithmic = algorithmic.bytes_per_launch"
-                     % (g["launches_per_step"], PMC_TRAFFIC))
+        pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in PMC_TRAFFIC.get(a.config, ())) if os.path.exists(q)), None)
+        if pmc and cfg == CONFIGS[a.config]:
+            ks = json.load(open(pmc))["kernels"]
+            g = ks.get("wino_conv3x3") if dtype == "f32" else ks.get("igemm16_conv")
+            if g:
+                traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
+                tnote = ("HBM bytes per launch, mean over the %d conv3x3 launches of a step: (2 x FETCH_SIZE + WRITE_SIZE) from "
+                         "profiles/%s; algorithmic = algorithmic.bytes_per_launch" % (g["launches_per_step"], os.path.basename(pmc)))
         if dom["flops"]:
-            # `achieved` = the flops the matrix cores EXECUTE per second in this kernel family. For the Winograd
-            # F(2x2,3x3) kernel that is 16/36 of the direct-convolution count plus tile padding (exec_flops, from the
-            # launch plans); the algorithmic (direct-conv, SURVEY.md §8d: 2*M*N*K) rate is kept beside it as
-            # `algorithmic` -- it can exceed the MFMA peak and says nothing about headroom, `frac` does.
+            # `achieved` = the flops the matrix cores EXECUTE per second in this kernel family (exec_flops, from the launch plans);
+            # the algorithmic (direct-conv, SURVEY.md §8d: 2*M*N*K) rate is kept beside it as frac_algorithmic / `algorithmic`.
             ex_flops = dom["exec_flops"] if dom["exec_flops"] else dom["flops"]
-            ex = ex_flops / (dom["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ex, 2), "peak": PEAK[a.dtype],
-                               "unit": "TFLOP/s", "frac": round(ex / PEAK[a.dtype], 4), "traffic": traffic, "traffic_note": tnote,
+            us_flops = dom["useful_flops"] if dom["useful_flops"] else dom["flops"]
+            ex, us, tfl = ex_flops / sec / 1e12, us_flops / sec / 1e12, dom["flops"] / sec / 1e12
+            gbs = dom["bytes"] / sec / 1e9
+            wino = abs(dom["exec_flops"] - dom["flops"]) > 1e-6 * dom["flops"]
+            out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ex, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ex / peak, 4), "frac_useful": round(us / peak, 4), "frac_algorithmic": round(tfl / peak, 4),
+                               "traffic": traffic, "traffic_note": tnote,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                                "flops_per_launch": ex_flops / dom["launches"],
-                               "algorithmic": {"tflops": round(tfl, 2), "frac_of_peak": round(tfl / PEAK[a.dtype], 4),
+                               "hbm": {"achieved_GBs_algorithmic": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                               "algorithmic": {"tflops": round(tfl, 2), "frac_of_peak": round(tfl / peak, 4),
                                                "flops_per_launch": dom["flops"] / dom["launches"],
                                                "bytes_per_launch": dom["bytes"] / dom["launches"]},
-                               "note": ("achieved / frac = MFMA flops issued (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 issues "
-                                        "2.25x fewer multiplies than the direct 3x3 convolution it computes); algorithmic = direct-conv "
-                                        "flops over the same time") if dom["exec_flops"] and abs(dom["exec_flops"] - dom["flops"]) > 1e-6 * dom["flops"]
-                                       else "achieved = 2*M*N*K of the launches / their HIP-event time"}
+                               "note": ("achieved / frac = MFMA flops issued: Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 issues 16/36 of the "
+                                        "direct 3x3 convolution's multiplies, plus the padding of ragged tile rows / columns; frac_useful = "
+                                        "without that padding; frac_algorithmic = direct-conv flops (SURVEY.md §8d) over the same time, "
+                                        "above 1 because the convolution is computed with 2.25x fewer multiplies") if wino
+                                       else "achieved = 2*M*N*K of the launches / their HIP-event time (direct implicit GEMM: issued = useful = algorithmic)"}
         else:
-            gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            gbs = dom["bytes"] / sec / 1e9
             out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4)}
         model_ms = sum(p["ms"] for p in prof)
+        # matrix-core utilisation of the WHOLE step: every MFMA kernel's issued flops (one bracketed step) over the timed ms/step
+        step_exec = sum((p["exec_flops"] or p["flops"]) for p in prof if p["flops"] and not p["name"].startswith(("vit_attention", "vit_grouped", "lstm_rec", "e11_direct", "unet_out")))
+        out["step_mfma_util"] = round(step_exec / (ms_per_step * 1e-3) / 1e12 / peak, 4)      # (this rank's kernels over the step time)
         out["breakdown_note"] = ("kernels / conv_layers / stages.model_ms: one untimed step with every launch bracketed by HIP "
                                  "events; roofline: the dominant family bracketed inside the timed region")
-        out["kernels"] = [{"name": p["name"], "ms_per_step": round(p["ms"] / n_untimed, 3), "launches_per_step": p["launches"] // n_untimed,
+        out["kernels"] = [{"name": p["name"], "ms_per_step": round(p["ms"], 3), "launches_per_step": p["launches"],
                            "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2) if p["flops"] and p["ms"] else None,
                            "gbs_algorithmic": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] else None}
                           for p in sorted(prof, key=lambda p: -p["ms"])]
-        out["model_ms_per_step"] = round(model_ms / n_untimed, 3)
-        out["conv_layers"] = [{"name": p["name"], "ms_per_step": round(p["ms"] / n_untimed, 3),
+        out["model_ms_per_step"] = round(model_ms, 3)
+        out["conv_layers"] = [{"name": p["name"], "ms_per_step": round(p["ms"], 3),
                                "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)}
                               for p in layers if p["name"].startswith(dom["name"] + "/")]
         out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_GBs_algorithmic": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
                          "voxelize_frac_of_hbm_peak": round(vox_bytes / (vox_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms / n_untimed, 3)}
-        mf = sum(p["flops"] for p in prof if p["flops"]) / n_untimed
+                         "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms, 3)}
+        if not a.no_stage_rates:
+            # labelled per-stage rates ("publish both P-only and V+D+P"): each stage alone on the same batch,
+            # inputs resident, torch events on the launch stream. V = voxelize + condition, D = OrigUNet + ConvLSTM,
+            # P = ViT + LSTM on 260x346 depth images (resize to 60x90 inside, like the composite's hand-off).
+            fper = B * T
+            rates = {"v_only": {"frames_per_s": round(fper / ((vox_ms + cond_ms) * 1e-3), 1), "ms": round(vox_ms + cond_ms, 4), "what": "voxelize + crop/q97 conditioning"}}
+            with torch.no_grad():
+                x = voxelizer.condition_frames(frames.view(B * T, Hs, Ws), out_hw=(H, W))
+                unet = model.origunet if composite else model
+                unet.set_compute_dtype(dtype)
+                d_ms = time_stage(lambda: unet.forward_streams(x, None, B, T), reps=3)
+                rates["d_only"] = {"frames_per_s": round(fper / (d_ms * 1e-3), 1), "ms": round(d_ms, 3), "what": "OrigUNet + ConvLSTM (depth) on conditioned frames"}
+                if composite:
+                    depth, _, _ = unet.forward_streams(x, None, B, T)
+                    vit = model.vitfly_vitlstm
+                    vit.set_compute_dtype(dtype)
+                    p_ms = time_stage(lambda: vit.forward_streams([depth, desvel, None], B, T), reps=3)
+                    rates["p_only"] = {"frames_per_s": round(fper / (p_ms * 1e-3), 1), "ms": round(p_ms, 3),
+                                       "what": f"LSTMNetVIT ({cfg['vit']} trunk) on 260x346 depth images (the metric string's 'ViT fwd')"}
+                    del depth
+            rates["v_d_p"] = {"frames_per_s": out["value"] / world, "ms": round(ms_per_step, 3), "what": "the headline: whole path per GPU"}
+            out["stage_rates"] = rates
+        if not composite:
+            # C5: the serial part of the ConvLSTM -- T dependent (hidden-side GEMM + gate kernel) pairs per chunk --
+            # and the latency of ONE stream's 16-frame sequence
+            serial = sum(p["ms"] for p in prof if p["name"] in ("convlstm_h_gemm", "convlstm_gates"))
+            xg = sum(p["ms"] for p in prof if p["name"] == "convlstm_x_gemm")
+            with torch.no_grad():
+                x1 = voxelizer.condition_frames(frames.view(B * T, Hs, Ws)[:T], out_hw=(H, W))
+                one_ms = time_stage(lambda: model.forward_streams(x1, None, 1, T), reps=5)
+            out["convlstm"] = {"serial_critical_path_ms_per_step": round(serial, 3), "steps_in_series": T,
+                               "batched_input_gemm_ms_per_step": round(xg, 3),
+                               "single_stream_sequence_ms": round(one_ms, 3), "single_stream_frames_per_s": round(T / (one_ms * 1e-3), 1),
+                               "note": f"serial = the {T} dependent (h-GEMM, gates) launch pairs of one {B}-stream chunk; single_stream = one stream's "
+                                       f"{T}-frame sequence through the U-Net alone (latency-bound: {T} frames do not fill the chip)"}
+        mf = sum(p["flops"] for p in prof if p["flops"])
         out["mfma_flops_per_frame"] = mf / (B * T)
-        if world == 1 and a.dtype == "f32" and not a.no_alt:
-            # Informational second precision mode, NOT the headline `value`: fp32 operands split into two bf16
-            # (x = hi + lo), 3 bf16 MFMAs per product, fp32 accumulate. Same inputs, same weights; the velocity
-            # deviation from the exact-fp32 run above is reported with it.
-            vel_f32 = vel_all.clone()
-            model.set_compute_dtype("bf16x3")
+        if world == 1 and a.config == "C2" and dtype == "f32" and not a.no_alt:
+            # Informational second precision mode, NOT the headline `value`: the bf16 pipeline (bf16 activations in HBM, bf16
+            # MFMA, fp32 accumulate). Same inputs, same weights; the velocity deviation from the exact-fp32 run is reported with it.
+            vel_f32 = out_dev.clone()
+            model.set_compute_dtype("bf16")
             with torch.no_grad():
                 for _ in range(max(1, a.warmup)):
                     v3 = step()
@@ -289,12 +391,13 @@ def main():
                     v3 = step()
                 torch.cuda.synchronize()
                 dt3 = time.perf_counter() - t1
-            out["alt_precision"] = {"dtype": "bf16x3", "value": round(B * T * a.steps / dt3, 2), "unit": "event-frames/s",
+            out["alt_precision"] = {"dtype": "bf16", "value": round(B * T * a.steps / dt3, 2), "unit": "event-frames/s",
                                     "ms_per_step": round(1e3 * dt3 / a.steps, 3),
                                     "max_rel_dev_velocity_vs_f32": float(((v3 - vel_f32).abs().max() / vel_f32.abs().max()).item()),
-                                    "note": "fp32-grade split precision (error ~2^-16 per product); informational"}
+                                    "note": "bf16 pipeline (BASELINE configs C3 / C5 run in it); informational, not the headline"}
+            model.set_compute_dtype("f32")
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sd, T, a.events_per_window, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, a.cpu_seconds)
     # The ONE JSON line goes last: RCCL writes a banner (host name, library path) into the C stdio buffer, which a pipe only
     # flushes at exit -- behind everything Python printed, on every rank. Flush C stdio on all ranks, meet, then print.
     import ctypes

@@ -55,8 +55,10 @@ class HipHandle:
             L.evfly_model_profile_get(self.h, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by), C.byref(ln))
             ex = C.c_double()
             L.evfly_model_profile_exec_flops(self.h, i, C.byref(ex))
+            us = C.c_double()
+            L.evfly_model_profile_useful_flops(self.h, i, C.byref(us))
             out.append(dict(name=name.value.decode(), ms=ms.value, flops=fl.value, bytes=by.value,
-                            launches=ln.value, exec_flops=ex.value))
+                            launches=ln.value, exec_flops=ex.value, useful_flops=us.value))
         return out
 
 

@@ -71,9 +71,12 @@ SIGNATURES = {
     "evfly_model_profile_get": (c_i, [c_p, c_i, C.c_char_p, c_i, C.POINTER(c_d), C.POINTER(c_d),
                                       C.POINTER(c_d), C.POINTER(c_i)]),
     "evfly_model_profile_exec_flops": (c_i, [c_p, c_i, C.POINTER(c_d)]),
+    "evfly_model_profile_useful_flops": (c_i, [c_p, c_i, C.POINTER(c_d)]),
     "evfly_model_profile_reset": (c_i, [c_p]),
     "evfly_op_conv2d_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
                                    c_p, c_p, c_i, c_p]),
+    "evfly_op_conv2d_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
+                                        c_p, c_p, c_p]),
 }
 
 

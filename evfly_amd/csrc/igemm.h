@@ -42,6 +42,12 @@ struct ConvDesc {
     int out_mode = OUT_ROWS;
     int up_cout = 0;            // OUT_UPCONV2X2: n = (dy*2+dx)*up_cout + co, bias indexed by co
     int dtype = EVFLY_DTYPE_F32;
+    // bf16 pipeline (dtype == EVFLY_DTYPE_BF16 with in_bf16): x, w point at bf16 elements (strides ldx / ldw stay in
+    // ELEMENTS; w is [Nc][ldw] bf16 rounded at pack time, ldw a multiple of 64) and go HBM/L2 -> LDS -> MFMA operands
+    // without touching a VALU. out_bf16: y is bf16 (one RNE rounding in the epilogue); res_bf16: the addend is bf16.
+    // in_bf16 == 0 with dtype BF16 is the staging-conversion kernel (fp32 x, fp32 w) kept for the few fp32 inputs
+    // of the pipeline (frames / depth images, K not a multiple of 32); it honours out_bf16 too.
+    int in_bf16 = 0, out_bf16 = 0, res_bf16 = 0;
     const float *zeros = nullptr;   // >= 16 B of zeros in global memory (set by igemm_launch)
     // optional second output of the Winograd 3x3 kernel: 2x2/stride-2 max pool (floor) of the activated output,
     // NHWC [NI][OH/2][OW/2][Nc] contiguous (nn.MaxPool2d(2, 2) fused into the producer)
@@ -84,6 +90,9 @@ inline int conv_k_index(int tap, int c, int C, int ntaps) {
 
 // Enqueue the GEMM on `st`. Returns 0 / negative (evfly_last_error).
 int igemm_launch(const ConvDesc &d, hipStream_t st);
+
+// bf16 pipeline kernel (igemm16.hip): d.in_bf16 set, bf16 x / w, C % 32 == 0, ldw % 64 == 0. igemm_launch routes to it.
+int igemm16_launch(const ConvDesc &d, hipStream_t st);
 
 // >= 256 B of zeros in global memory on the current device (source of masked LDS-DMA rows)
 int igemm_zero_page(const float **out);

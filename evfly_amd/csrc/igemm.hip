@@ -16,6 +16,8 @@
 
 #include <atomic>
 
+#include "bf16.h"
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -668,6 +670,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
             // running pointer (one 64-bit multiply per tile instead of one per row)
             const int64_t m_base = m0 + wm * WM + i * 32 + 4 * fh;
             float *yr = d.y + m_base * d.ldy + ncol0;
+            bf16_t *yr16 = reinterpret_cast<bf16_t *>(d.y) + m_base * d.ldy + ncol0;      // out_bf16 (bf16 pipeline, fp32-input layers)
             const float *rr = plain_res ? d.res + m_base * d.ldres + ncol0 : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -684,11 +687,13 @@ __global__ __launch_bounds__(256) void k_igemm(ConvDesc d, int n_mt, int n_nt, i
                         float v = acc[i][j][r] + bj[j];
                         if (rrow) v += rrow[j * 32];
                         v = apply_act(v, act);
-                        yr[j * 32] = v;
+                        if (d.out_bf16) yr16[j * 32] = f2bf_dev(v);
+                        else yr[j * 32] = v;
                     }
                 }
                 const int64_t adv = (r & 3) == 3 ? 5 : 1;    // next row of this lane
                 yr += adv * d.ldy;
+                yr16 += adv * d.ldy;
                 if (rr) rr += adv * d.ldres;
             }
         }
@@ -709,7 +714,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvDesc d, int splits, c
             if (d.res_rpi > 0) { const int g = (int)m / d.res_rpi; rrow = (int64_t)g * d.res_img_rows + ((int)m - g * d.res_rpi); }
             v += d.res[rrow * d.ldres + n];
         }
-        d.y[m * d.ldy + n] = apply_act(v, d.act);
+        v = apply_act(v, d.act);
+        if (d.out_bf16) reinterpret_cast<bf16_t *>(d.y)[m * d.ldy + n] = f2bf_dev(v);
+        else d.y[m * d.ldy + n] = v;
     }
 }
 
@@ -790,7 +797,10 @@ int igemm_zero_page(const float **out) {
 }
 
 int igemm_launch(const ConvDesc &d_in, hipStream_t st) {
+    if (d_in.in_bf16) return igemm16_launch(d_in, st);
     ConvDesc d = d_in;
+    EVFLY_REQUIRE(!d.res_bf16 && (!d.out_bf16 || (d.dtype == EVFLY_DTYPE_BF16 && d.out_mode == OUT_ROWS)),
+                  "igemm: bf16 output / addend need the bf16 pipeline (dtype BF16; fp32-input layers: row outputs, fp32 addend)");
     if (int rc = igemm_zero_page(&d.zeros)) return rc;
     EVFLY_REQUIRE(d.x && d.w && d.y && d.M > 0 && d.Nc > 0 && d.K > 0, "igemm: empty problem");
     EVFLY_REQUIRE(d.ldw % BK == 0 && d.ldw >= d.K, "igemm: weights must be zero padded to a multiple of 32 (ldw=%d K=%d)",

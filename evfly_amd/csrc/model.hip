@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "bf16.h"
 #include "common.h"
 #include "igemm.h"
 #include "ops.h"
@@ -29,16 +30,19 @@ struct HostTensor {
 struct Tap {
     float *ptr;
     int64_t shape[4];
+    bool bf16;      // the buffer holds bf16 elements (bf16 pipeline)
 };
 
 struct ProfRec {
     std::string name;
-    double flops, bytes, exec;
+    double flops, bytes, exec, useful;
     hipEvent_t e0, e1;
 };
 struct ProfAgg {
     std::string name;
-    double ms = 0, flops = 0, bytes = 0, exec = 0;   // exec: matrix-core flops actually issued (Winograd: < flops)
+    // exec: matrix-core flops actually issued (Winograd: 16/36 of flops plus tile padding); useful: the part of exec that
+    // lands on real output tiles (Winograd: 16/36 of the direct-conv count, no padding; equal to flops for direct GEMMs)
+    double ms = 0, flops = 0, bytes = 0, exec = 0, useful = 0;
     int launches = 0;
 };
 
@@ -70,6 +74,10 @@ struct evfly_model {
     int vp_hidden = 0;   // lstm_velpred hidden size = flattened conv features (set at finalize)
     // full-resolution encoder maps: kept complete when EVFLY_FULL_ENCODER_OUTPUTS is set at evfly_model_create time (debug
     // taps "e1".."e4"); otherwise the fused-skip Winograd launches store only the block-border pixels (`skip_bands`)
+    // bf16 pipeline (compute_dtype BF16): activations are bf16 NHWC in the arena, GEMM weights bf16 (rounded at pack time).
+    // EVFLY_BF16_LEGACY at create time keeps the round-1 path (fp32 activations rounded while they are staged) for A/B runs.
+    bool act16 = false;
+    size_t esz() const { return act16 ? 2 : 4; }           // bytes per activation element
     bool full_encoder_outputs = false;
     bool bands_used = false;   // the last forward left "e1".."e4" partial
 
@@ -94,6 +102,8 @@ struct evfly_model {
         woff[name] = off;
         return wstage.data() + off;
     }
+    // bf16 weights share the staging vector (two elements per float slot, 256-B aligned like the others)
+    bf16_t *stage16(const std::string &name, size_t n) { return reinterpret_cast<bf16_t *>(stage(name, (n + 1) / 2)); }
     const float *W(const std::string &name) const {
         auto it = woff.find(name);
         return it == woff.end() ? nullptr : wdev + it->second;
@@ -108,8 +118,13 @@ struct evfly_model {
         if (planning) { plan_peak = std::max(plan_peak, arena_off); return reinterpret_cast<float *>(16); }
         return reinterpret_cast<float *>(arena + off);
     }
-    void tap(const char *name, float *p, int64_t a, int64_t b, int64_t c, int64_t d) {
-        if (!planning) taps[name] = Tap{p, {a, b, c, d}};
+    // activation buffers: n ELEMENTS of the pipeline's activation type (fp32, or bf16 in the bf16 pipeline)
+    float *alloc_act(int64_t n_elems) { return act16 ? alloc((n_elems + 1) / 2) : alloc(n_elems); }
+    // p + n elements of the activation type
+    float *eoff(float *p, int64_t n_elems) const { return reinterpret_cast<float *>(reinterpret_cast<char *>(p) + n_elems * (int64_t)esz()); }
+    const float *eoff(const float *p, int64_t n_elems) const { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + n_elems * (int64_t)esz()); }
+    void tap(const char *name, float *p, int64_t a, int64_t b, int64_t c, int64_t d, bool is16 = false) {
+        if (!planning) taps[name] = Tap{p, {a, b, c, d}, is16};
     }
 
     // ------------------------------------------------------------------ profiling
@@ -117,10 +132,11 @@ struct evfly_model {
     bool prof_skipped = false;
     // fused first-conv producer for the next conv() call (consumed and cleared there; Winograd path only)
     struct { const float *frames = nullptr, *w = nullptr, *b = nullptr; int cin = 0, form_bev = 0, apply_form = 0; float cutoff = 0.f; } pre;
-    double next_exec = 0;   // set by conv() before RUN when the kernel issues fewer flops than the algorithmic count
+    double next_exec = 0, next_useful = 0;   // set by conv() before RUN when the kernel issues fewer flops than the algorithmic count
     int prof_begin(const char *name, double flops, double bytes) {
         const double ex = next_exec > 0 ? next_exec : flops;
-        next_exec = 0;
+        const double us = next_useful > 0 ? next_useful : flops;
+        next_exec = 0; next_useful = 0;
         prof_skipped = false;
         if (!profiling || planning) return 0;
         if (!prof_filter.empty() && std::strncmp(name, prof_filter.c_str(), prof_filter.size()) != 0) { prof_skipped = true; return 0; }
@@ -129,7 +145,7 @@ struct evfly_model {
             EVFLY_HIP(hipEventCreate(&e));
             ev_pool.push_back(e);
         }
-        ProfRec r{name, flops, bytes, ex, ev_pool[ev_used], ev_pool[ev_used + 1]};
+        ProfRec r{name, flops, bytes, ex, us, ev_pool[ev_used], ev_pool[ev_used + 1]};
         ev_used += 2;
         EVFLY_HIP(hipEventRecord(r.e0, st));
         prof.push_back(r);
@@ -149,7 +165,7 @@ struct evfly_model {
             ProfAgg *a = nullptr;
             for (auto &x : agg) if (x.name == r.name) a = &x;
             if (!a) { agg.push_back(ProfAgg{r.name}); a = &agg.back(); }
-            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->exec += r.exec; a->launches += 1;
+            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->exec += r.exec; a->useful += r.useful; a->launches += 1;
         }
         prof.clear();
         ev_used = 0;
@@ -172,19 +188,30 @@ namespace {
 // Conv2d weight (O, I, kh, kw) -> [O][kh][kw][I], k padded with zeros to a multiple of 32
 // pad_cin: lay the weights out for an input whose channel count is padded to a multiple of 32 with zero channels (the
 // vectorised / DMA K walk of the GEMM kernel needs C % 32 == 0; the generic gather is an order of magnitude slower)
-int pack_conv(evfly_model *m, const char *prefix, const std::string &key, const std::string &name, bool need = true, bool pad_cin = false) {
+int pack_conv(evfly_model *m, const char *prefix, const std::string &key, const std::string &name, bool need = true, bool pad_cin = false,
+              bool w16 = false) {
     const HostTensor *t = m->find(key + ".weight", prefix);
     if (!t) { if (need) return fail(-4, "missing tensor %s%s.weight", prefix, key.c_str()); return 1; }
     EVFLY_REQUIRE(t->shape.size() == 4, "%s.weight: expected 4 dims", key.c_str());
     const int O = (int)t->shape[0], I = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
     const int Ip = pad_cin ? round_up(I, 32) : I;
-    const int K = kh * kw * Ip, ld = round_up(K, 32);
-    float *dst = m->stage(name + ".w", (size_t)O * ld);        // (staged zero-filled)
-    for (int o = 0; o < O; ++o)
-        for (int i = 0; i < I; ++i)
-            for (int y = 0; y < kh; ++y)
-                for (int x = 0; x < kw; ++x)
-                    dst[(size_t)o * ld + conv_k_index(y * kw + x, i, Ip, kh * kw)] = t->v[(((size_t)o * I + i) * kh + y) * kw + x];
+    w16 = w16 && Ip % 32 == 0;                                  // bf16 weights go with the bf16 GEMM kernel (bf16 input, C % 32 == 0)
+    const int K = kh * kw * Ip, ld = round_up(K, w16 ? 64 : 32);
+    if (w16) {
+        bf16_t *dst = m->stage16(name + ".w", (size_t)O * ld);     // (staged zero-filled)
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int y = 0; y < kh; ++y)
+                    for (int x = 0; x < kw; ++x)
+                        dst[(size_t)o * ld + conv_k_index(y * kw + x, i, Ip, kh * kw)] = host_f2bf(t->v[(((size_t)o * I + i) * kh + y) * kw + x]);
+    } else {
+        float *dst = m->stage(name + ".w", (size_t)O * ld);        // (staged zero-filled)
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int y = 0; y < kh; ++y)
+                    for (int x = 0; x < kw; ++x)
+                        dst[(size_t)o * ld + conv_k_index(y * kw + x, i, Ip, kh * kw)] = t->v[(((size_t)o * I + i) * kh + y) * kw + x];
+    }
     m->wld[name] = ld;
     const HostTensor *b = m->find(key + ".bias", prefix);
     if (b) std::memcpy(m->stage(name + ".b", b->v.size()), b->v.data(), b->v.size() * 4);
@@ -193,7 +220,7 @@ int pack_conv(evfly_model *m, const char *prefix, const std::string &key, const 
 
 // Linear weight (O, I) (optionally spectral-normalised, optionally with permuted input columns)
 int pack_linear(evfly_model *m, const char *prefix, const std::string &key, const std::string &name, bool need = true,
-                const std::vector<int> *col_perm = nullptr) {
+                const std::vector<int> *col_perm = nullptr, bool w16 = false) {
     const HostTensor *t = m->find(key + ".weight", prefix);
     std::vector<float> folded;
     if (!t) {   // old-style torch.nn.utils.spectral_norm: W = weight_orig / (u . (W v)), no power iteration in eval
@@ -212,10 +239,16 @@ int pack_linear(evfly_model *m, const char *prefix, const std::string &key, cons
         t = wo;
     }
     const std::vector<float> &src = folded.empty() ? t->v : folded;
-    const int O = (int)t->shape[0], I = (int)t->shape[1], ld = round_up(I, 32);
-    float *dst = m->stage(name + ".w", (size_t)O * ld);
-    for (int o = 0; o < O; ++o)
-        for (int i = 0; i < I; ++i) dst[(size_t)o * ld + (col_perm ? (*col_perm)[i] : i)] = src[(size_t)o * I + i];
+    const int O = (int)t->shape[0], I = (int)t->shape[1], ld = round_up(I, w16 ? 64 : 32);
+    if (w16) {
+        bf16_t *dst = m->stage16(name + ".w", (size_t)O * ld);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i) dst[(size_t)o * ld + (col_perm ? (*col_perm)[i] : i)] = host_f2bf(src[(size_t)o * I + i]);
+    } else {
+        float *dst = m->stage(name + ".w", (size_t)O * ld);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i) dst[(size_t)o * ld + (col_perm ? (*col_perm)[i] : i)] = src[(size_t)o * I + i];
+    }
     m->wld[name] = ld;
     const HostTensor *b = m->find(key + ".bias", prefix);
     if (b) std::memcpy(m->stage(name + ".b", b->v.size()), b->v.data(), b->v.size() * 4);
@@ -248,8 +281,9 @@ int pack_unet(evfly_model *m) {
     }
     const char *convs[] = {"e12", "e21", "e22", "e31", "e32", "e41", "e42", "e51", "e52",
                            "d11", "d12", "d21", "d22", "d31", "d32", "d41", "d42"};
+    const bool w16 = m->act16;
     for (const char *n : convs) {
-        if (int rc = pack_conv(m, kUnetP, std::string("unet_") + n, n)) return rc;
+        if (int rc = pack_conv(m, kUnetP, std::string("unet_") + n, n, true, false, w16)) return rc;
         // Winograd F(2x2,3x3) weights U = G g G^T in the streamed layout of wino.hip (exact-fp32 path only)
         const HostTensor *t = m->find(std::string("unet_") + n + ".weight", kUnetP);
         if (c.compute_dtype == EVFLY_DTYPE_F32 && t && t->shape[1] % 32 == 0) {
@@ -261,11 +295,18 @@ int pack_unet(evfly_model *m) {
         const std::string key = "unet_upconv" + std::to_string(l);
         const HostTensor *t = m->find(key + ".weight", kUnetP);
         if (!t) return fail(-4, "missing tensor %s.weight", key.c_str());
-        const int I = (int)t->shape[0], O = (int)t->shape[1], ld = round_up(I, 32);
-        float *dst = m->stage("up" + std::to_string(l) + ".w", (size_t)4 * O * ld);
-        for (int i = 0; i < I; ++i)
-            for (int o = 0; o < O; ++o)
-                for (int q = 0; q < 4; ++q) dst[((size_t)q * O + o) * ld + i] = t->v[((size_t)i * O + o) * 4 + q];
+        const int I = (int)t->shape[0], O = (int)t->shape[1], ld = round_up(I, w16 ? 64 : 32);
+        if (w16) {
+            bf16_t *dst = m->stage16("up" + std::to_string(l) + ".w", (size_t)4 * O * ld);
+            for (int i = 0; i < I; ++i)
+                for (int o = 0; o < O; ++o)
+                    for (int q = 0; q < 4; ++q) dst[((size_t)q * O + o) * ld + i] = host_f2bf(t->v[((size_t)i * O + o) * 4 + q]);
+        } else {
+            float *dst = m->stage("up" + std::to_string(l) + ".w", (size_t)4 * O * ld);
+            for (int i = 0; i < I; ++i)
+                for (int o = 0; o < O; ++o)
+                    for (int q = 0; q < 4; ++q) dst[((size_t)q * O + o) * ld + i] = t->v[((size_t)i * O + o) * 4 + q];
+        }
         m->wld["up" + std::to_string(l)] = ld;
         if (int rc = pack_vec(m, kUnetP, key + ".bias", "up" + std::to_string(l) + ".b")) return rc;
     }
@@ -278,6 +319,17 @@ int pack_unet(evfly_model *m) {
         if (!t) return fail(-4, "missing tensor lstm.cell_list.0.conv.weight");
         const int O = (int)t->shape[0], I = (int)t->shape[1], hid = O / 4;
         EVFLY_REQUIRE(I == 2 * hid && hid == 512, "ConvLSTM weight: expected (2048,1024,1,1)");
+        if (w16) {
+            m->stage16("clstm.wx", (size_t)O * hid);
+            m->stage16("clstm.wh", (size_t)O * hid);   // staging may reallocate: take the pointers afterwards
+            bf16_t *wx = reinterpret_cast<bf16_t *>(m->wstage.data() + m->woff["clstm.wx"]);
+            bf16_t *wh = reinterpret_cast<bf16_t *>(m->wstage.data() + m->woff["clstm.wh"]);
+            for (int o = 0; o < O; ++o)
+                for (int i = 0; i < hid; ++i) {
+                    wx[(size_t)o * hid + i] = host_f2bf(t->v[(size_t)o * I + i]);
+                    wh[(size_t)o * hid + i] = host_f2bf(t->v[(size_t)o * I + hid + i]);
+                }
+        } else {
         m->stage("clstm.wx", (size_t)O * hid);
         m->stage("clstm.wh", (size_t)O * hid);   // staging may reallocate: take the pointers afterwards
         float *wx = m->wstage.data() + m->woff["clstm.wx"], *wh = m->wstage.data() + m->woff["clstm.wh"];
@@ -286,6 +338,7 @@ int pack_unet(evfly_model *m) {
                 wx[(size_t)o * hid + i] = t->v[(size_t)o * I + i];
                 wh[(size_t)o * hid + i] = t->v[(size_t)o * I + hid + i];
             }
+        }
     }
     return 0;
 }
@@ -402,45 +455,52 @@ int pack_velpred(evfly_model *m) {
 
 int pack_vit(evfly_model *m) {
     const auto &c = m->cfg;
+    const bool w16 = m->act16;      // bf16 pipeline: every GEMM whose input is a bf16 activation (C % 32 == 0) gets bf16 weights
     for (int s = 0; s < 2; ++s) {
         if (c.vit_layers[s] == 0 && s == 1) continue;   // single-stage handle
         const std::string P = "encoder_blocks." + std::to_string(s) + ".", N = "s" + std::to_string(s) + ".";
-        if (int rc = pack_conv(m, kVitP, P + "patchMerge.cn1", N + "pm")) return rc;
+        if (int rc = pack_conv(m, kVitP, P + "patchMerge.cn1", N + "pm", true, false, w16)) return rc;
         if (int rc = pack_vec(m, kVitP, P + "patchMerge.layerNorm.weight", N + "pm.g")) return rc;
         if (int rc = pack_vec(m, kVitP, P + "patchMerge.layerNorm.bias", N + "pm.beta")) return rc;
         for (int l = 0; l < c.vit_layers[s]; ++l) {
             const std::string A = P + "_attn." + std::to_string(l) + ".", F = P + "_ffn." + std::to_string(l) + ".";
             const std::string NL = N + std::to_string(l) + ".";
-            if (int rc = pack_conv(m, kVitP, A + "cn1", NL + "red")) return rc;
+            if (int rc = pack_conv(m, kVitP, A + "cn1", NL + "red", true, false, w16)) return rc;
             if (int rc = pack_vec(m, kVitP, A + "ln1.weight", NL + "ln1.g")) return rc;
             if (int rc = pack_vec(m, kVitP, A + "ln1.bias", NL + "ln1.beta")) return rc;
-            if (int rc = pack_linear(m, kVitP, A + "keyValueExtractor", NL + "kv")) return rc;
-            if (int rc = pack_linear(m, kVitP, A + "query", NL + "q")) return rc;
-            if (int rc = pack_linear(m, kVitP, A + "finalLayer", NL + "fin")) return rc;
-            if (int rc = pack_linear(m, kVitP, F + "mlp1", NL + "mlp1")) return rc;
+            if (int rc = pack_linear(m, kVitP, A + "keyValueExtractor", NL + "kv", true, nullptr, w16)) return rc;
+            if (int rc = pack_linear(m, kVitP, A + "query", NL + "q", true, nullptr, w16)) return rc;
+            if (int rc = pack_linear(m, kVitP, A + "finalLayer", NL + "fin", true, nullptr, w16)) return rc;
+            if (int rc = pack_linear(m, kVitP, F + "mlp1", NL + "mlp1", true, nullptr, w16)) return rc;
             if (int rc = pack_vec(m, kVitP, F + "depthwise.weight", NL + "dw.w")) return rc;
             if (int rc = pack_vec(m, kVitP, F + "depthwise.bias", NL + "dw.b")) return rc;
-            if (int rc = pack_linear(m, kVitP, F + "mlp2", NL + "mlp2")) return rc;
+            if (int rc = pack_linear(m, kVitP, F + "mlp2", NL + "mlp2", true, nullptr, w16)) return rc;
             if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".weight", NL + "ln.g")) return rc;
             if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".bias", NL + "ln.beta")) return rc;
         }
     }
     if (c.head == EVFLY_HEAD_NONE) return 0;
-    if (int rc = pack_conv(m, kVitP, "down_sample", "ds", true, true)) return rc;
+    if (int rc = pack_conv(m, kVitP, "down_sample", "ds", true, true, w16)) return rc;
     // decoder consumes out.flatten(1) of a (12,16,24) CHW tensor (vitfly_models.py:143); ours is HWC
     std::vector<int> perm(4608);
     for (int ch = 0; ch < 12; ++ch)
         for (int p = 0; p < 384; ++p) perm[ch * 384 + p] = p * 12 + ch;
-    if (int rc = pack_linear(m, kVitP, "decoder", "dec", true, &perm)) return rc;
+    if (int rc = pack_linear(m, kVitP, "decoder", "dec", true, &perm, w16)) return rc;
     if (c.head == EVFLY_HEAD_LSTMNETVIT) {
         // layer 0 input side as a GEMM over all frames; biases b_ih + b_hh folded into its bias
         const HostTensor *wi0 = m->find("lstm.weight_ih_l0", kVitP);
         if (!wi0) return fail(-4, "missing tensor lstm.weight_ih_l0");
-        const int G = (int)wi0->shape[0], I = (int)wi0->shape[1], ld = round_up(I, 32);
+        const int G = (int)wi0->shape[0], I = (int)wi0->shape[1], ld = round_up(I, w16 ? 64 : 32);
         EVFLY_REQUIRE(G == 512 && I == 517, "lstm.weight_ih_l0: expected (512,517)");
-        float *d0 = m->stage("lstm.ih0.w", (size_t)G * ld);
-        for (int g = 0; g < G; ++g)
-            for (int i = 0; i < I; ++i) d0[(size_t)g * ld + i] = wi0->v[(size_t)g * I + i];
+        if (w16) {
+            bf16_t *d0 = m->stage16("lstm.ih0.w", (size_t)G * ld);
+            for (int g = 0; g < G; ++g)
+                for (int i = 0; i < I; ++i) d0[(size_t)g * ld + i] = host_f2bf(wi0->v[(size_t)g * I + i]);
+        } else {
+            float *d0 = m->stage("lstm.ih0.w", (size_t)G * ld);
+            for (int g = 0; g < G; ++g)
+                for (int i = 0; i < I; ++i) d0[(size_t)g * ld + i] = wi0->v[(size_t)g * I + i];
+        }
         m->wld["lstm.ih0"] = ld;
         for (int l = 0; l < 3; ++l) {
             const std::string sl = std::to_string(l);
@@ -462,8 +522,8 @@ int pack_vit(evfly_model *m) {
         }
         if (int rc = pack_linear(m, kVitP, "nn_fc2", "fc2")) return rc;
     } else {
-        if (int rc = pack_linear(m, kVitP, "nn_fc1", "fc1")) return rc;
-        if (int rc = pack_linear(m, kVitP, "nn_fc2", "fc2")) return rc;
+        if (int rc = pack_linear(m, kVitP, "nn_fc1", "fc1", true, nullptr, w16)) return rc;
+        if (int rc = pack_linear(m, kVitP, "nn_fc2", "fc2", true, nullptr, w16)) return rc;
     }
     return 0;
 }
@@ -474,20 +534,24 @@ struct Ctx {
     hipStream_t st;
 };
 
+// element types of a GEMM's tensors in the bf16 pipeline (fp32 pipelines pass 0)
+enum : int { IN16 = 1, OUT16 = 2, RES16 = 4, IO16 = IN16 | OUT16 };
+
 // y[N,OH,OW,Cout] = act(conv(x) + b (+res))
 int conv(evfly_model *m, const char *pname, const std::string &wname, const float *x, int n, int H, int W, int C,
          int64_t ldx, int cout, int kh, int kw, int stride, int pad, int act, const float *res, int64_t ldres, float *y,
          int64_t ldy, float *y_pool = nullptr, bool *pool_fused = nullptr, float *skip_y = nullptr, int skip_h = 0, int skip_w = 0,
-         int64_t skip_ld = 0, int *skip_region = nullptr) {
+         int64_t skip_ld = 0, int *skip_region = nullptr, int f16 = 0) {
     ConvDesc d;
     d.x = x; d.ldx = ldx; d.NI = n; d.H = H; d.W = W; d.C = C;
-    d.w = m->W(wname + ".w"); d.ldw = m->planning ? round_up(kh * kw * C, 32) : m->wld[wname];
+    d.in_bf16 = (f16 & IN16) != 0; d.out_bf16 = (f16 & OUT16) != 0; d.res_bf16 = (f16 & RES16) != 0;
+    d.w = m->W(wname + ".w"); d.ldw = m->planning ? round_up(kh * kw * C, d.in_bf16 ? 64 : 32) : m->wld[wname];
     d.bias = m->W(wname + ".b");
     d.KH = kh; d.KW = kw; d.stride = stride; d.pad = pad;
     conv_finish(d);
     d.Nc = cout; d.res = res; d.ldres = ldres; d.act = act; d.y = y; d.ldy = ldy; d.dtype = m->cfg.compute_dtype;
     if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", wname.c_str());
-    const double bytes = 4.0 * ((double)n * H * W * C + (double)d.M * cout + (double)cout * d.K);
+    const double bytes = (d.in_bf16 ? 2.0 : 4.0) * ((double)n * H * W * C + (double)cout * d.K) + (d.out_bf16 ? 2.0 : 4.0) * (double)d.M * cout;
     const std::string pn = std::string(pname) + "/" + wname;   // family/layer: bench.py groups by family
     double extra_flops = 0;
     if (m->pre.frames) {                                       // first U-Net conv computed on the fly by the consumer
@@ -496,7 +560,7 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
         extra_flops = 2.0 * n * H * W * C * 9 * m->pre.cin;
         m->pre.frames = nullptr;
     }
-    if (wino_applicable(d) && m->has(wname + ".u")) {          // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
+    if (!f16 && wino_applicable(d) && m->has(wname + ".u")) {  // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
         d.y_pool = y_pool;                                     // nn.MaxPool2d(2,2): one window per Winograd tile
         if (pool_fused) *pool_fused = y_pool != nullptr;
         if (skip_y && skip_region) {                           // 'interp' skip: resampled from the tile in LDS where the taps allow
@@ -507,7 +571,10 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
             d.skip_bands = d.skip_y && y_pool && !m->full_encoder_outputs;
             if (d.skip_bands && !m->planning) m->bands_used = true;
         }
-        if (!m->planning && m->profiling) m->next_exec = wino_exec_flops(d);   // only a profiled launch consumes it
+        if (!m->planning && m->profiling) {                                    // only a profiled launch consumes them
+            m->next_exec = wino_exec_flops(d);
+            m->next_useful = igemm_flops(d) * (16.0 / 36.0);
+        }
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;
     }
@@ -518,9 +585,10 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
 }
 
 int linear(evfly_model *m, const char *pname, const std::string &wname, const float *x, int64_t rows, int K, int64_t ldx,
-           int cout, int act, const float *res, int64_t ldres, float *y, int64_t ldy) {
+           int cout, int act, const float *res, int64_t ldres, float *y, int64_t ldy, int f16 = 0) {
     // rows can exceed int range only for absurd batches; NI is an int
-    return conv(m, pname, wname, x, (int)rows, 1, 1, K, ldx, cout, 1, 1, 1, 0, act, res, ldres, y, ldy);
+    return conv(m, pname, wname, x, (int)rows, 1, 1, K, ldx, cout, 1, 1, 1, 0, act, res, ldres, y, ldy, nullptr, nullptr, nullptr, 0, 0, 0,
+                nullptr, f16);
 }
 
 }  // namespace
@@ -537,14 +605,19 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     const int cin = (c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels;
     const int apply_form = (c.num_in_channels == 2 || c.form_bev > 0) ? 1 : 0;   // learner_models.py:523
     hipStream_t st = m->st;
+    const bool a16 = m->act16;                 // bf16 pipeline: every activation below is bf16 unless it says fp32
+    const int io = a16 ? IO16 : 0;
 
     // ---- encoder (valid 3x3 convs; sizes of learner_models.py:373-390)
     // exact-fp32 mode: e11 (1 or 2 -> 32 channels, HBM-write-bound: 11.4 MB per frame) is never materialised; the
     // Winograd kernel of e12 computes its input patch from the raw frame while staging it
     static const bool no_fuse = getenv("EVFLY_NO_E11_FUSION") != nullptr;
     const bool fuse_e11 = c.compute_dtype == EVFLY_DTYPE_F32 && m->has("e12.u") && !no_fuse;
-    float *e11 = fuse_e11 ? nullptr : m->alloc((int64_t)F * 258 * 344 * 32);
-    if (!fuse_e11)
+    float *e11 = fuse_e11 ? nullptr : m->alloc_act((int64_t)F * 258 * 344 * 32);
+    if (!fuse_e11 && a16)
+        RUN(m, "e11_direct", 2.0 * F * 258 * 344 * 32 * 9 * cin, F * (4.0 * 260 * 346 + 2.0 * 258 * 344 * 32),
+            launch16_e11(frames, F, 260, 346, cin, c.form_bev, apply_form, c.evs_min_cutoff, m->W("e11.w"), m->W("e11.b"), e11, st));
+    else if (!fuse_e11)
     RUN(m, "e11_direct", 2.0 * F * 258 * 344 * 32 * 9 * cin, 4.0 * F * (260.0 * 346 + 258.0 * 344 * 32),
         launch_e11(frames, F, 260, 346, cin, c.form_bev, apply_form, c.evs_min_cutoff, m->W("e11.w"), m->W("e11.b"), e11, st));
     struct Lvl { int H, W, C; float *y; } lv[5];
@@ -557,7 +630,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     float *cats[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // by decoder level 1..4
     int skip_region[5][2] = {};                                            // block region of the fused producer (0: not fused)
     if (run_decoder && c.skip_type == EVFLY_SKIP_INTERP && !no_skip_fuse)
-        for (int l = 1; l <= 4; ++l) cats[l] = m->alloc((int64_t)F * small[l - 1][0] * small[l - 1][1] * 2 * (512 >> l));
+        for (int l = 1; l <= 4; ++l) cats[l] = m->alloc_act((int64_t)F * small[l - 1][0] * small[l - 1][1] * 2 * (512 >> l));
     const float *cur = e11;
     int H = 258, W = 344, C = 32;
     const char *names[5][2] = {{nullptr, "e12"}, {"e21", "e22"}, {"e31", "e32"}, {"e41", "e42"}, {"e51", "e52"}};
@@ -567,14 +640,16 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     for (int l = 0; l < 5; ++l) {
         if (l > 0) {
             float *p = pooled;
-            if (!pool_done) RUN(m, "maxpool", 0, 4.0 * F * H * W * C * 1.25, launch_maxpool2x2(cur, F, H, W, C, p, st));
+            if (!pool_done && a16) RUN(m, "maxpool", 0, 2.0 * F * H * W * C * 1.25, launch16_maxpool2x2(cur, F, H, W, C, p, st));
+            else if (!pool_done) RUN(m, "maxpool", 0, 4.0 * F * H * W * C * 1.25, launch_maxpool2x2(cur, F, H, W, C, p, st));
             cur = p; H /= 2; W /= 2;
-            float *a = m->alloc((int64_t)F * (H - 2) * (W - 2) * chans[l]);
-            if (int rc = conv(m, "conv3x3", names[l][0], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, chans[l])) return rc;
+            float *a = m->alloc_act((int64_t)F * (H - 2) * (W - 2) * chans[l]);
+            if (int rc = conv(m, "conv3x3", names[l][0], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, chans[l],
+                              nullptr, nullptr, nullptr, 0, 0, 0, nullptr, io)) return rc;
             cur = a; H -= 2; W -= 2; C = chans[l];
         }
-        float *b = m->alloc((int64_t)F * (H - 2) * (W - 2) * chans[l]);
-        pooled = l < 4 ? m->alloc((int64_t)F * ((H - 2) / 2) * ((W - 2) / 2) * chans[l]) : nullptr;
+        float *b = m->alloc_act((int64_t)F * (H - 2) * (W - 2) * chans[l]);
+        pooled = l < 4 ? m->alloc_act((int64_t)F * ((H - 2) / 2) * ((W - 2) / 2) * chans[l]) : nullptr;
         pool_done = false;
         if (l == 0 && fuse_e11) {
             m->pre.frames = frames; m->pre.w = m->W("e11.w"); m->pre.b = m->W("e11.b"); m->pre.cin = cin;
@@ -584,24 +659,25 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         float *skip_dst = l < 4 ? cats[dl] : nullptr;
         if (int rc = conv(m, "conv3x3", names[l][1], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, chans[l],
                           pooled, &pool_done, skip_dst, skip_dst ? small[dl - 1][0] : 0, skip_dst ? small[dl - 1][1] : 0, 2 * chans[l],
-                          skip_dst ? skip_region[dl] : nullptr)) return rc;
+                          skip_dst ? skip_region[dl] : nullptr, io)) return rc;
         cur = b; H -= 2; W -= 2; C = chans[l];
         lv[l] = Lvl{H, W, C, b};
         static const char *tn[5] = {"e1", "e2", "e3", "e4", "e5"};
-        m->tap(tn[l], b, F, H, W, C);
+        m->tap(tn[l], b, F, H, W, C, a16);
     }
     // ---- ConvLSTM bottleneck (batch-as-time: the T frames of a stream are its time steps)
     float *y5 = lv[4].y;   // (F, 8, 13, 512)
     if (c.num_recurrent_unet > 0) {
         const int rpi = 8 * 13, hid = 512;
-        float *zx = m->alloc((int64_t)F * rpi * 4 * hid);
+        float *zx = m->alloc((int64_t)F * rpi * 4 * hid);          // fp32 pre-activations in every pipeline
         {   // input-side 1x1 conv for every frame at once
             ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W("clstm.wx"); d.ldw = hid;
-            conv_finish(d); d.Nc = 4 * hid; d.y = zx; d.ldy = 4 * hid; d.dtype = c.compute_dtype;
-            RUN(m, "convlstm_x_gemm", igemm_flops(d), 4.0 * (d.M * 5.0 * hid + 4.0 * hid * hid), igemm_launch(d, st));
+            conv_finish(d); d.Nc = 4 * hid; d.y = zx; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
+            RUN(m, "convlstm_x_gemm", igemm_flops(d), d.M * (a16 ? 2.0 : 4.0) * hid + d.M * 16.0 * hid + (a16 ? 2.0 : 4.0) * 4.0 * hid * hid,
+                igemm_launch(d, st));
         }
         float *z = m->alloc((int64_t)S * rpi * 4 * hid);
-        float *hseq = m->alloc((int64_t)F * rpi * hid);
+        float *hseq = m->alloc_act((int64_t)F * rpi * hid);
         float *hs = h_state, *cs = c_state;
         if (!hs) {
             hs = m->alloc((int64_t)S * rpi * hid); cs = m->alloc((int64_t)S * rpi * hid);
@@ -610,21 +686,44 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
                 EVFLY_HIP(hipMemsetAsync(cs, 0, (size_t)S * rpi * hid * 4, st));
             }
         }
+        // bf16 pipeline: the hidden-side GEMM reads a bf16 copy of h that the gate kernel keeps beside the fp32 state
+        float *h16 = a16 ? m->alloc_act((int64_t)S * rpi * hid) : nullptr;
+        if (a16 && !m->planning) {
+            if (int rc = launch_f32_to_bf16(hs, (int64_t)S * rpi * hid, h16, st)) return rc;
+        }
         for (int t = 0; t < T; ++t) {
-            ConvDesc d; d.x = hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W("clstm.wh"); d.ldw = hid;
-            conv_finish(d); d.Nc = 4 * hid; d.y = z; d.ldy = 4 * hid; d.dtype = c.compute_dtype;
+            ConvDesc d; d.x = a16 ? h16 : hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W("clstm.wh"); d.ldw = hid;
+            conv_finish(d); d.Nc = 4 * hid; d.y = z; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             d.res = zx + (int64_t)t * rpi * 4 * hid; d.ldres = 4 * hid; d.res_rpi = rpi; d.res_img_rows = (int64_t)T * rpi;
-            RUN(m, "convlstm_h_gemm", igemm_flops(d), 4.0 * (d.M * 9.0 * hid + 4.0 * hid * hid), igemm_launch(d, st));
+            RUN(m, "convlstm_h_gemm", igemm_flops(d), d.M * (a16 ? 2.0 : 4.0) * hid + d.M * 32.0 * hid + (a16 ? 2.0 : 4.0) * 4.0 * hid * hid,
+                igemm_launch(d, st));
+            if (a16)
+                RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
+                    launch16_convlstm_gates(z, (int64_t)S * rpi, hid, cs, hs, h16, m->eoff(hseq, (int64_t)t * rpi * hid), rpi, (int64_t)T * rpi, st));
+            else
             RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
                 launch_convlstm_gates(z, (int64_t)S * rpi, hid, cs, hs, hseq + (int64_t)t * rpi * hid, rpi, (int64_t)T * rpi, st));
         }
         y5 = hseq;
-        m->tap("e5_lstm", hseq, F, 8, 13, 512);
+        m->tap("e5_lstm", hseq, F, 8, 13, 512, a16);
     }
     // ---- decoder (learner_models.py:553-583); is_deployment skips it unless a velpred head reads its output
+    // the velpred head runs on fp32 activations in every pipeline (its inputs are fp32 images except y_e5)
+    auto y5_f32 = [&](const float **out) -> int {
+        *out = y5;
+        if (!a16) return 0;
+        float *t = m->alloc((int64_t)F * 8 * 13 * 512);
+        if (!m->planning) { if (int rc = launch_bf16_to_f32(y5, (int64_t)F * 8 * 13 * 512, t, st)) return rc; }
+        *out = t;
+        return 0;
+    };
     if (!run_decoder) {
         if (depth_dev) *depth_dev = nullptr;
-        if (c.velpred == 2 && yvel_out) return velpred_chunk(m, y5, S, T, vp_h, vp_c, yvel_out);
+        if (c.velpred == 2 && yvel_out) {
+            const float *y5f = nullptr;
+            if (int rc = y5_f32(&y5f)) return rc;
+            return velpred_chunk(m, y5f, S, T, vp_h, vp_c, yvel_out);
+        }
         return 0;
     }
     const float *dcur = y5;
@@ -634,9 +733,14 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         const int co = dc / 2, uh = 2 * dh, uw = 2 * dw;
         EVFLY_REQUIRE(uh == small[l - 1][0] && uw == small[l - 1][1], "decoder geometry");
         const int ccat = c.skip_type == EVFLY_SKIP_NONE ? co : 2 * co;
-        float *cat = cats[l] ? cats[l] : m->alloc((int64_t)F * uh * uw * ccat);
-        float *up_dst = cat + (ccat - co);
-        if (c.skip_type == EVFLY_SKIP_INTERP)       // F.interpolate(y, size=small, bilinear, align_corners=False) (:514)
+        float *cat = cats[l] ? cats[l] : m->alloc_act((int64_t)F * uh * uw * ccat);
+        float *up_dst = m->eoff(cat, ccat - co);
+        if (c.skip_type == EVFLY_SKIP_INTERP && a16)
+            RUN(m, "skip_bilinear", 0, 2.0 * F * uh * uw * co * 5, launch16_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, st));
+        else if (c.skip_type == EVFLY_SKIP_CROP && a16)
+            RUN(m, "skip_crop", 0, 2.0 * F * uh * uw * co * 2,
+                launch16_crop(enc.y, F, enc.H, enc.W, enc.C, enc.H / 2 - uh / 2, enc.W / 2 - uw / 2, cat, uh, uw, ccat, st));
+        else if (c.skip_type == EVFLY_SKIP_INTERP)  // F.interpolate(y, size=small, bilinear, align_corners=False) (:514)
         {
             // share of the skip pixels left to the resize kernel (taps in two producer blocks): rows / columns whose second tap
             // starts a block region, counted with the resize's own index arithmetic (for the bytes figure of the profile only)
@@ -664,26 +768,33 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             ConvDesc d; d.x = dcur; d.ldx = dc; d.NI = F; d.H = dh; d.W = dw; d.C = dc; d.w = m->W(un + ".w");
             d.ldw = m->planning ? dc : m->wld[un]; d.bias = m->W(un + ".b");
             conv_finish(d); d.Nc = 4 * co; d.y = up_dst; d.ldy = ccat; d.out_mode = OUT_UPCONV2X2; d.up_cout = co;
-            d.dtype = c.compute_dtype;
-            RUN(m, "upconv2x2", igemm_flops(d), 4.0 * F * dh * dw * (dc + 4.0 * co), igemm_launch(d, st));
+            d.dtype = c.compute_dtype; d.in_bf16 = d.out_bf16 = a16;
+            RUN(m, "upconv2x2", igemm_flops(d), (a16 ? 2.0 : 4.0) * F * dh * dw * (dc + 4.0 * co), igemm_launch(d, st));
         }
-        float *a = m->alloc((int64_t)F * (uh - 2) * (uw - 2) * co);
+        float *a = m->alloc_act((int64_t)F * (uh - 2) * (uw - 2) * co);
         const std::string n1 = "d" + std::to_string(l) + "1", n2 = "d" + std::to_string(l) + "2";
-        if (int rc = conv(m, "conv3x3", n1, cat, F, uh, uw, ccat, ccat, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, co)) return rc;
-        float *b = m->alloc((int64_t)F * (uh - 4) * (uw - 4) * co);
-        if (int rc = conv(m, "conv3x3", n2, a, F, uh - 2, uw - 2, co, co, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, co)) return rc;
+        if (int rc = conv(m, "conv3x3", n1, cat, F, uh, uw, ccat, ccat, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, co, nullptr, nullptr, nullptr,
+                          0, 0, 0, nullptr, io)) return rc;
+        float *b = m->alloc_act((int64_t)F * (uh - 4) * (uw - 4) * co);
+        if (int rc = conv(m, "conv3x3", n2, a, F, uh - 2, uw - 2, co, co, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, co, nullptr, nullptr, nullptr,
+                          0, 0, 0, nullptr, io)) return rc;
         dcur = b; dh = uh - 4; dw = uw - 4; dc = co;
         static const char *tn[4] = {"d1", "d2", "d3", "d4"};
-        m->tap(tn[l - 1], b, F, dh, dw, dc);
+        m->tap(tn[l - 1], b, F, dh, dw, dc, a16);
     }
     // ---- unet_out (1x1, 32 -> 1) and form_output (:496-508)
     float *up = upconv_out ? upconv_out : m->alloc((int64_t)F * 68 * 148);
+    if (a16) RUN(m, "unet_out", 2.0 * F * 68 * 148 * 32, F * 68.0 * 148 * (2.0 * 32 + 4), launch16_dot_out(dcur, (int64_t)F * 68 * 148, 32, m->W("out.w"), m->W("out.b"), up, st));
+    else
     RUN(m, "unet_out", 2.0 * F * 68 * 148 * 32, 4.0 * F * 68 * 148 * 33, launch_dot_out(dcur, (int64_t)F * 68 * 148, 32, m->W("out.w"), m->W("out.b"), up, st));
     float *dp = depth_out ? depth_out : m->alloc((int64_t)F * c.input_h * c.input_w);
     RUN(m, "depth_bilinear", 0, 4.0 * F * c.input_h * c.input_w * 2, launch_bilinear(up, F, 68, 148, 1, 1, dp, c.input_h, c.input_w, 1, 0, 0, st));
     if (depth_dev) *depth_dev = dp;
-    if (c.velpred > 0 && yvel_out)
-        return velpred_chunk(m, c.velpred == 1 ? dp : c.velpred == 11 ? up : y5, S, T, vp_h, vp_c, yvel_out);
+    if (c.velpred > 0 && yvel_out) {
+        const float *y5f = nullptr;
+        if (c.velpred == 2) { if (int rc = y5_f32(&y5f)) return rc; }
+        return velpred_chunk(m, c.velpred == 1 ? dp : c.velpred == 11 ? up : y5f, S, T, vp_h, vp_c, yvel_out);
+    }
     return 0;
 }
 
@@ -758,51 +869,67 @@ static int velpred_chunk(evfly_model *m, const float *x, int S, int T, float *vp
 }
 
 // ============================================================================ Mix-Transformer stage
+// x16: the stage input is a bf16 activation (bf16 pipeline, stage 2 / a stand-alone stage with C_in % 32 == 0); a stage fed
+// by the fp32 depth image (stage 1, C_in = 1) reads fp32 and writes bf16.
 static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W, int Cin, float *y_out, float **y_ret,
-                     int *Ho, int *Wo) {
+                     int *Ho, int *Wo, bool x16 = false) {
     const auto &c = m->cfg;
     hipStream_t st = m->st;
+    const bool a16 = m->act16;
+    const int io = a16 ? IO16 : 0;
+    const double eb = a16 ? 2.0 : 4.0;
     const int C = c.vit_width[s], heads = c.vit_heads[s], R = c.vit_reduction[s], E = C * c.vit_expansion;
     const int k = c.vit_patch[s], sd = c.vit_stride[s], pd = c.vit_pad[s];
     const int h = (H + 2 * pd - k) / sd + 1, w = (W + 2 * pd - k) / sd + 1;
     const int64_t rows = (int64_t)n * h * w;
     const std::string N = "s" + std::to_string(s) + ".";
+    auto layernorm = [&](const float *src, int64_t nrows, const std::string &g, const std::string &bta, float *dst) -> int {
+        if (a16) RUN(m, "vit_layernorm", 0, 2 * eb * nrows * C, launch16_layernorm(src, nrows, C, m->W(g), m->W(bta), dst, st));
+        else RUN(m, "vit_layernorm", 0, 8.0 * nrows * C, launch_layernorm(src, nullptr, nrows, C, m->W(g), m->W(bta), dst, st));
+        return 0;
+    };
     // OverlapPatchMerging: conv + LayerNorm (ViTsubmodules.py:30-33)
-    float *t0 = m->alloc(rows * C);
-    if (int rc = conv(m, "vit_patch_conv", N + "pm", x, n, H, W, Cin, Cin, C, k, k, sd, pd, ACT_NONE, nullptr, 0, t0, C)) return rc;
-    float *xcur = m->alloc(rows * C);
-    RUN(m, "vit_layernorm", 0, 8.0 * rows * C, launch_layernorm(t0, nullptr, rows, C, m->W(N + "pm.g"), m->W(N + "pm.beta"), xcur, st));
+    float *t0 = m->alloc_act(rows * C);
+    if (int rc = conv(m, "vit_patch_conv", N + "pm", x, n, H, W, Cin, Cin, C, k, k, sd, pd, ACT_NONE, nullptr, 0, t0, C, nullptr, nullptr, nullptr,
+                      0, 0, 0, nullptr, a16 ? (OUT16 | (x16 ? IN16 : 0)) : 0)) return rc;
+    float *xcur = m->alloc_act(rows * C);
+    if (int rc = layernorm(t0, rows, N + "pm.g", N + "pm.beta", xcur)) return rc;
     const int rh = (h - R) / R + 1, rw = (w - R) / R + 1, nkv = rh * rw;
     for (int l = 0; l < c.vit_layers[s]; ++l) {
         const std::string NL = N + std::to_string(l) + ".";
         // --- EfficientSelfAttention (:54-83)
-        float *red = m->alloc((int64_t)n * nkv * C);
-        if (int rc = conv(m, "vit_kv_reduce_conv", NL + "red", xcur, n, h, w, C, C, C, R, R, R, 0, ACT_NONE, nullptr, 0, red, C)) return rc;
-        float *redn = m->alloc((int64_t)n * nkv * C);
-        RUN(m, "vit_layernorm", 0, 8.0 * n * nkv * C, launch_layernorm(red, nullptr, (int64_t)n * nkv, C, m->W(NL + "ln1.g"), m->W(NL + "ln1.beta"), redn, st));
-        float *kv = m->alloc((int64_t)n * nkv * 2 * C);
-        if (int rc = linear(m, "vit_linear", NL + "kv", redn, (int64_t)n * nkv, C, C, 2 * C, ACT_NONE, nullptr, 0, kv, 2 * C)) return rc;
-        float *q = m->alloc(rows * C);
-        if (int rc = linear(m, "vit_linear", NL + "q", xcur, rows, C, C, C, ACT_NONE, nullptr, 0, q, C)) return rc;
-        float *att = m->alloc(rows * C);
-        RUN(m, "vit_attention", 4.0 * rows * C * nkv, 8.0 * rows * C, launch_attention(q, kv, n, h * w, nkv, C, heads, att, st));
-        float *x1 = m->alloc(rows * C);   // x = x + attn(x)   (:144)
-        if (int rc = linear(m, "vit_linear", NL + "fin", att, rows, C, C, C, ACT_NONE, xcur, C, x1, C)) return rc;
+        float *red = m->alloc_act((int64_t)n * nkv * C);
+        if (int rc = conv(m, "vit_kv_reduce_conv", NL + "red", xcur, n, h, w, C, C, C, R, R, R, 0, ACT_NONE, nullptr, 0, red, C, nullptr, nullptr,
+                          nullptr, 0, 0, 0, nullptr, io)) return rc;
+        float *redn = m->alloc_act((int64_t)n * nkv * C);
+        if (int rc = layernorm(red, (int64_t)n * nkv, NL + "ln1.g", NL + "ln1.beta", redn)) return rc;
+        float *kv = m->alloc_act((int64_t)n * nkv * 2 * C);
+        if (int rc = linear(m, "vit_linear", NL + "kv", redn, (int64_t)n * nkv, C, C, 2 * C, ACT_NONE, nullptr, 0, kv, 2 * C, io)) return rc;
+        float *q = m->alloc_act(rows * C);
+        if (int rc = linear(m, "vit_linear", NL + "q", xcur, rows, C, C, C, ACT_NONE, nullptr, 0, q, C, io)) return rc;
+        float *att = m->alloc_act(rows * C);
+        if (a16) RUN(m, "vit_attention", 4.0 * rows * C * nkv, 2 * eb * rows * C, launch16_attention(q, kv, n, h * w, nkv, C, heads, att, st));
+        else RUN(m, "vit_attention", 4.0 * rows * C * nkv, 8.0 * rows * C, launch_attention(q, kv, n, h * w, nkv, C, heads, att, st));
+        float *x1 = m->alloc_act(rows * C);   // x = x + attn(x)   (:144)
+        if (int rc = linear(m, "vit_linear", NL + "fin", att, rows, C, C, C, ACT_NONE, xcur, C, x1, C, a16 ? (IO16 | RES16) : 0)) return rc;
         // --- MixFFN (:98-120)
-        float *h1 = m->alloc(rows * E);
-        if (int rc = linear(m, "vit_linear", NL + "mlp1", x1, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E)) return rc;
-        float *h2 = m->alloc(rows * E);
+        float *h1 = m->alloc_act(rows * E);
+        if (int rc = linear(m, "vit_linear", NL + "mlp1", x1, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E, io)) return rc;
+        float *h2 = m->alloc_act(rows * E);
+        if (a16) RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 2 * eb * rows * E,
+                     launch16_grouped_conv_gelu(h1, n, h, w, E, m->W(NL + "dw.w"), m->W(NL + "dw.b"), h2, st));
+        else
         RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 8.0 * rows * E,
             launch_grouped_conv_gelu(h1, n, h, w, E, m->W(NL + "dw.w"), m->W(NL + "dw.b"), h2, st));
-        float *x2 = m->alloc(rows * C);   // x = x + ffn(x)    (:145)
-        if (int rc = linear(m, "vit_linear", NL + "mlp2", h2, rows, E, E, C, ACT_NONE, x1, C, x2, C)) return rc;
+        float *x2 = m->alloc_act(rows * C);   // x = x + ffn(x)    (:145)
+        if (int rc = linear(m, "vit_linear", NL + "mlp2", h2, rows, E, E, C, ACT_NONE, x1, C, x2, C, a16 ? (IO16 | RES16) : 0)) return rc;
         const bool last = l == c.vit_layers[s] - 1;
-        float *xn = (last && y_out) ? y_out : m->alloc(rows * C);
-        RUN(m, "vit_layernorm", 0, 8.0 * rows * C, launch_layernorm(x2, nullptr, rows, C, m->W(NL + "ln.g"), m->W(NL + "ln.beta"), xn, st));
+        float *xn = (last && y_out) ? y_out : m->alloc_act(rows * C);
+        if (int rc = layernorm(x2, rows, NL + "ln.g", NL + "ln.beta", xn)) return rc;
         xcur = xn;
     }
     if (c.vit_layers[s] == 0 && y_out && !m->planning)
-        EVFLY_HIP(hipMemcpyAsync(y_out, xcur, (size_t)rows * C * 4, hipMemcpyDeviceToDevice, st));
+        EVFLY_HIP(hipMemcpyAsync(y_out, xcur, (size_t)rows * C * m->esz(), hipMemcpyDeviceToDevice, st));
     if (y_ret) *y_ret = xcur;
     *Ho = h; *Wo = w;
     return 0;
@@ -814,7 +941,10 @@ static int vit_chunk(evfly_model *m, const float *img, int ih, int iw, int clip2
     const auto &c = m->cfg;
     hipStream_t st = m->st;
     const int F = S * T;
-    // refine_inputs (vitfly_models.py:27-29) + the depth hand-off clip (learner_models.py:634)
+    const bool a16 = m->act16;
+    const int io = a16 ? IO16 : 0;
+    const double eb = a16 ? 2.0 : 4.0;
+    // refine_inputs (vitfly_models.py:27-29) + the depth hand-off clip (learner_models.py:634); fp32 in every pipeline
     const float *vin = img;
     if (ih != 60 || iw != 90 || clip2x) {
         float *t = m->alloc((int64_t)F * 60 * 90);
@@ -824,34 +954,43 @@ static int vit_chunk(evfly_model *m, const float *img, int ih, int iw, int clip2
     m->tap("vit_in", const_cast<float *>(vin), F, 60, 90, 1);
     float *s1 = nullptr, *s2 = nullptr;
     int h1, w1, h2, w2;
-    if (int rc = vit_stage(m, 0, vin, F, 60, 90, c.vit_in_channels, nullptr, &s1, &h1, &w1)) return rc;
-    m->tap("s1", s1, F, h1, w1, c.vit_width[0]);
-    if (int rc = vit_stage(m, 1, s1, F, h1, w1, c.vit_width[0], nullptr, &s2, &h2, &w2)) return rc;
-    m->tap("s2", s2, F, h2, w2, c.vit_width[1]);
+    if (int rc = vit_stage(m, 0, vin, F, 60, 90, c.vit_in_channels, nullptr, &s1, &h1, &w1, false)) return rc;
+    m->tap("s1", s1, F, h1, w1, c.vit_width[0], a16);
+    if (int rc = vit_stage(m, 1, s1, F, h1, w1, c.vit_width[0], nullptr, &s2, &h2, &w2, a16)) return rc;
+    m->tap("s2", s2, F, h2, w2, c.vit_width[1], a16);
     EVFLY_REQUIRE(2 * h2 == 16 && 2 * w2 == 24, "ViT head expects a 16x24 map (got %dx%d)", 2 * h2, 2 * w2);
     // cat[PixelShuffle(2)(s2), Upsample(s1 -> 16x24, align_corners=True)]   (vitfly_models.py:141)
     // (pixel pitch padded to a multiple of 32 channels, the padding zero: the head conv then takes the GEMM kernel's
     // vectorised K walk -- with 48 channels it fell back to the per-element gather, 0.14 ms for 2.5 GFLOP)
     const int c_ps = c.vit_width[1] / 4, ccat_real = c_ps + c.vit_width[0], ccat = round_up(ccat_real, 32);
-    float *cat = m->alloc((int64_t)F * 16 * 24 * ccat);
-    if (ccat != ccat_real && !m->planning) EVFLY_HIP(hipMemsetAsync(cat, 0, (size_t)F * 16 * 24 * ccat * 4, st));
+    float *cat = m->alloc_act((int64_t)F * 16 * 24 * ccat);
+    if (ccat != ccat_real && !m->planning) EVFLY_HIP(hipMemsetAsync(cat, 0, (size_t)F * 16 * 24 * ccat * m->esz(), st));
+    if (a16) {
+        EVFLY_REQUIRE(c_ps % 8 == 0 && c.vit_width[0] % 8 == 0, "bf16 pipeline: ViT head widths must be multiples of 8 channels");
+        RUN(m, "vit_pixel_shuffle", 0, 2 * eb * F * 384 * c_ps, launch16_pixel_shuffle2(s2, F, h2, w2, c.vit_width[1], cat, ccat, st));
+        RUN(m, "vit_upsample", 0, 2 * eb * F * 384 * c.vit_width[0],
+            launch16_bilinear(s1, F, h1, w1, c.vit_width[0], c.vit_width[0], m->eoff(cat, c_ps), 16, 24, ccat, 1, st));
+    } else {
     RUN(m, "vit_pixel_shuffle", 0, 8.0 * F * 384 * c_ps, launch_pixel_shuffle2(s2, F, h2, w2, c.vit_width[1], cat, ccat, st));
     RUN(m, "vit_upsample", 0, 8.0 * F * 384 * c.vit_width[0],
         launch_bilinear(s1, F, h1, w1, c.vit_width[0], c.vit_width[0], cat + c_ps, 16, 24, ccat, 1, 0, st));
-    float *flat = m->alloc((int64_t)F * 4608);
-    if (int rc = conv(m, "vit_head_conv", "ds", cat, F, 16, 24, ccat, ccat, 12, 3, 3, 1, 1, ACT_NONE, nullptr, 0, flat, 12)) return rc;
-    m->tap("flat", flat, F, 16, 24, 12);
+    }
+    float *flat = m->alloc_act((int64_t)F * 4608);
+    if (int rc = conv(m, "vit_head_conv", "ds", cat, F, 16, 24, ccat, ccat, 12, 3, 3, 1, 1, ACT_NONE, nullptr, 0, flat, 12, nullptr, nullptr, nullptr,
+                      0, 0, 0, nullptr, io)) return rc;
+    m->tap("flat", flat, F, 16, 24, 12, a16);
     const int LD = 544;   // 517 padded to a multiple of 32
-    float *x517 = m->alloc((int64_t)F * LD);
-    if (int rc = linear(m, "vit_decoder_linear", "dec", flat, F, 4608, 4608, 512, ACT_NONE, nullptr, 0, x517, LD)) return rc;
-    RUN(m, "vit_meta_fill", 0, 4.0 * F * 32, launch_meta_fill(x517, F, LD, desvel, quat, st));
-    m->tap("x517", x517, F, LD, 1, 1);
+    float *x517 = m->alloc_act((int64_t)F * LD);
+    if (int rc = linear(m, "vit_decoder_linear", "dec", flat, F, 4608, 4608, 512, ACT_NONE, nullptr, 0, x517, LD, io)) return rc;
+    if (a16) RUN(m, "vit_meta_fill", 0, eb * F * 32, launch16_meta_fill(x517, F, LD, desvel, quat, st));
+    else RUN(m, "vit_meta_fill", 0, 4.0 * F * 32, launch_meta_fill(x517, F, LD, desvel, quat, st));
+    m->tap("x517", x517, F, LD, 1, 1, a16);
     if (c.head == EVFLY_HEAD_LSTMNETVIT) {
-        float *xg0 = m->alloc((int64_t)F * 512);
+        float *xg0 = m->alloc((int64_t)F * 512);        // fp32: the recurrence kernel's input
         {
-            ConvDesc d; d.x = x517; d.ldx = LD; d.NI = F; d.C = LD; d.w = m->W("lstm.ih0.w"); d.ldw = LD; d.bias = m->W("lstm.b0");
-            conv_finish(d); d.Nc = 512; d.y = xg0; d.ldy = 512; d.dtype = c.compute_dtype;
-            RUN(m, "lstm_x_gemm", igemm_flops(d), 4.0 * (F * (LD + 512.0) + 512.0 * LD), igemm_launch(d, st));
+            ConvDesc d; d.x = x517; d.ldx = LD; d.NI = F; d.C = LD; d.w = m->W("lstm.ih0.w"); d.ldw = a16 ? round_up(LD, 64) : LD; d.bias = m->W("lstm.b0");
+            conv_finish(d); d.Nc = 512; d.y = xg0; d.ldy = 512; d.dtype = c.compute_dtype; d.in_bf16 = a16;
+            RUN(m, "lstm_x_gemm", igemm_flops(d), eb * (F * (double)LD + 512.0 * LD) + 4.0 * F * 512.0, igemm_launch(d, st));
         }
         LstmWeights w{};
         for (int l = 0; l < 3; ++l) {
@@ -862,9 +1001,9 @@ static int vit_chunk(evfly_model *m, const float *img, int ih, int iw, int clip2
         w.fc_w = m->W("fc2.w"); w.fc_b = m->W("fc2.b");
         RUN(m, "lstm_recurrence", 2.0 * F * 5 * 128 * 512, 4.0 * F * 5 * 128 * 512, launch_lstm(xg0, S, T, w, lstm_h, lstm_c, vel, st));
     } else {
-        float *f1 = m->alloc((int64_t)F * 256);
-        if (int rc = linear(m, "vit_fc", "fc1", x517, F, LD, LD, 256, ACT_LEAKY, nullptr, 0, f1, 256)) return rc;
-        if (int rc = linear(m, "vit_fc", "fc2", f1, F, 256, 256, 3, ACT_NONE, nullptr, 0, vel, 3)) return rc;
+        float *f1 = m->alloc_act((int64_t)F * 256);
+        if (int rc = linear(m, "vit_fc", "fc1", x517, F, LD, LD, 256, ACT_LEAKY, nullptr, 0, f1, 256, io)) return rc;
+        if (int rc = linear(m, "vit_fc", "fc2", f1, F, 256, 256, 3, ACT_NONE, nullptr, 0, vel, 3, a16 ? IN16 : 0)) return rc;
     }
     return 0;
 }
@@ -954,7 +1093,25 @@ extern "C" int evfly_vit_stage_forward(evfly_model *m, int stage, const float *x
     EVFLY_REQUIRE(x && y && n > 0, "vit_stage_forward: null argument");
     const int cin = stage == 0 ? m->cfg.vit_in_channels : m->cfg.vit_width[0];
     int ho, wo;
-    auto body = [&]() { return vit_stage(m, stage, x, n, h, w, cin, y, nullptr, &ho, &wo); };
+    if (!m->act16) {
+        auto body = [&]() { return vit_stage(m, stage, x, n, h, w, cin, y, nullptr, &ho, &wo); };
+        return with_arena(m, body);
+    }
+    // bf16 pipeline behind the fp32 ABI: the input is rounded to bf16 when the stage's first conv takes a bf16 operand
+    // (C_in % 32 == 0), the stage output is widened back to fp32
+    auto body = [&]() {
+        const bool x16 = cin % 32 == 0;
+        const float *xin = x;
+        if (x16) {
+            float *t = m->alloc_act((int64_t)n * h * w * cin);
+            if (!m->planning) { if (int rc = launch_f32_to_bf16(x, (int64_t)n * h * w * cin, t, m->st)) return rc; }
+            xin = t;
+        }
+        float *yr = nullptr;
+        if (int rc = vit_stage(m, stage, xin, n, h, w, cin, nullptr, &yr, &ho, &wo, x16)) return rc;
+        if (!m->planning) return launch_bf16_to_f32(yr, (int64_t)n * ho * wo * m->cfg.vit_width[stage], y, m->st);
+        return 0;
+    };
     return with_arena(m, body);
 }
 
@@ -1023,6 +1180,7 @@ extern "C" int evfly_model_create(const evfly_model_config *cfg, evfly_model **o
     auto *m = new evfly_model();
     m->cfg = *cfg;
     m->full_encoder_outputs = getenv("EVFLY_FULL_ENCODER_OUTPUTS") != nullptr;
+    m->act16 = cfg->compute_dtype == EVFLY_DTYPE_BF16 && getenv("EVFLY_BF16_LEGACY") == nullptr;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(-2, "hipGetDevice failed"); }
     *out = m;
     return 0;
@@ -1071,6 +1229,12 @@ extern "C" int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_
     for (int i = 0; i < 4; ++i) { n *= it->second.shape[i]; if (shape_out) shape_out[i] = it->second.shape[i]; }
     EVFLY_REQUIRE(n <= max_elems, "tap '%s' has %lld elements, buffer holds %lld", name, (long long)n, (long long)max_elems);
     EVFLY_HIP(hipStreamSynchronize(as_stream(stream)));
+    if (it->second.bf16) {      // bf16 pipeline: widen on the host
+        std::vector<bf16_t> tmp((size_t)n);
+        EVFLY_HIP(hipMemcpy(tmp.data(), it->second.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) dst_host[i] = host_bf2f(tmp[(size_t)i]);
+        return n;
+    }
     EVFLY_HIP(hipMemcpy(dst_host, it->second.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
     return n;
 }
@@ -1107,6 +1271,12 @@ extern "C" int evfly_model_profile_exec_flops(evfly_model *m, int i, double *exe
     return 0;
 }
 
+extern "C" int evfly_model_profile_useful_flops(evfly_model *m, int i, double *useful_flops_out) {
+    EVFLY_REQUIRE(m && useful_flops_out && i >= 0 && i < (int)m->agg.size(), "profile_useful_flops: index out of range");
+    *useful_flops_out = m->agg[i].useful;
+    return 0;
+}
+
 extern "C" int evfly_model_profile_reset(evfly_model *m) {
     EVFLY_REQUIRE(m, "null handle");
     if (int rc = m->prof_collect()) return rc;
@@ -1137,5 +1307,27 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
         if (int rc = wino_pack_device(w_packed, cout, cin, (int64_t)9 * cin, 1, cin, static_cast<float *>(u), as_stream(stream))) return rc;
         return wino_launch(d, static_cast<const float *>(u), as_stream(stream));
     }
+    return igemm_launch(d, as_stream(stream));
+}
+
+// bf16-pipeline twin: x, res, y are bf16 NHWC (raw bits), cin % 32 == 0; the fp32 weights are rounded to bf16 and laid out
+// for the kernel on the device (scratch slot 2), exactly what evfly_model_finalize does on the host.
+extern "C" int evfly_op_conv2d_nhwc_bf16(const uint16_t *x, int n, int h, int w, int cin, const float *w_packed, const float *bias,
+                                         int cout, int kh, int kw, int stride, int pad, int act, const uint16_t *res, uint16_t *y,
+                                         void *stream) {
+    EVFLY_REQUIRE(x && w_packed && y, "op_conv2d_bf16: null argument");
+    EVFLY_REQUIRE(cin % 32 == 0, "op_conv2d_bf16: cin must be a multiple of 32");
+    ConvDesc d;
+    d.x = reinterpret_cast<const float *>(x); d.ldx = cin; d.NI = n; d.H = h; d.W = w; d.C = cin; d.bias = bias;
+    d.KH = kh; d.KW = kw; d.stride = stride; d.pad = pad;
+    conv_finish(d);
+    const int ld = round_up(d.K, 64);
+    void *scr = nullptr;
+    if (int rc = scratch_get((size_t)cout * ld * 2, &scr, as_stream(stream), 2)) return rc;
+    if (int rc = launch16_repack_w(w_packed, cout, kh * kw, cin, ld, scr, as_stream(stream))) return rc;
+    d.w = static_cast<const float *>(scr); d.ldw = ld;
+    d.Nc = cout; d.res = reinterpret_cast<const float *>(res); d.ldres = cout; d.act = act;
+    d.y = reinterpret_cast<float *>(y); d.ldy = cout; d.dtype = EVFLY_DTYPE_BF16;
+    d.in_bf16 = d.out_bf16 = 1; d.res_bf16 = res != nullptr;
     return igemm_launch(d, as_stream(stream));
 }

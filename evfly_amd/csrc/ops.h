@@ -51,6 +51,26 @@ struct LstmWeights {
 int launch_lstm(const float *xg0 /*(S*T, 512)*/, int n_streams, int T, LstmWeights w, float *h_state, float *c_state,
                 float *vel, hipStream_t st);
 
+// ---- bf16 pipeline (ops16.hip): the same operators on bf16 NHWC activations (void * = bf16 elements), fp32 arithmetic
+int launch16_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff, const float *w_packed,
+                 const float *bias, void *y, hipStream_t st);
+int launch16_maxpool2x2(const void *x, int n, int H, int W, int C, void *y, hipStream_t st);
+int launch16_bilinear(const void *x, int n, int Hi, int Wi, int C, int64_t ldx, void *y, int Ho, int Wo, int64_t ldy, int align_corners,
+                      hipStream_t st);
+int launch16_crop(const void *x, int n, int Hi, int Wi, int C, int top, int left, void *y, int Ho, int Wo, int64_t ldy, hipStream_t st);
+// z, c, h fp32 (state updated in place); h16 = bf16 copy of h (next step's GEMM operand), h_copy = bf16 hseq row
+int launch16_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *h16, void *h_copy, int rpi,
+                            int64_t copy_img_rows, hipStream_t st);
+int launch16_dot_out(const void *x, int64_t rows, int C, const float *w, const float *bias, float *y, hipStream_t st);
+int launch16_layernorm(const void *a, int64_t rows, int C, const float *gamma, const float *beta, void *y, hipStream_t st);
+int launch16_attention(const void *q, const void *kv, int frames, int N, int nkv, int C, int heads, void *out, hipStream_t st);
+int launch16_grouped_conv_gelu(const void *x, int n, int H, int W, int Ce, const float *w, const float *bias, void *y, hipStream_t st);
+int launch16_pixel_shuffle2(const void *x, int n, int H, int W, int C, void *y, int64_t ldy, hipStream_t st);
+int launch16_meta_fill(void *x517, int64_t rows, int ld, const float *desvel, const float *quat, hipStream_t st);
+int launch16_repack_w(const float *w, int cout, int ntaps, int cin, int ld, void *out, hipStream_t st);
+int launch_f32_to_bf16(const float *x, int64_t n, void *y, hipStream_t st);
+int launch_bf16_to_f32(const void *x, int64_t n, float *y, hipStream_t st);
+
 // [cout][tap][cin] -> chunk-major K order of igemm.h conv_k_index (cin % 32 == 0)
 int launch_repack_chunk_major(const float *w, int cout, int ntaps, int cin, float *out, hipStream_t st);
 

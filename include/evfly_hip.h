@@ -153,7 +153,9 @@ typedef struct evfly_model evfly_model;
 #define EVFLY_HEAD_VIT 2        /* ... + ViT (FC head)                learner/vitfly_models.py:152  */
 
 #define EVFLY_DTYPE_F32 0  /* f32-input MFMA, exact fp32 */
-#define EVFLY_DTYPE_BF16 1 /* bf16 MFMA operands, fp32 accumulate / statistics */
+#define EVFLY_DTYPE_BF16 1 /* bf16 pipeline: activations live in HBM as bf16 NHWC, GEMM weights are rounded to bf16 at pack
+                            * time, tiles go HBM -> LDS -> v_mfma_f32_32x32x16_bf16 operands untouched; fp32 accumulate,
+                            * fp32 LayerNorm / softmax / gate statistics, fp32 recurrent state and outputs */
 #define EVFLY_DTYPE_BF16X3 2 /* fp32 operands split x = hi + lo (two bf16), a*w ~ ah*wh + ah*wl + al*wh on the bf16
                               * MFMA, fp32 accumulate: ~2^-16 relative error per product (fp32-grade, not bit-exact) */
 
@@ -283,6 +285,9 @@ int evfly_model_profile_get(evfly_model *m, int i, char *name_out, int name_cap,
 /* Matrix-core flops actually ISSUED by record i (equals flops_out of evfly_model_profile_get for direct GEMMs; the
  * Winograd F(2x2,3x3) kernel issues 16/36 of the algorithmic count, plus its tile padding). */
 int evfly_model_profile_exec_flops(evfly_model *m, int i, double *exec_flops_out);
+/* The part of exec_flops that computes real output tiles: the Winograd kernel pads its last tile row / column and image
+ * group to whole 32-tile blocks, so useful = 16/36 of the algorithmic count < exec; equal to flops_out for direct GEMMs. */
+int evfly_model_profile_useful_flops(evfly_model *m, int i, double *useful_flops_out);
 int evfly_model_profile_reset(evfly_model *m);
 
 /* ------------------------------------------------------------------------------------------
@@ -294,6 +299,13 @@ int evfly_model_profile_reset(evfly_model *m);
 int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin, const float *w_packed,
                          const float *bias, int cout, int kh, int kw, int stride, int pad, int act,
                          const float *res, float *y, int dtype, void *stream);
+
+/* The same operator in the bf16 pipeline (compute_dtype EVFLY_DTYPE_BF16): x, res, y are bf16 NHWC tensors (raw
+ * bits in uint16_t), cin % 32 == 0; w_packed / bias stay fp32 (the weights are rounded to bf16 once, like
+ * evfly_model_finalize does); fp32 accumulation, one rounding of the result. */
+int evfly_op_conv2d_nhwc_bf16(const uint16_t *x, int n, int h, int w, int cin, const float *w_packed,
+                              const float *bias, int cout, int kh, int kw, int stride, int pad, int act,
+                              const uint16_t *res, uint16_t *y, void *stream);
 
 #ifdef __cplusplus
 }

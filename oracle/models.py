@@ -152,6 +152,7 @@ def origunet_forward(sd, x, state=None, *, prefix="", form_BEV=2, evs_min_cutoff
     e = F.max_pool2d(y_e4, 2, 2)
     y_e5 = relu(_conv(sd, P + "unet_e52.", relu(_conv(sd, P + "unet_e51.", e))))    # :541
     taps["y_e5_pre"] = y_e5
+    taps.update(y_e1=y_e1, y_e2=y_e2, y_e3=y_e3, y_e4=y_e4)
     h_unet = None
     if num_recurrent[0] > 0:                                                        # :544-546
         y_e5, h_unet = convlstm_forward(sd, P + "lstm.", y_e5, state)

@@ -29,5 +29,22 @@ def test_committed_bench_line_has_the_contract_fields():
 def test_bench_source_keeps_the_contract_keys():
     src = open(os.path.join(REPO, "bench.py")).read()
     for k in ('"metric"', '"value"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"',
-              '"data"', '"config"', '"roofline"', '"cpu_baseline"', "--gpus", "--steps", "--warmup", "dist.barrier()"):
+              '"data"', '"config"', '"roofline"', '"cpu_baseline"', "--gpus", "--steps", "--warmup", "dist.barrier()",
+              '"frac_useful"', '"frac_algorithmic"', '"step_mfma_util"', '"stage_rates"', '"threads_1"', '"threads_nproc"', "--config",
+              "pin_memory()"):
         assert k in src, k
+
+
+def test_bench_configs_are_the_baseline_configs():
+    """--config C2 / C3 / C4 / C5 = BASELINE.json configs[1..4]; C2 is the default and the headline."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    c = b.CONFIGS
+    assert c["C2"] == dict(streams=64, windows=5, epw=60_000, sensor=(260, 346), vit="tiny", dtype="f32", model="composite")
+    assert c["C3"]["streams"] == 256 and c["C3"]["windows"] == 10 and c["C3"]["sensor"] == (480, 640) and c["C3"]["dtype"] == "bf16" and c["C3"]["vit"] == "base"
+    assert c["C4"]["streams"] == 256 and c["C4"]["windows"] == 5 and c["C4"]["vit"] == "base"
+    assert c["C5"]["windows"] == 16 and c["C5"]["dtype"] == "bf16" and c["C5"]["model"] == "unet"
+    base = json.load(open(os.path.join(REPO, "BASELINE.json")))
+    assert len(base["configs"]) == 5 and "batch=256, 480" in base["configs"][2] and "seq_len=16" in base["configs"][4]

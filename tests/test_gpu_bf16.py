@@ -1,0 +1,188 @@
+"""GPU parity of the bf16 pipeline (compute_dtype "bf16": bf16 NHWC activations in HBM, bf16 weights, fp32 accumulate).
+
+Kernel level: `evfly_op_conv2d_nhwc_bf16` (the GEMM kernel every layer of the pipeline launches) against torch's fp32
+convolution of the SAME bf16-rounded operands -- the only differences left are the fp32 summation order and the one
+rounding of the result, so the bar is one bf16 ulp (2^-8 relative) plus fp32 noise, far tighter than the model-level
+3e-2 against the fp32 oracle. Model level: U-Net / ViT / composite against the oracle, the bf16 bound written in the test.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from evfly_amd import _lib, synthetic as syn
+from oracle import models as om
+
+from _util import cond_frames, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ACT = {0: lambda t: t, 1: torch.relu, 2: lambda t: F.leaky_relu(t, 0.01)}
+
+
+def _bits(t):
+    """fp32 tensor -> (bf16 tensor, its raw bits as int16 tensor on the GPU)."""
+    b = t.to(torch.bfloat16)
+    return b, b.view(torch.int16).cuda().contiguous()
+
+
+def _conv_bf16(n, h, w, cin, cout, k, stride, pad, act, with_res, seed):
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(rs.standard_normal((n, h, w, cin)).astype(np.float32))
+    wt = torch.from_numpy((rs.standard_normal((cout, k, k, cin)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32))
+    bias = torch.from_numpy((0.1 * rs.standard_normal(cout)).astype(np.float32))
+    xb, xbits = _bits(x)
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.from_numpy(rs.standard_normal((n, oh, ow, cout)).astype(np.float32)) if with_res else None
+    rb, rbits = _bits(res) if with_res else (None, None)
+    y = torch.empty(n, oh, ow, cout, dtype=torch.int16, device="cuda")
+    L = _lib.lib()
+    wd = wt.cuda().contiguous()
+    bd = bias.cuda()
+    _lib.check(L.evfly_op_conv2d_nhwc_bf16(_lib.ptr(xbits), n, h, w, cin, _lib.ptr(wd), _lib.ptr(bd), cout, k, k, stride, pad, act,
+                                           _lib.ptr(rbits), _lib.ptr(y), _lib.cur_stream()))
+    got = y.cpu().view(torch.bfloat16).float()
+    # reference: the same rounded operands, fp32 conv on the CPU
+    ref = F.conv2d(xb.float().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float().permute(0, 3, 1, 2), bias, stride=stride, padding=pad)
+    ref = ref.permute(0, 2, 3, 1)
+    if with_res:
+        ref = ref + rb.float()
+    ref = ACT[act](ref)
+    return got, ref
+
+
+def _assert_bf16_close(got, ref):
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 1e-4 * ref.abs().max()        # one bf16 ulp of the value + fp32 summation noise
+    bad = err > bound
+    assert not bad.any(), (int(bad.sum()), float(err.max()), float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, stride, pad, act, res
+    (2, 20, 30, 32, 32, 3, 1, 0, 1, False),      # C = 32: two taps per K-step, 9 halves (the last K-step is half empty); 256x32 tile
+    (3, 18, 22, 32, 64, 3, 1, 0, 1, False),      # 256x64 tile
+    (2, 17, 19, 64, 64, 3, 1, 0, 1, False),
+    (2, 14, 13, 128, 128, 3, 1, 0, 1, False),    # 128x128 tile, M tail
+    (1, 10, 15, 256, 512, 3, 1, 0, 0, False),    # deep layer: long K, few tiles -> split-K
+    (4, 15, 23, 32, 64, 3, 2, 1, 0, False),      # ViT stage-2 patch conv: stride 2, padding 1 (zero-masked taps)
+    (4, 15, 23, 32, 32, 8, 8, 0, 0, False),      # K/V reduction conv 8x8 stride 8 (K = 2048)
+    (4, 8, 12, 64, 64, 4, 4, 0, 0, False),
+    (6, 15, 23, 32, 32, 1, 1, 0, 0, True),       # Linear K = 32 (half a K-step) + residual
+    (6, 15, 23, 256, 32, 1, 1, 0, 0, True),      # MixFFN mlp2 + residual
+    (6, 15, 23, 32, 256, 1, 1, 0, 2, False),     # mlp1, leaky epilogue
+    (5, 1, 1, 544, 512, 1, 1, 0, 0, False),      # K = 544 = 17 halves (the LSTM input projection)
+    (7, 1, 1, 4608, 512, 1, 1, 0, 0, False),     # decoder Linear: few rows, K = 4608 -> split-K
+    (3, 16, 24, 64, 12, 3, 1, 1, 0, False),      # head conv: 12 output channels -> scalar store tail
+    (9, 1, 1, 256, 3, 1, 1, 0, 0, False),        # fc2: 3 outputs
+    (40, 26, 30, 32, 32, 3, 1, 0, 1, False),     # > 8 M tiles: every XCD slot, ragged last tile
+])
+def test_conv_bf16_pipeline_kernel(gpu_device, case):
+    n, h, w, cin, cout, k, stride, pad, act, with_res = case
+    got, ref = _conv_bf16(n, h, w, cin, cout, k, stride, pad, act, with_res, seed=hash(case) & 0xffff)
+    _assert_bf16_close(got, ref)
+
+
+def _unet(dev, **kw):
+    import evfly_amd.learner_models as lm
+    args = dict(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346], velpred=0,
+                form_BEV=2, evs_min_cutoff=0.15, skip_type="interp", logger=lambda *a: None)
+    args.update(kw)
+    net = lm.OrigUNet(**args)
+    sd = syn.fill_state_dict(net.state_dict(), "origunet.")
+    net.load_state_dict(sd)
+    net.set_compute_dtype("bf16")
+    return net.to(dev).eval(), sd
+
+
+TOL = 3e-2      # bf16 pipeline vs the fp32 oracle, max|a - b| / max|b|  (bf16 has 8 significant bits; 22 layers deep)
+
+
+@pytest.mark.parametrize("kw", [dict(skip_type="interp", form_BEV=2), dict(skip_type="crop", form_BEV=0),
+                                dict(skip_type="none", form_BEV=1, num_recurrent=[0, 0])])
+def test_unet_bf16_pipeline_layers(gpu_device, kw):
+    """Per-layer taps of the bf16 pipeline against the fp32 oracle: localises a wrong bf16 kernel (pool, skip resample /
+    crop, transposed conv scatter, gate kernel) instead of letting it hide in the end-to-end bound."""
+    net, sd = _unet(gpu_device, **kw)
+    x = cond_frames(71, 3)
+    _, (depth, up, (st, _)) = net([x.clone().to(gpu_device), None, None])
+    okw = {k: v for k, v in kw.items() if k in ("skip_type", "form_BEV")}
+    if "num_recurrent" in kw:
+        okw["num_recurrent"] = kw["num_recurrent"]
+    (_, taps) = om.origunet_forward(sd, x, None, return_taps=True, **okw)
+    _, (d_ref, up_ref, (st_ref, _)) = om.origunet_forward(sd, x, None, **okw)
+    hh = net.hip()
+    names = [("e1", "y_e1"), ("e2", "y_e2"), ("e3", "y_e3"), ("e4", "y_e4"), ("e5", "y_e5_pre"), ("d1", "y_d1"), ("d2", "y_d2"),
+             ("d3", "y_d3"), ("d4", "y_d4")]
+    if kw.get("num_recurrent", [1, 0])[0] > 0:
+        names.insert(5, ("e5_lstm", "y_e5"))
+    for name, key in names:
+        if key not in taps:
+            continue
+        got = hh.tap(name).permute(0, 3, 1, 2)
+        assert rel_err(got, taps[key]) < TOL, (name, rel_err(got, taps[key]))
+    assert rel_err(up.cpu(), up_ref) < TOL and rel_err(depth.cpu(), d_ref) < TOL
+    if st is not None:
+        assert rel_err(st[0][0].cpu(), st_ref[0][0]) < TOL and rel_err(st[0][1].cpu(), st_ref[0][1]) < TOL
+
+
+def test_unet_bf16_stateful_split_equals_one_call(gpu_device):
+    """ConvLSTM state hand-off in the bf16 pipeline: frames [0..3) then [3..5) with the carried fp32 state against five frames
+    in one call. Same kernels and rounding points (the bf16 copy of h is re-derived from the fp32 state), but the two call
+    shapes pick different split-K factors for the deep layers: fp32 reassociation flips bf16 roundings (one ulp = 2^-8), so
+    the bar is the pipeline's own bound, not the fp32 pipeline's 1e-5."""
+    net, _ = _unet(gpu_device)
+    x = cond_frames(72, 5).to(gpu_device)
+    _, (_, up_all, (st_all, _)) = net([x.clone(), None, None])
+    _, (_, up_a, (st_a, _)) = net([x[:3].clone(), None, None])
+    _, (_, up_b, (st_b, _)) = net([x[3:].clone(), None, (st_a, None)])
+    assert rel_err(torch.cat([up_a, up_b]).cpu(), up_all.cpu()) < TOL
+    assert rel_err(st_b[0][1].cpu(), st_all[0][1].cpu()) < TOL
+    # ... and bit-identical when the call shape is the same
+    _, (_, up_b2, _) = net([x[3:].clone(), None, (st_a, None)])
+    assert torch.equal(up_b, up_b2)
+
+
+@pytest.mark.parametrize("trunk", ["tiny", "base"])
+def test_vit_bf16_pipeline(gpu_device, trunk):
+    import evfly_amd.vitfly_models as vm
+    cfg = vm.TINY if trunk == "tiny" else vm.BASE
+    om.use_trunk(heads=cfg["heads"], layers=cfg["layers"], reductions=cfg["reductions"])
+    try:
+        for cls, fwd in ((vm.LSTMNetVIT, om.lstmnetvit_forward), (vm.ViT, om.vit_forward)):
+            net = cls(**cfg)
+            prefix = "vitfly_vitlstm." if cls is vm.LSTMNetVIT else "vit."
+            sd = syn.fill_state_dict(net.state_dict(), prefix)
+            net.load_state_dict(sd)
+            net.set_compute_dtype("bf16")
+            net = net.to(gpu_device).eval()
+            rs = np.random.RandomState(5)
+            img = torch.from_numpy(rs.rand(4, 1, 60, 90).astype(np.float32))
+            desvel = torch.full((4, 1), 4.0)
+            v, h = net([img.to(gpu_device), desvel.to(gpu_device), None])
+            out = fwd(sd, [img, desvel, None])
+            assert rel_err(v.cpu(), out[0]) < TOL, (cls.__name__, rel_err(v.cpu(), out[0]))
+            # stage taps
+            hh = net.hip()
+            for name in ("s1", "s2"):
+                t = hh.tap(name)
+                assert torch.isfinite(t).all() and t.abs().max() > 0
+    finally:
+        om.use_trunk()
+
+
+def test_mix_stage_bf16_standalone_entry(gpu_device):
+    """evfly_vit_stage_forward keeps its fp32 ABI in the bf16 pipeline (input rounded / output widened inside)."""
+    import evfly_amd.ViTsubmodules as vs
+    stage = vs.MixTransformerEncoderLayer(32, 64, patch_size=3, stride=2, padding=1, n_layers=2, reduction_ratio=4, num_heads=2,
+                                          expansion_factor=8)
+    sd = syn.fill_state_dict(stage.state_dict(), "vitfly_vitlstm.encoder_blocks.1.")
+    stage.load_state_dict(sd)
+    rs = np.random.RandomState(6)
+    x = torch.from_numpy(rs.standard_normal((2, 32, 15, 23)).astype(np.float32))
+    y32 = stage.to(gpu_device).eval()(x.to(gpu_device)).cpu()
+    stage.set_compute_dtype("bf16")
+    y16 = stage(x.to(gpu_device)).cpu()
+    assert y16.shape == y32.shape and rel_err(y16, y32) < TOL

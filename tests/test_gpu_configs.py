@@ -80,3 +80,51 @@ def test_c5_convlstm_seq16(gpu_device, dtype, tol):
     _, (d_ref, up_ref, (st_ref, _)) = om.origunet_forward(sd, x, None)
     assert rel_err(up.cpu(), up_ref) < tol and rel_err(depth.cpu(), d_ref) < tol
     assert rel_err(st[0][0].cpu(), st_ref[0][0]) < tol and rel_err(st[0][1].cpu(), st_ref[0][1]) < tol
+
+
+def test_c4_shard_256_streams_vit_base(gpu_device, base_trunk):
+    """One GPU's shard of BASELINE config C4: 256 streams x 5 windows through `forward_streams` with the ViT-base trunk
+    (1280 frames: four passes of the 320-frame chunker, state hand-off per stream), fp32. Checked against the oracle on
+    three sampled streams (first chunk, a middle one, the last stream) and for run-to-run bit repeatability."""
+    import evfly_amd.learner_models as lm
+    from evfly_amd import voxelizer
+    S, T = 256, 5
+    net = lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
+                                       input_shape=[1, 1, 260, 346], velpred=0, form_BEV=2, evs_min_cutoff=0.15,
+                                       skip_type="interp", logger=lambda *a: None, vit_trunk=base_trunk)
+    sd = syn.fill_state_dict(net.state_dict())
+    net.load_state_dict(sd)
+    net = net.to(gpu_device).eval()
+    raw = torch.from_numpy(syn.make_frames(4242, S * T)).reshape(S * T, 260, 346)
+    x = voxelizer.condition_frames(raw.to(gpu_device))                      # (S*T, 1, 260, 346), q97-conditioned on the device
+    desvel = torch.full((S * T, 1), 4.0)
+    v, (d, up, ((h_unet, _), (lh, lc))) = net.forward_streams([x, desvel.to(gpu_device), [None, None], None], S, T)
+    assert v.shape == (S * T, 3) and d.shape == (S * T, 1, 260, 346) and lh.shape == (S, 3, 128)
+    assert h_unet[0][0].shape == (S, 512, 8, 13) and torch.isfinite(v).all()
+    xc = x.cpu()
+    for s in (0, 131, 255):
+        rows = slice(s * T, (s + 1) * T)
+        v_ref, d_ref = om.composite_streams(sd, xc[rows], desvel[rows], 1, T)
+        assert rel_err(v[rows].cpu(), v_ref) < 1e-4 and rel_err(d[rows].cpu(), d_ref) < 1e-4, s
+    v2, (d2, _, _) = net.forward_streams([x, desvel.to(gpu_device), [None, None], None], S, T)
+    assert torch.equal(v, v2) and torch.equal(d, d2)
+
+
+def test_bench_child_process_rccl_path_on_one_gpu(tmp_path):
+    """`bench.py` as the driver launches it, in a CHILD process, with the RCCL path forced on one GPU
+    (EVFLY_BENCH_FORCE_DIST=1: init_process_group("nccl"), barrier, all_gather of the velocity rows, MAX all_reduce of the
+    time): the JSON line must come out complete. Covers the N > 1 code path on the hardware a 1-GPU box has."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVFLY_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt",
+                        "--no-stage-rates", "--streams", "16"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    b = json.loads(line)
+    assert b["n_gpus"] == 1 and b["steps"] == 2 and b["unit"] == "event-frames/s" and b["value"] > 0
+    assert abs(b["value"] - 16 * 5 * 1e3 / b["ms_per_step"]) < 1e-2 * b["value"] and "roofline" in b
