@@ -75,6 +75,9 @@ SIGNATURES = {
     "evfly_model_profile_reset": (c_i, [c_p]),
     "evfly_op_conv2d_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
                                    c_p, c_p, c_i, c_p]),
+    "evfly_op_pool2d_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "evfly_op_velpred_vec": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    "evfly_op_convlstm_gates": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p]),
     "evfly_op_conv2d_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
                                         c_p, c_p, c_p]),
 }

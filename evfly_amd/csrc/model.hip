@@ -1293,14 +1293,15 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
     d.x = x; d.ldx = cin; d.NI = n; d.H = h; d.W = w; d.C = cin; d.w = w_packed; d.bias = bias;
     d.KH = kh; d.KW = kw; d.stride = stride; d.pad = pad;
     conv_finish(d);
-    EVFLY_REQUIRE(d.K % 32 == 0, "op_conv2d: kh*kw*cin must be a multiple of 32 (weights are [cout][kh][kw][cin] unpadded)");
-    if (cin % 32 == 0 && kh * kw > 1) {   // the kernel walks K chunk-major (igemm.h conv_k_index): permute a copy
+    // the kernel walks K in the order of igemm.h conv_k_index, zero padded to a multiple of 32: lay a copy out like that
+    const int ld = round_up(d.K, 32);
+    {
         void *scr = nullptr;
-        if (int rc = scratch_get((size_t)cout * d.K * 4, &scr, as_stream(stream))) return rc;
-        if (int rc = launch_repack_chunk_major(w_packed, cout, kh * kw, cin, static_cast<float *>(scr), as_stream(stream))) return rc;
+        if (int rc = scratch_get((size_t)cout * ld * 4, &scr, as_stream(stream))) return rc;
+        if (int rc = launch_repack_w(w_packed, cout, kh * kw, cin, ld, static_cast<float *>(scr), as_stream(stream))) return rc;
         d.w = static_cast<const float *>(scr);
     }
-    d.ldw = d.K; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
+    d.ldw = ld; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
     if (wino_applicable(d) && !(getenv("EVFLY_WINO_OP") && atoi(getenv("EVFLY_WINO_OP")) == 0)) {
         void *u = nullptr;
         if (int rc = scratch_get(wino_u_floats(cout, cin) * 4, &u, as_stream(stream), 2)) return rc;
@@ -1330,4 +1331,23 @@ extern "C" int evfly_op_conv2d_nhwc_bf16(const uint16_t *x, int n, int h, int w,
     d.y = reinterpret_cast<float *>(y); d.ldy = cout; d.dtype = EVFLY_DTYPE_BF16;
     d.in_bf16 = d.out_bf16 = 1; d.res_bf16 = res != nullptr;
     return igemm_launch(d, as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------- small stateless operators
+// (the kernels the model handles launch, exposed for the stand-alone forwards of the reference's helper modules)
+extern "C" int evfly_op_pool2d_nhwc(const float *x, int n, int h, int w, int c, int k, int stride, int type, int negate, float *y, void *stream) {
+    EVFLY_REQUIRE(x && y && n > 0 && c > 0, "op_pool2d: null or empty argument");
+    EVFLY_REQUIRE(type == EVFLY_POOL_MAX || type == EVFLY_POOL_AVG, "op_pool2d: type must be EVFLY_POOL_MAX or EVFLY_POOL_AVG");
+    return launch_pool2d(x, n, h, w, c, k, stride, type, negate, y, as_stream(stream));
+}
+
+extern "C" int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, float *vel, void *stream) {
+    EVFLY_REQUIRE(y && vel && rows > 0, "op_velpred_vec: null or empty argument");
+    EVFLY_REQUIRE(num_out == 1 || num_out == 2, "op_velpred_vec: num_out must be 1 or 2 (3 is the identity)");
+    return num_out == 1 ? launch_velpred_vec(y, rows, 1, vel, as_stream(stream)) : launch_velpred_vec2(y, rows, 2, vel, as_stream(stream));
+}
+
+extern "C" int evfly_op_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *stream) {
+    EVFLY_REQUIRE(z && c && h && rows > 0 && hid > 0, "op_convlstm_gates: null or empty argument");
+    return launch_convlstm_gates(z, rows, hid, c, h, nullptr, 1, 0, as_stream(stream));
 }

@@ -13,6 +13,10 @@ int launch_maxpool2x2(const float *x, int n, int H, int W, int C, float *y, hipS
 int launch_pool2d(const float *x, int n, int H, int W, int C, int k, int s, int type, int negate, float *y, hipStream_t st);
 // VelPredictor tail for num_out == 1 (learner_models.py:326-336): vel = [sqrt(clip(1 - y*y, 0, 1)), y, 0]
 int launch_velpred_vec(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st);
+// num_out == 2 (:312-321): vel = [sqrt(clip(1 - y0^2 - y1^2, 0, 1)), y0, y1]
+int launch_velpred_vec2(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st);
+// [cout][tap][cin] -> [cout][ld] in the kernel's K order (igemm.h conv_k_index), zero padded (any cin)
+int launch_repack_w(const float *w, int cout, int ntaps, int cin, int ld, float *out, hipStream_t st);
 // bilinear resize (F.interpolate / nn.Upsample); y pixel stride ldy, written at channel offset 0 of y.
 // pre: 0 none, 1 clip(2*v, 0, 1) applied to every source sample (learner_models.py:634)
 // excl_h x excl_w > 0: skip the output pixels whose four taps lie inside one excl_h x excl_w region of the source grid

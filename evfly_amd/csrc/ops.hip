@@ -131,6 +131,35 @@ __global__ __launch_bounds__(256) void k_velpred_vec(const float *__restrict__ y
     vel[r * 3 + 2] = 0.f;
 }
 
+// VelPredictor tail for num_out == 2 (learner_models.py:312-321): vel = [sqrt(clip(1 - y0^2 - y1^2, 0, 1)), y0, y1]
+__global__ __launch_bounds__(256) void k_velpred_vec2(const float *__restrict__ y, int64_t rows, int64_t ldy,
+                                                      float *__restrict__ vel) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float a = y[r * ldy], b = y[r * ldy + 1];
+    float rad = 1.0f - (a * a + b * b);                 // torch.pow(x, 2).sum(dim=1): a^2 + b^2, then 1 - sum
+    rad = rad < 0.f ? 0.f : (rad > 1.f ? 1.f : rad);
+    vel[r * 3 + 0] = sqrtf(rad);
+    vel[r * 3 + 1] = a;
+    vel[r * 3 + 2] = b;
+}
+
+// [cout][tap][cin] fp32 -> [cout][ld] in the K order of igemm.h conv_k_index (chunk-major when cin % 32 == 0, tap-major
+// otherwise), zero padded to ld: what evfly_model_finalize does on the host, for the stateless operator entry points
+__global__ __launch_bounds__(256) void k_repack_w(const float *__restrict__ w, int cout, int ntaps, int cin, int ld, float *__restrict__ out) {
+    const int K = ntaps * cin;
+    const int64_t total = (int64_t)cout * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int o = (int)(i / ld), k = (int)(i - (int64_t)o * ld);
+        float v = 0.f;
+        if (k < K) {
+            if (cin % 32 == 0) { const int q = k >> 5, cl = k & 31, cc = q / ntaps, tap = q - cc * ntaps; v = w[(int64_t)o * K + (int64_t)tap * cin + cc * 32 + cl]; }
+            else v = w[(int64_t)o * K + k];
+        }
+        out[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bilinear
 // ATen upsample_bilinear2d (aten/src/ATen/native/UpSample.h area_pixel_compute_* + cpu/UpSampleKernel.cpp):
 // fp32 scale, source index, lambdas (bilinear_src_index, common.h); result = wh0*(ww0*v00 + ww1*v01) + wh1*(ww0*v10 + ww1*v11).
@@ -557,6 +586,18 @@ int launch_pool2d(const float *x, int n, int H, int W, int C, int k, int s, int 
 
 int launch_velpred_vec(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st) {
     hipLaunchKernelGGL(k_velpred_vec, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, y, rows, ldy, vel);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_velpred_vec2(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st) {
+    hipLaunchKernelGGL(k_velpred_vec2, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, y, rows, ldy, vel);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_repack_w(const float *w, int cout, int ntaps, int cin, int ld, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_repack_w, dim3(grid_for((int64_t)cout * ld, 256)), dim3(256), 0, st, w, cout, ntaps, cin, ld, out);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

@@ -76,8 +76,9 @@ __global__ void k_window_ranges(const int64_t *__restrict__ t, const int64_t *__
 //   GENERAL = false: time-sorted stream and <= 65535 events in the window: the window is the
 //     contiguous range [starts[w], starts[w+1]); only x, y, p are read (5 B / event); P and N
 //     are 16-bit halves of one LDS word.
-//   GENERAL = true: any order / any count: the whole stream is scanned with the int64 time test
-//     of to_events.py:405-406; P and N are separate 32-bit LDS words.
+//   GENERAL = true: any order / any count; P and N are separate 32-bit LDS words. Unsorted streams are scanned whole
+//     with the int64 time test of to_events.py:405-406; sorted windows with more than 65535 events take their
+//     contiguous range like the fast path.
 // ------------------------------------------------------------------------------------------
 struct VoxArgs {
     const uint16_t *x, *y;
@@ -114,7 +115,11 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
     const bool fast_ok = sorted && (s1 - s0) <= kFastMax;
     if (GENERAL == fast_ok) return;  // the other instantiation owns this frame
     int64_t e0 = 0, e1 = 0;
-    if (GENERAL) {
+    // GENERAL blocks own two kinds of frames: unsorted streams (scan the whole stream with the time test) and sorted
+    // windows with more than 65535 events (480x640 sensors at 200 k events / window): the contiguous range like the fast
+    // path, only the counters are 32 bits wide. Block-uniform choice.
+    const bool timed = GENERAL && !sorted;
+    if (timed) {
         lo = a.offs[b]; hi = a.offs[b + 1];
         e0 = a.edges[b * (a.T + 1) + w]; e1 = a.edges[b * (a.T + 1) + w + 1];
     } else {
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
             // np.histogram2d: the right-most edge is inclusive (x == W counts in column W-1)
             const int cx = min((int)ex, a.W - 1), cy = min((int)ey, a.H - 1);
             bool ok = (i >= lo) && (i < hi) && (int)ex <= a.W && (int)ey <= a.H && cy >= r0 && cy < r1;
-            if (GENERAL && ok) {
+            if (GENERAL && timed && ok) {
                 const int64_t tt = a.t[i];
                 ok = (tt >= e0) && (tt < e1);
             }

@@ -47,3 +47,31 @@ def form_eventframe(view_events, H, W, times0=None, times1=None, N=None, device=
             raise IndexError("index -1 is out of bounds for axis 0 with size 0")   # view_events_timed[-1,0], :133
         times1 = (lt + 1) / 1e9                                                # :133
     return out, times1
+
+
+def simple_evim(evframe, scaledown_percentile=100, style='gray'):
+    """Display image of an event frame (utils/ev_utils.py:14-78; evfly_ros/run.py:321 publishes it for debugging):
+    optional scale-down by a percentile of |frame| + clip to [-1, 1], then 'gray' (min-max to 0..255, encoding '8UC1'),
+    'redblue-on-black' or 'redblue-on-white' (positive = red, negative = blue; 'rgb8'). Returns (uint8 image, encoding).
+    Visualisation only: host numpy on a frame that is already on its way to a ROS image message -- not part of the
+    event -> depth -> velocity path and not measured."""
+    if isinstance(evframe, torch.Tensor):
+        evframe = evframe.cpu().detach().numpy()
+    if not isinstance(evframe, np.ndarray):
+        raise ValueError("[simple_evim] evframe must be a numpy array or a torch tensor")
+    f = evframe
+    if scaledown_percentile is not None:
+        pct = scaledown_percentile * 100.0 if scaledown_percentile <= 1 else scaledown_percentile
+        f = np.clip(evframe / np.percentile(np.abs(evframe), pct), -1.0, 1.0)
+    if style == 'gray':
+        lo, hi = np.min(f), np.max(f)
+        return (255 * (f - lo) / (hi - lo)).astype(np.uint8), '8UC1'
+    if style not in ('redblue-on-black', 'redblue-on-white'):
+        raise ValueError("[simple_evim] style not recognized")
+    pos = np.where(f > 0, f, 0.0)                      # magnitudes of the two polarities (one of them is 0 at every pixel)
+    neg = np.where(f < 0, -f, 0.0)
+    if style == 'redblue-on-black':
+        rgb = np.stack([255 * pos, np.zeros_like(pos), 255 * neg], axis=-1)
+    else:
+        rgb = np.stack([255 - 255 * neg, 255 - 255 * (pos + neg), 255 - 255 * pos], axis=-1)
+    return rgb.astype(np.uint8), 'rgb8'

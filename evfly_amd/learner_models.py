@@ -21,16 +21,23 @@ _SKIP = {"crop": 0, "interp": 1, "none": 2}
 _ACTS = {'relu': nn.ReLU, 'sigmoid': nn.Sigmoid, 'tanh': nn.Tanh, 'leaky_relu': nn.LeakyReLU}
 
 
-def _never_run(name):
-    def forward(self, *a, **k):
-        raise NotImplementedError(f"{name} is a parameter container; it runs inside OrigUNet's native forward "
-                                  f"(evfly_unet_forward, include/evfly_hip.h). There is no CPU path.")
-    return forward
+def _op_conv(x, w_packed, bias, k, stride, act):
+    """act(conv2d(x NHWC, w_packed [cout][k][k][cin], stride, no padding) + bias) through evfly_op_conv2d_nhwc (fp32)."""
+    L = _lib.lib()
+    n, h, w, cin = x.shape
+    cout = w_packed.shape[0]
+    y = torch.empty(n, (h - k) // stride + 1, (w - k) // stride + 1, cout, device=x.device, dtype=torch.float32)
+    _lib.check(L.evfly_op_conv2d_nhwc(_lib.ptr(x), n, h, w, cin, _lib.ptr(w_packed), _lib.ptr(bias), cout, k, k, stride, 0, act, None,
+                                      _lib.ptr(y), 0, _lib.cur_stream()))
+    return y
 
 
 class InvertLayer(nn.Module):
-    """learner/learner_models.py:14-16."""
-    forward = _never_run("InvertLayer")
+    """learner/learner_models.py:14-16: x -> -x. Inside DynamicConvNet the negation rides on the pool kernel; called on
+    its own it is a sign flip of the tensor (no arithmetic to offload)."""
+
+    def forward(self, x):
+        return -x
 
 
 class DynamicConvNet(nn.Module):
@@ -102,7 +109,29 @@ class DynamicConvNet(nn.Module):
                 raise ValueError(f'[DynamicConvNet] layer {i} shrinks the input to nothing')
         return c, h, w
 
-    forward = _never_run("DynamicConvNet")
+    def forward(self, x):
+        """learner_models.py:97-98 `self.layers(x)`: x (N, C, H, W) -> (N, C', H', W'), eval mode (BatchNorm2d running
+        statistics folded into the bias-free conv: w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps),
+        what evfly_model_finalize does for the head inside OrigUNet). Native: evfly_op_conv2d_nhwc + evfly_op_pool2d_nhwc."""
+        L = _lib.lib()
+        sp = self.spec
+        dev = x.device
+        cur = to_gpu(x).permute(0, 2, 3, 1).contiguous()                  # NHWC
+        for i in range(sp['num_layers']):
+            conv, bn = getattr(self.layers, f'conv2d_{i}'), getattr(self.layers, f'batchnorm_{i}')
+            sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().to("cuda", torch.float32)
+            wp = (conv.weight.detach().to("cuda", torch.float32) * sc[:, None, None, None]).permute(0, 2, 3, 1).contiguous()
+            bp = (bn.bias.detach().to("cuda", torch.float32) - bn.running_mean.detach().to("cuda", torch.float32) * sc).contiguous()
+            cur = _op_conv(cur, wp, bp, sp['kernel_sizes'][i], sp['kernel_strides'][i], _lib.ACT_CODES[sp['activations'][i]])
+            pool = sp['pool_type'] != 'none'
+            if pool or sp['invert']:                                       # one InvertLayer survives, in front of the pool (:77-92)
+                n, h, w, c = cur.shape
+                k, st = (sp['pool_kernels'][i], sp['pool_strides'][i]) if pool else (1, 1)
+                out = torch.empty(n, (h - k) // st + 1, (w - k) // st + 1, c, device="cuda", dtype=torch.float32)
+                _lib.check(L.evfly_op_pool2d_nhwc(_lib.ptr(cur), n, h, w, c, k, st, _lib.POOL_CODES[sp['pool_type']] if pool else 1,
+                                                  int(sp['invert']), _lib.ptr(out), _lib.cur_stream()))
+                cur = out
+        return cur.permute(0, 3, 1, 2).contiguous().to(dev)
 
 
 class DynamicFCNet(nn.Module):
@@ -128,7 +157,16 @@ class DynamicFCNet(nn.Module):
         mylogger(f'[DynamicFCNet] Initialized DynamicFCNet with input_features={input_features}, '
                  f'num_layers={num_layers}, layer_sizes={layer_sizes}, activations={activations}, dropout_p={dropout_p}')
 
-    forward = _never_run("DynamicFCNet")
+    def forward(self, x):
+        """learner_models.py:144-145 `self.layers(x)`: x (N, F) -> (N, layer_sizes[-1]); Dropout is the identity in eval.
+        Native: one evfly_op_conv2d_nhwc (1x1, H = W = 1) per Linear with the activation in its epilogue."""
+        dev = x.device
+        cur = to_gpu(x).reshape(x.shape[0], 1, 1, -1).contiguous()
+        for i in range(self.spec['num_layers']):
+            fc = getattr(self.layers, f'fc_{i}')
+            wp = fc.weight.detach().to("cuda", torch.float32).reshape(fc.out_features, 1, 1, fc.in_features).contiguous()
+            cur = _op_conv(cur, wp, fc.bias.detach().to("cuda", torch.float32).contiguous(), 1, 1, _lib.ACT_CODES[self.spec['activations'][i]])
+        return cur.reshape(x.shape[0], -1).to(dev)
 
 
 class VelPredictor(nn.Module):
@@ -148,7 +186,22 @@ class VelPredictor(nn.Module):
                                   layer_sizes=fc_params['layer_sizes'], activations=fc_params['activations'],
                                   dropout_p=fc_params['dropout_p'], logger=logger, device=device)
 
-    forward = _never_run("VelPredictor")
+    def forward(self, X):
+        """learner_models.py:309-336: X = [features, ...]; flatten -> fcnet -> unit-vector completion for num_out 1 / 2.
+        Returns (vel, None)."""
+        x = torch.flatten(X[0], 1)
+        dev = x.device
+        y = self.fcnet(x)
+        if self.num_out in (1, 2):
+            L = _lib.lib()
+            yg = to_gpu(y)
+            if self.num_out == 2 and bool(((yg * yg).sum(dim=1) > 1).any()) or self.num_out == 1 and bool((yg.abs() > 1).any()):
+                self.mylogger('[VelPredictor] Warning: radicand contains negatives when computing first element of '
+                              f'{"3-vector from 2-vector" if self.num_out == 2 else "2-vector from 1-vector"}.')
+            vel = torch.empty(yg.shape[0], 3, device="cuda", dtype=torch.float32)
+            _lib.check(L.evfly_op_velpred_vec(_lib.ptr(yg), yg.shape[0], self.num_out, _lib.ptr(vel), _lib.cur_stream()))
+            y = vel.to(dev)
+        return y, None
 
 
 class OrigUNet(HipModule):

@@ -294,11 +294,26 @@ int evfly_model_profile_reset(evfly_model *m);
  * Single-operator entry points (kernel-level parity tests; same kernels the models launch)
  * ---------------------------------------------------------------------------------------- */
 
-/* y[N,OH,OW,Cout] = act(conv2d(x[N,H,W,Cin], w) + bias (+ res)); w_packed is [Cout][KH][KW][Cin].
- * act: 0 none, 1 relu, 2 leaky_relu(0.01). dtype EVFLY_DTYPE_*. */
+/* y[N,OH,OW,Cout] = act(conv2d(x[N,H,W,Cin], w) + bias (+ res)); w_packed is [Cout][KH][KW][Cin] (any Cin; a Linear
+ * layer is the 1x1 case with H = W = 1). act: EVFLY_ACT_*. dtype EVFLY_DTYPE_* (fp32 tensors in every mode).
+ * Replaces nn.Conv2d / nn.Linear (+ activation) wherever the reference's helper modules call them on their own:
+ * DynamicConvNet / DynamicFCNet learner/learner_models.py:18-145, ConvLSTMCell learner/ConvLSTM_pytorch/convlstm.py:38-43. */
 int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin, const float *w_packed,
                          const float *bias, int cout, int kh, int kw, int stride, int pad, int act,
                          const float *res, float *y, int dtype, void *stream);
+
+/* nn.MaxPool2d / nn.AvgPool2d(k, stride) of DynamicConvNet (learner/learner_models.py:81-84), floor mode, no padding, NHWC;
+ * negate != 0 pools -x (the InvertLayer that survives in front of the pool, :77-92). type EVFLY_POOL_MAX / _AVG. */
+int evfly_op_pool2d_nhwc(const float *x, int n, int h, int w, int c, int k, int stride, int type, int negate,
+                         float *y, void *stream);
+
+/* Tail of VelPredictor.forward learner/learner_models.py:309-334 for num_out 1 / 2 (3 is the identity):
+ * y (rows, num_out) -> vel (rows, 3) = [sqrt(clip(1 - y^2, 0, 1)), y, 0]  /  [sqrt(clip(1 - y0^2 - y1^2, 0, 1)), y0, y1]. */
+int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, float *vel, void *stream);
+
+/* ConvLSTMCell gate arithmetic learner/ConvLSTM_pytorch/convlstm.py:44-51: z (rows, 4*hid) = [i | f | o | g]
+ * pre-activations of conv(cat[x, h]); c, h (rows, hid) updated in place (c = f*c + i*g, h = o*tanh(c)). */
+int evfly_op_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *stream);
 
 /* The same operator in the bf16 pipeline (compute_dtype EVFLY_DTYPE_BF16): x, res, y are bf16 NHWC tensors (raw
  * bits in uint16_t), cin % 32 == 0; w_packed / bias stay fp32 (the weights are rounded to bf16 once, like

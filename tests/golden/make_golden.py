@@ -465,6 +465,20 @@ def g13():
     save("g13_dataloader", **out)
 
 
+# ------------------------------------------------------------------ G14: simple_evim display images (run.py:321)
+def g14():
+    f = syn.make_frames(140, 2)[:, 0, :40, :50].astype(np.float64)
+    f[1, :3, :3] = 0
+    out = {}
+    for i, fr in enumerate(f):
+        for pct in (100, 97, 0.9, None):
+            for st in ("gray", "redblue-on-black", "redblue-on-white"):
+                im, enc = ref_ev.simple_evim(fr, pct, st)
+                out[f"{i}_{pct}_{st}"] = im
+                out[f"{i}_{pct}_{st}_enc"] = np.array(enc)
+    save("g14_simple_evim", **out)
+
+
 # ------------------------------------------------------------------ G0: state-dict key inventory
 def g0():
     import json
@@ -484,7 +498,7 @@ def g0():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     with torch.no_grad():
         for g in which:
             globals()[g]()

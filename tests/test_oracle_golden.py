@@ -323,3 +323,17 @@ def test_composite_stateful():
     assert rel_err(v3, g["vel_batch"]) < TOL
     vs, _ = om.composite_streams(sd, x, desvel.repeat(3, 1), 1, 3)
     assert rel_err(vs, g["vel_batch"]) < TOL
+
+
+def test_g14_simple_evim_display_images():
+    """`ev_utils.simple_evim` (host visualisation helper imported by run.py:24) against the reference's own images."""
+    import numpy as np
+    from evfly_amd import ev_utils, synthetic as syn
+    g = golden("g14_simple_evim")
+    f = syn.make_frames(140, 2)[:, 0, :40, :50].astype(np.float64)
+    f[1, :3, :3] = 0
+    for i, fr in enumerate(f):
+        for pct in (100, 97, 0.9, None):
+            for st in ("gray", "redblue-on-black", "redblue-on-white"):
+                im, enc = ev_utils.simple_evim(fr, pct, st)
+                assert enc == str(g[f"{i}_{pct}_{st}_enc"]) and np.array_equal(im, g[f"{i}_{pct}_{st}"]), (i, pct, st)
