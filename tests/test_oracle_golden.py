@@ -248,7 +248,7 @@ def test_velpred_shell_errors():
     bad = {**case, "enc_params": {**case["enc_params"], "conv_function": "upconv2d"}}
     with pytest.raises(NotImplementedError):
         lm.OrigUNet(num_recurrent=[1, 0], **base, **bad)
-    with pytest.raises(NotImplementedError):       # the containers never compute on the CPU
+    with pytest.raises(RuntimeError, match="no CPU fallback"):       # stand-alone forwards are native: never on the CPU
         lm.DynamicFCNet(4, 1, [1], ["tanh"], logger=lambda *a: None)(torch.zeros(1, 4))
 
 
