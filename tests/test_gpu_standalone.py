@@ -39,7 +39,8 @@ def test_convlstm_forward_vs_golden_g6(gpu_device):
     # stateful split 10 + 6 continues identically (convlstm.py:142-149)
     o_a, st_a = net(x[:, :10].to(gpu_device), None)
     o_b, st_b = net(x[:, 10:].to(gpu_device), st_a)
-    assert torch.equal(o_b[0][0][-1].cpu(), o[-1]) and torch.equal(st_b[0][1].cpu(), st[0][1].cpu())
+    # (the 16-, 10- and 6-frame input GEMMs pick different split-K factors: fp32 reassociation only)
+    assert rel_err(o_b[0][0][-1].cpu(), o[-1]) < 1e-5 and rel_err(st_b[0][1].cpu(), st[0][1].cpu()) < 1e-5
     # time-major input (batch_first=False) is the same sequence
     net.batch_first = False
     outs_tm, _ = net(x.permute(1, 0, 2, 3, 4).to(gpu_device), None)
