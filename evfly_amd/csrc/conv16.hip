@@ -1,0 +1,373 @@
+// Direct 3x3 valid convolution of the bf16 pipeline for the shallow U-Net layers (C_in = 32 or 64, C_out a multiple
+// of 32), gfx950. The implicit GEMM of igemm16.hip re-reads every input pixel nine times from L2 (one im2col row per
+// tap): at C_in = 32 the L2 -> LDS stream, not the matrix pipe, set its pace (e12: 231 TFLOP/s). Here a block stages the
+// (TH + 2) x 34 input patch of a TH x 32 output tile ONCE per 32-channel chunk and takes all nine taps from LDS.
+//
+// Persistent blocks (one per CU, 512 threads = 8 waves): a block owns one slice of NTB * 32 output channels, keeps that
+// slice's weights resident in LDS for its whole life and walks over output tiles; patches are double-buffered, the patch
+// of step s + 1 (next chunk or next tile) arrives by LDS-DMA while step s computes. The DMA is issued from inline asm
+// (`buffer_load_dwordx4 ... lds`, out-of-range lanes read zeros) and counted by hand -- hipcc would put a vmcnt(0) in front
+// of every ds_read that follows a DMA it knows about, which serialises exactly the overlap this structure exists for.
+//
+// MFMA roles are swapped against the GEMM kernels: A = weights (32 output channels x 16 k), B = pixels (16 k x 32
+// pixels of one output row), so D[channel][pixel] leaves every lane with ONE pixel's channels {0-3, 8-11, 16-19, 24-27}
+// (+4 for lanes 32-63). One v_permlane32_swap per packed dword pair turns that into 8 adjacent channels per lane: bias,
+// ReLU, bf16 rounding and 16-B NHWC stores straight from the accumulators -- no LDS transpose, no epilogue barrier.
+// nn.MaxPool2d(2, 2) fuses for free: a wave owns two adjacent output rows (vertical max in registers) and the horizontal
+// neighbour is the next lane (one DPP-style shuffle per value).
+// LDS patch: 64 B per pixel (32 channels), its four 16-B chunks XOR-swizzled with (pixel >> 2) & 3: the 16 lanes of a
+// ds_read_b128 group read 16 consecutive pixels (mod 16) of one row = 16 distinct 16-B slots. Weights sit in the exact
+// order the waves consume them: [chunk][tap][k-half][n-tile][lane][8 bf16], packed on the host (conv16_pack_host).
+#include "igemm.h"
+
+#include <algorithm>
+#include <atomic>
+
+#include "bf16.h"
+
+namespace evfly {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int TW = 32;             // output pixels per tile row = one MFMA pixel tile
+constexpr int PWD = TW + 2;        // patch width
+constexpr int NWAVE = 8;
+
+struct Conv16Geom {
+    int tiles_x, tiles_y, n_tiles;     // per image; n_tiles = NI * tiles_y * tiles_x
+    int n_slices;                      // output-channel slices of NTB * 32
+    int blocks_per_slice;
+    unsigned u_tx, u_ty;               // magic divisors for tiles_x, tiles_y
+    float *y_pool;
+};
+
+__device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+}
+
+// swizzled byte offset of 16-B chunk c of patch pixel q (64 B per pixel)
+__device__ __forceinline__ int patch_off(int q, int c) { return q * 64 + ((c ^ ((q >> 2) & 3)) << 4); }
+
+// ROWS: output rows per wave (tile height = 8 * ROWS); NTB: 32-channel output tiles per block slice; POOL: also write the
+// 2x2 max pool (ROWS == 2 only)
+template <int ROWS, int NTB, bool POOL>
+__global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const bf16_t *__restrict__ wd) {
+    constexpr int TH = NWAVE * ROWS, PH = TH + 2, NPIX = PH * PWD;
+    constexpr int NPIECE = (NPIX * 64 + 1023) / 1024;          // 1-KiB DMA pieces per patch
+    constexpr int PPW = (NPIECE + NWAVE - 1) / NWAVE;           // pieces per wave
+    constexpr int PATCH_BYTES = NPIECE * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
+    // LDS: [patch buffer 0][patch buffer 1][weights of the slice: nchunks * 18 * NTB KiB]
+    const int nchunks = d.C >> 5;
+    unsigned char *wl = smem + 2 * PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.x / g.blocks_per_slice, bis = blockIdx.x - slice * g.blocks_per_slice;
+    const int n0 = slice * NTB * 32;
+
+    // ---- weights of this slice -> LDS (linear copy, 1 KiB per wave-instruction)
+    {
+        const int wbytes = nchunks * 18 * NTB * 1024;
+        const uint64_t wbase = (uint64_t)(uintptr_t)wd + (uint64_t)slice * wbytes;
+        i32x4 srd = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xffff), wbytes, 0x00020000};
+        srd[0] = __builtin_amdgcn_readfirstlane(srd[0]); srd[1] = __builtin_amdgcn_readfirstlane(srd[1]);
+        srd[2] = __builtin_amdgcn_readfirstlane(srd[2]);
+        const unsigned wl0 = lds0 + 2 * PATCH_BYTES;
+        for (int pc = wv; pc * 1024 < wbytes; pc += NWAVE)
+            dma16((unsigned)(pc * 1024 + lane * 16), srd, __builtin_amdgcn_readfirstlane(wl0 + (unsigned)pc * 1024u));
+    }
+
+    // ---- per-lane patch geometry of this wave's DMA pieces: piece p covers patch pixels 16 p .. 16 p + 15; lane l holds
+    // slot l & 3 of pixel 16 p + (l >> 2), i.e. logical chunk (l & 3) ^ ((pixel >> 2) & 3)
+    unsigned poff[PPW];        // byte offset of the lane's 16 B relative to the tile's patch origin (row pitch known), per piece
+    unsigned prc[PPW];         // patch row | col << 8  (0xffff: beyond the patch)
+    const unsigned rowb = (unsigned)d.W * (unsigned)d.ldx * 2u;      // bytes per input row
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wv + i * NWAVE;
+        const int q = pc * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((q >> 2) & 3);
+        const int pr = q / PWD, pcx = q - pr * PWD;
+        const bool in = pc < NPIECE && q < NPIX;
+        poff[i] = in ? (unsigned)pr * rowb + (unsigned)pcx * (unsigned)d.ldx * 2u + (unsigned)c * 16u : 0x7ffffff0u;
+        prc[i] = in ? ((unsigned)pr | ((unsigned)pcx << 8)) : 0xffffu;
+    }
+
+    // ---- work list of this block: tiles bis, bis + blocks_per_slice, ...; a step = (tile, chunk)
+    auto tile_decode = [&](int t, int &img, int &ty, int &tx) {
+        const int rowq = g.tiles_x == 1 ? t : (int)__umulhi((unsigned)t, g.u_tx);
+        tx = t - rowq * g.tiles_x;
+        img = g.tiles_y == 1 ? rowq : (int)__umulhi((unsigned)rowq, g.u_ty);
+        ty = rowq - img * g.tiles_y;
+    };
+    auto issue_patch = [&](int t, int cc, int buf) {
+        int img, ty, tx;
+        tile_decode(t, img, ty, tx);
+        const int iy0 = ty * TH, ix0 = tx * TW;
+        const uint64_t xb = (uint64_t)(uintptr_t)d.x + ((uint64_t)(unsigned)img * (unsigned)d.H + (unsigned)iy0) * rowb + (uint64_t)(unsigned)ix0 * (unsigned)d.ldx * 2u +
+                            (uint64_t)cc * 64u;
+        i32x4 srd;
+        srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        srd[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffff));
+        srd[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)PH * rowb));      // the patch rows of this image region
+        srd[3] = 0x00020000;
+        const int hrem = d.H - iy0, wrem = d.W - ix0;
+        const bool interior = PH <= hrem && PWD <= wrem;                            // wave-uniform
+        const unsigned dst = lds0 + (unsigned)buf * PATCH_BYTES;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wv + i * NWAVE;
+            if (pc < NPIECE) {
+                unsigned vo = poff[i];
+                if (!interior) vo = ((int)(prc[i] & 0xffu) < hrem && (int)(prc[i] >> 8) < wrem) ? vo : 0x7ffffff0u;
+                dma16(vo, srd, __builtin_amdgcn_readfirstlane(dst + (unsigned)pc * 1024u));
+            }
+        }
+    };
+
+    const int n_my = bis < g.n_tiles ? (g.n_tiles - bis + g.blocks_per_slice - 1) / g.blocks_per_slice : 0;
+    const int n_steps = n_my * nchunks;
+    if (n_steps > 0) issue_patch(bis, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // bias of this lane's channels: n = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float bv[NTB][16];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            bv[j][r] = (d.bias && n < d.Nc) ? d.bias[n] : 0.f;
+        }
+
+    const int fj = lane & 31, fh = lane >> 5;
+    f32x16 acc[ROWS][NTB];
+    int t_cur = bis, cc = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        // the next step's patch flies under this step's MFMAs
+        {
+            int t_nx = t_cur, c_nx = cc + 1;
+            if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
+            if (s + 1 < n_steps) issue_patch(t_nx, c_nx, (s + 1) & 1);
+        }
+        const unsigned char *pb = smem + (s & 1) * PATCH_BYTES;
+        const unsigned char *wc = wl + (size_t)cc * 18 * NTB * 1024;
+        if (cc == 0) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int j = 0; j < NTB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 px[ROWS], wf[NTB];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int q = (wv * ROWS + r + ky) * PWD + fj + kx;
+                    px[r] = *reinterpret_cast<const bf16x8 *>(pb + patch_off(q, kb * 2 + fh));
+                }
+#pragma unroll
+                for (int j = 0; j < NTB; ++j)
+                    wf[j] = *reinterpret_cast<const bf16x8 *>(wc + ((t * 2 + kb) * NTB + j) * 1024 + lane * 16);
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], px[r], acc[r][j], 0, 0, 0);
+            }
+        }
+        if (cc == nchunks - 1) {
+            // ---- epilogue of the tile: straight from the accumulators
+            int img, ty, tx;
+            tile_decode(t_cur, img, ty, tx);
+            const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
+            const bool col_ok = ox < d.OW;
+            bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
+            unsigned pk[ROWS][NTB][8];           // packed bf16 pairs: [r-group 0..3][dword 0..1]
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int j = 0; j < NTB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        float v0 = acc[r][j][e] + bv[j][e], v1 = acc[r][j][e + 1] + bv[j][e + 1];
+                        if (d.act == ACT_RELU) { v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; }
+                        else if (d.act != ACT_NONE) { v0 = apply_act(v0, d.act); v1 = apply_act(v1, d.act); }
+                        pk[r][j][e >> 1] = pack_bf2(v0, v1);
+                    }
+            // lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: after the swaps lane l
+            // owns channels 0-7 and 16-23, lane l + 32 channels 8-15 and 24-31 (16 B each)
+            auto store_rows = [&](const unsigned (&p)[8], bf16_t *dst_px, bool ok, int nbase, int ncount) {
+                unsigned o[8];
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp)          // quads (0, 1) and (2, 3)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(p[(2 * grp) * 2 + w], p[(2 * grp + 1) * 2 + w], false, false);
+                        o[grp * 4 + w] = sw[0];          // lanes < 32: own quad 2 grp       | lanes >= 32: partner's quad 2 grp + 1
+                        o[grp * 4 + 2 + w] = sw[1];      // lanes < 32: partner's quad 2 grp | lanes >= 32: own quad 2 grp + 1
+                    }
+                if (!ok) return;
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) {
+                    const int ch = grp * 16 + fh * 8;     // first of this lane's 8 channels inside the 32-channel tile
+                    if (nbase + ch < ncount)
+                        *reinterpret_cast<uint4 *>(dst_px + nbase + ch) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int oy = oy0 + r;
+                const bool ok = col_ok && oy < d.OH;
+                bf16_t *dst_px = y16 + (((int64_t)img * d.OH + (ok ? oy : 0)) * d.OW + (ok ? ox : 0)) * d.ldy;
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) store_rows(pk[r][j], dst_px, ok, n0 + j * 32, d.Nc);
+            }
+            if (POOL && ROWS == 2) {
+                // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes.
+                // The max of bf16-rounded values is the rounded max (rounding is monotonic): pool the packed results.
+                bf16_t *yp = reinterpret_cast<bf16_t *>(g.y_pool);
+                const int PHo = d.OH / 2, PWo = d.OW / 2;
+                const int py = oy0 >> 1, pxo = ox >> 1;
+                const bool pok = (fj & 1) == 0 && py < PHo && pxo < PWo;
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) {
+                    unsigned pm[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned a = pk[0][j][e], b = pk[ROWS - 1][j][e];
+                        float lo = fmaxf(bf_lo(a), bf_lo(b)), hi = fmaxf(bf_hi(a), bf_hi(b));       // ReLU outputs: no NaN ordering issue beyond fmaxf's
+                        // NaN-propagating like torch: fmaxf drops NaN, put it back
+                        lo = (bf_lo(a) != bf_lo(a)) ? bf_lo(a) : (bf_lo(b) != bf_lo(b)) ? bf_lo(b) : lo;
+                        hi = (bf_hi(a) != bf_hi(a)) ? bf_hi(a) : (bf_hi(b) != bf_hi(b)) ? bf_hi(b) : hi;
+                        const float lo2 = __shfl_xor(lo, 1), hi2 = __shfl_xor(hi, 1);
+                        float ml = fmaxf(lo, lo2), mh = fmaxf(hi, hi2);
+                        ml = (lo != lo) ? lo : (lo2 != lo2) ? lo2 : ml;
+                        mh = (hi != hi) ? hi : (hi2 != hi2) ? hi2 : mh;
+                        pm[e] = pack_bf2(ml, mh);
+                    }
+                    bf16_t *dst_px = yp + (((int64_t)img * PHo + (pok ? py : 0)) * PWo + (pok ? pxo : 0)) * d.Nc;
+                    store_rows(pm, dst_px, pok, n0 + j * 32, d.Nc);
+                }
+            }
+        }
+        // the next patch has landed (this wave's pieces) and every wave is done reading this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (++cc == nchunks) { cc = 0; t_cur += g.blocks_per_slice; }
+    }
+}
+
+template <int ROWS, int NTB, bool POOL>
+int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
+    constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
+    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024;
+    auto kern = k_conv16<ROWS, NTB, POOL>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    EVFLY_REQUIRE(lds <= kMaxLds, "conv16: %d B of LDS", lds);
+    hipLaunchKernelGGL(kern, dim3(g.n_slices * g.blocks_per_slice), dim3(512), lds, st, d, g, wd);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// weights (O, I, 3, 3) fp32 -> bf16 in consumption order: [slice][chunk][tap][k-half kb][n-tile j][lane = half * 32 + n][8]
+// with value W[slice * ntb * 32 + j * 32 + n][chunk * 32 + kb * 16 + half * 8 + e][tap]; output channels padded with zeros
+size_t conv16_weight_elems(int cout, int cin, int ntb) { return (size_t)((cout + ntb * 32 - 1) / (ntb * 32)) * (cin / 32) * 18 * ntb * 512; }
+int conv16_ntb(int cout) { return cout % 64 == 0 ? 2 : 1; }
+bool conv16_applicable(const ConvDesc &d) {
+    static const bool off = getenv("EVFLY_NO_CONV16") != nullptr;
+    return !off && d.in_bf16 && d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 &&
+           (d.C == 32 || d.C == 64) && d.Nc % 32 == 0 && !d.res && d.out_mode == OUT_ROWS && d.ldx % 8 == 0 && d.ldy % 8 == 0 &&
+           ((uintptr_t)d.x) % 16 == 0 && ((uintptr_t)d.y) % 16 == 0 && d.OW >= 1 && d.OH >= 1 &&
+           (int64_t)(d.H) * d.W * d.ldx * 2 < ((int64_t)1 << 31);
+}
+void conv16_pack_host(const float *w_oihw, int cout, int cin, bf16_t *out) {
+    const int ntb = conv16_ntb(cout), nsl = (cout + ntb * 32 - 1) / (ntb * 32), ncc = cin / 32;
+    for (int sl = 0; sl < nsl; ++sl)
+        for (int cc = 0; cc < ncc; ++cc)
+            for (int t = 0; t < 9; ++t)
+                for (int kb = 0; kb < 2; ++kb)
+                    for (int j = 0; j < ntb; ++j)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int n = sl * ntb * 32 + j * 32 + (l & 31), c = cc * 32 + kb * 16 + (l >> 5) * 8 + e;
+                                const float v = n < cout ? w_oihw[((size_t)n * cin + c) * 9 + t] : 0.f;
+                                out[((((((size_t)sl * ncc + cc) * 9 + t) * 2 + kb) * ntb + j) * 64 + l) * 8 + e] = host_f2bf(v);
+                            }
+}
+
+namespace {
+// device twin of conv16_pack_host for the stateless operator entry point: w is [cout][tap][cin] fp32 (evfly_op_conv2d layout)
+__global__ __launch_bounds__(256) void k16_pack_wd(const float *__restrict__ w, int cout, int cin, int ntb, bf16_t *__restrict__ out, int64_t total) {
+    const int ncc = cin / 32;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i;
+        const int e = (int)(r & 7); r >>= 3;
+        const int l = (int)(r & 63); r >>= 6;
+        const int j = (int)(r % ntb); r /= ntb;
+        const int kb = (int)(r & 1); r >>= 1;
+        const int t = (int)(r % 9); r /= 9;
+        const int cc = (int)(r % ncc);
+        const int sl = (int)(r / ncc);
+        const int n = sl * ntb * 32 + j * 32 + (l & 31), c = cc * 32 + kb * 16 + (l >> 5) * 8 + e;
+        out[i] = f2bf_dev(n < cout ? w[((int64_t)n * 9 + t) * cin + c] : 0.f);
+    }
+}
+}  // namespace
+
+int conv16_pack_device(const float *w_otc, int cout, int cin, void *out, hipStream_t st) {
+    const int ntb = conv16_ntb(cout);
+    const int64_t total = (int64_t)conv16_weight_elems(cout, cin, ntb);
+    hipLaunchKernelGGL(k16_pack_wd, dim3((unsigned)std::min<int64_t>(2048, (total + 255) / 256)), dim3(256), 0, st, w_otc, cout, cin, ntb,
+                       static_cast<bf16_t *>(out), total);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+// y_pool: optional bf16 (NI, OH / 2, OW / 2, Nc) 2x2 max pool of the activated output
+int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t st) {
+    EVFLY_REQUIRE(conv16_applicable(d), "conv16: layer not eligible");
+    const int ntb = conv16_ntb(d.Nc);
+    // tile height: 16 rows (two per wave; needed for the fused pool) unless 8-row tiles waste fewer rows
+    const bool pool = y_pool != nullptr;
+    const int waste16 = cdiv(d.OH, 16) * 16 - d.OH, waste8 = cdiv(d.OH, 8) * 8 - d.OH;
+    const int rows = (pool || waste16 <= waste8 + 2) ? 2 : 1;
+    EVFLY_REQUIRE(!pool || (d.OH % 2 == 0 || true), "conv16: pool");
+    Conv16Geom g{};
+    const int TH = 8 * rows;
+    g.tiles_x = cdiv(d.OW, TW); g.tiles_y = cdiv(d.OH, TH);
+    g.n_tiles = d.NI * g.tiles_y * g.tiles_x;
+    g.n_slices = cdiv(d.Nc, ntb * 32);
+    g.blocks_per_slice = std::max(1, std::min(g.n_tiles, kNumCU / g.n_slices));
+    auto magic32 = [](int x) -> unsigned { return x <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)x + 1); };
+    g.u_tx = magic32(g.tiles_x); g.u_ty = magic32(g.tiles_y);
+    EVFLY_REQUIRE((int64_t)g.n_tiles < (1 << 24), "conv16: too many tiles");
+    g.y_pool = y_pool;
+    const bf16_t *w = static_cast<const bf16_t *>(wd);
+    if (rows == 2) {
+        if (ntb == 2) return pool ? launch16d<2, 2, true>(d, g, w, st) : launch16d<2, 2, false>(d, g, w, st);
+        return pool ? launch16d<2, 1, true>(d, g, w, st) : launch16d<2, 1, false>(d, g, w, st);
+    }
+    return ntb == 2 ? launch16d<1, 2, false>(d, g, w, st) : launch16d<1, 1, false>(d, g, w, st);
+}
+
+}  // namespace evfly

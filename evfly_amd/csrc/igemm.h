@@ -94,6 +94,16 @@ int igemm_launch(const ConvDesc &d, hipStream_t st);
 // bf16 pipeline kernel (igemm16.hip): d.in_bf16 set, bf16 x / w, C % 32 == 0, ldw % 64 == 0. igemm_launch routes to it.
 int igemm16_launch(const ConvDesc &d, hipStream_t st);
 
+// Direct 3x3 convolution of the bf16 pipeline for the shallow layers (conv16.hip): C in {32, 64}, stride 1, no padding,
+// bf16 in / out, weights in the kernel's own order (conv16_pack_host / conv16_pack_device: conv16_weight_elems bf16
+// elements); optional fused 2x2 max pool (bf16, (NI, OH / 2, OW / 2, Nc)).
+bool conv16_applicable(const ConvDesc &d);
+int conv16_ntb(int cout);
+size_t conv16_weight_elems(int cout, int cin, int ntb);
+void conv16_pack_host(const float *w_oihw, int cout, int cin, unsigned short *out);
+int conv16_pack_device(const float *w_otc, int cout, int cin, void *out, hipStream_t st);
+int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t st);
+
 // >= 256 B of zeros in global memory on the current device (source of masked LDS-DMA rows)
 int igemm_zero_page(const float **out);
 

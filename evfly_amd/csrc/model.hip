@@ -284,6 +284,13 @@ int pack_unet(evfly_model *m) {
     const bool w16 = m->act16;
     for (const char *n : convs) {
         if (int rc = pack_conv(m, kUnetP, std::string("unet_") + n, n, true, false, w16)) return rc;
+        if (w16) {   // bf16 pipeline, shallow layers: the direct-convolution kernel's weight stream (conv16.hip)
+            const HostTensor *tw = m->find(std::string("unet_") + n + ".weight", kUnetP);
+            if (tw && (tw->shape[1] == 32 || tw->shape[1] == 64) && tw->shape[0] % 32 == 0) {
+                const int O = (int)tw->shape[0], I = (int)tw->shape[1];
+                conv16_pack_host(tw->v.data(), O, I, m->stage16(std::string(n) + ".wd", conv16_weight_elems(O, I, conv16_ntb(O))));
+            }
+        }
         // Winograd F(2x2,3x3) weights U = G g G^T in the streamed layout of wino.hip (exact-fp32 path only)
         const HostTensor *t = m->find(std::string("unet_") + n + ".weight", kUnetP);
         if (c.compute_dtype == EVFLY_DTYPE_F32 && t && t->shape[1] % 32 == 0) {
@@ -474,6 +481,12 @@ int pack_vit(evfly_model *m) {
             if (int rc = pack_linear(m, kVitP, F + "mlp1", NL + "mlp1", true, nullptr, w16)) return rc;
             if (int rc = pack_vec(m, kVitP, F + "depthwise.weight", NL + "dw.w")) return rc;
             if (int rc = pack_vec(m, kVitP, F + "depthwise.bias", NL + "dw.b")) return rc;
+            {   // the same weights laid out per group for the scalar-operand kernel (gconv.hip)
+                const HostTensor *dwt = m->find(F + "depthwise.weight", kVitP);
+                EVFLY_REQUIRE(dwt && dwt->shape.size() == 4 && dwt->shape[1] == 8 && dwt->shape[2] == 3 && dwt->shape[3] == 3 && dwt->shape[0] % 8 == 0,
+                              "%sdepthwise.weight: expected (Ce, 8, 3, 3)", F.c_str());
+                gconv_pack_host(dwt->v.data(), (int)dwt->shape[0], m->stage(NL + "dw.wp", dwt->v.size()));
+            }
             if (int rc = pack_linear(m, kVitP, F + "mlp2", NL + "mlp2", true, nullptr, w16)) return rc;
             if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".weight", NL + "ln.g")) return rc;
             if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".bias", NL + "ln.beta")) return rc;
@@ -579,6 +592,11 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
         return 0;
     }
     EVFLY_REQUIRE(!d.pre_frames, "the fused first conv needs the Winograd path");
+    if (f16 == IO16 && m->has(wname + ".wd") && (m->planning || conv16_applicable(d))) {   // bf16 pipeline, C_in <= 64: direct conv from an LDS patch
+        if (pool_fused) *pool_fused = y_pool != nullptr;
+        RUN(m, pn.c_str(), igemm_flops(d), bytes + (y_pool ? 0.5 * d.M * cout : 0.0), conv16_launch(d, m->W(wname + ".wd"), y_pool, m->st));
+        return 0;
+    }
     if (pool_fused) *pool_fused = false;
     RUN(m, pn.c_str(), igemm_flops(d), bytes, igemm_launch(d, m->st));
     return 0;
@@ -916,7 +934,11 @@ static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W,
         float *h1 = m->alloc_act(rows * E);
         if (int rc = linear(m, "vit_linear", NL + "mlp1", x1, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E, io)) return rc;
         float *h2 = m->alloc_act(rows * E);
-        if (a16) RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 2 * eb * rows * E,
+        static const bool old_gconv = getenv("EVFLY_OLD_GCONV") != nullptr;      // A/B switch: the round-2 kernels
+        if (gconv_fits(h, w, E) && !old_gconv)
+            RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 2 * eb * rows * E,
+                launch_gconv_gelu(h1, n, h, w, E, m->W(NL + "dw.wp"), m->W(NL + "dw.b"), h2, a16, st));
+        else if (a16) RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 2 * eb * rows * E,
                      launch16_grouped_conv_gelu(h1, n, h, w, E, m->W(NL + "dw.w"), m->W(NL + "dw.b"), h2, st));
         else
         RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 8.0 * rows * E,
@@ -1330,6 +1352,12 @@ extern "C" int evfly_op_conv2d_nhwc_bf16(const uint16_t *x, int n, int h, int w,
     d.Nc = cout; d.res = reinterpret_cast<const float *>(res); d.ldres = cout; d.act = act;
     d.y = reinterpret_cast<float *>(y); d.ldy = cout; d.dtype = EVFLY_DTYPE_BF16;
     d.in_bf16 = d.out_bf16 = 1; d.res_bf16 = res != nullptr;
+    if (conv16_applicable(d)) {     // the shallow 3x3 layers of the pipeline run the direct-convolution kernel
+        void *wdp = nullptr;
+        if (int rc = scratch_get(conv16_weight_elems(cout, cin, conv16_ntb(cout)) * 2, &wdp, as_stream(stream), 1)) return rc;
+        if (int rc = conv16_pack_device(w_packed, cout, cin, wdp, as_stream(stream))) return rc;
+        return conv16_launch(d, wdp, nullptr, as_stream(stream));
+    }
     return igemm_launch(d, as_stream(stream));
 }
 

@@ -41,6 +41,11 @@ int launch_attention(const float *q, const float *kv, int frames, int N, int nkv
 // MixFFN middle: grouped 3x3 'same' conv (groups = Ce/8, 8 in / 8 out per group) + bias + erf-GELU
 int launch_grouped_conv_gelu(const float *x, int n, int H, int W, int Ce, const float *w /*[Ce][8][3][3]*/,
                              const float *bias, float *y, hipStream_t st);
+// gconv.hip: the same operator with a wave per group and the group's weights as scalar operands (fp32 or bf16 activations);
+// wp = gconv_pack_host(depthwise.weight): [Ce / 8][9 taps][8 co][8 ci]. gconv_fits: the frame's padded slab fits the LDS tile.
+bool gconv_fits(int H, int W, int Ce);
+void gconv_pack_host(const float *w, int Ce, float *out);
+int launch_gconv_gelu(const void *x, int n, int H, int W, int Ce, const float *wp, const float *bias, void *y, bool bf16, hipStream_t st);
 int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st);
 // x517 assembly (vitfly_models.py:144): cols [512] = desvel/10, [513..516] = quat (or 1,0,0,0), rest of the pad 0
 int launch_meta_fill(float *x517, int64_t rows, int ld, const float *desvel, const float *quat, hipStream_t st);

@@ -78,6 +78,13 @@ def _assert_bf16_close(got, ref):
     (3, 16, 24, 64, 12, 3, 1, 1, 0, False),      # head conv: 12 output channels -> scalar store tail
     (9, 1, 1, 256, 3, 1, 1, 0, 0, False),        # fc2: 3 outputs
     (40, 26, 30, 32, 32, 3, 1, 0, 1, False),     # > 8 M tiles: every XCD slot, ragged last tile
+    # direct-convolution kernel of the shallow layers (conv16.hip): several tiles per row / column with ragged right and bottom
+    # edges, 16- and 8-row tiles, one and two 32-channel output tiles per block, three output slices, two input chunks
+    (2, 40, 75, 64, 64, 3, 1, 0, 1, False),
+    (3, 21, 37, 32, 96, 3, 1, 0, 0, False),
+    (5, 12, 70, 64, 32, 3, 1, 0, 1, False),
+    (300, 10, 36, 32, 32, 3, 1, 0, 1, False),    # more tiles than persistent blocks: every block walks several tiles
+    (2, 72, 152, 64, 32, 3, 1, 0, 1, False),     # d41's geometry
 ])
 def test_conv_bf16_pipeline_kernel(gpu_device, case):
     n, h, w, cin, cout, k, stride, pad, act, with_res = case
