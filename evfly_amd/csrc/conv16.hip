@@ -54,9 +54,14 @@ __device__ __forceinline__ int patch_off(int q, int c) { return q * 64 + ((c ^ (
 
 // ROWS: output rows per wave (tile height = 8 * ROWS); NTB: 32-channel output tiles per block slice; POOL: also write the
 // 2x2 max pool (ROWS == 2 only)
-template <int ROWS, int NTB, bool POOL>
+// PRE: the input patch is not DMA'd but PRODUCED: pixel (y, x) of it is relu(conv3x3(form(frame))[y][x]) of the FIRST U-Net conv
+// (learner_models.py:476-494,533; C_in = 32, one frame channel), computed by the VALU from a staged frame patch while
+// the matrix cores work on the previous tile -- the 32-channel e11 map (11 MB per frame in fp32, 5.7 MB in bf16) never
+// exists in HBM. Same fmaf order as k16_e11 and the same single bf16 rounding: bitwise the unfused result.
+template <int ROWS, int NTB, bool POOL, bool PRE>
 __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const bf16_t *__restrict__ wd) {
     constexpr int TH = NWAVE * ROWS, PH = TH + 2, NPIX = PH * PWD;
+    constexpr int FH = PH + 2, FW = PWD + 2, FPIX = FH * FW;           // PRE: frame patch behind the weights, double-buffered
     constexpr int NPIECE = (NPIX * 64 + 1023) / 1024;          // 1-KiB DMA pieces per patch
     constexpr int PPW = (NPIECE + NWAVE - 1) / NWAVE;           // pieces per wave
     constexpr int PATCH_BYTES = NPIECE * 1024;
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     // LDS: [patch buffer 0][patch buffer 1][weights of the slice: nchunks * 18 * NTB KiB]
     const int nchunks = d.C >> 5;
     unsigned char *wl = smem + 2 * PATCH_BYTES;
+    float *fbuf = reinterpret_cast<float *>(wl + (size_t)nchunks * 18 * NTB * 1024);      // PRE: [2][FPIX] formed frame patches
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slice = blockIdx.x / g.blocks_per_slice, bis = blockIdx.x - slice * g.blocks_per_slice;
@@ -130,9 +136,74 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         }
     };
 
+    // ---- PRE: frame patch staging (global fp32 -> formed value -> LDS) and patch production
+    auto stage_frame = [&](int t, int fb) {
+        int img, ty, tx;
+        tile_decode(t, img, ty, tx);
+        const int fy0 = ty * TH, fx0 = tx * TW;                        // the frame is (H + 2) x (W + 2): frame pixel = e11 pixel + tap
+        float *f = fbuf + fb * FPIX;
+        for (int i = tid; i < FPIX; i += 512) {
+            const int fy = i / FW, fx = i - fy * FW;
+            const int gy = fy0 + fy, gx = fx0 + fx;
+            float v = (gy < d.H + 2 && gx < d.W + 2) ? d.pre_frames[((int64_t)img * (d.H + 2) + gy) * (d.W + 2) + gx] : 0.f;
+            if (d.pre_apply_form) {                                     // learner_models.py:476-494 (ops16.hip form_value16)
+                if (fabsf(v) < d.pre_cutoff) v = 0.0f;
+                if (d.pre_form_bev == 2) v = v != 0.0f ? 1.0f : 0.0f;
+                else if (d.pre_form_bev == 1) v = fabsf(v);
+                else v = v > 0.0f ? v : 0.0f;
+            }
+            f[i] = v;
+        }
+    };
+    // thread = (patch pixel tid >> 2 (+ 128 per pass), 8-channel group tid & 3): its 9 x 8 weights and 8 biases live in registers
+    float pw[PRE ? 72 : 1], pbias[PRE ? 8 : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) pw[t * 8 + c] = d.pre_w[t * 32 + (tid & 3) * 8 + c];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pbias[c] = d.pre_b[(tid & 3) * 8 + c];
+    }
+    auto produce_patch = [&](int t, int fb, int buf) {
+        int img, ty, tx;
+        tile_decode(t, img, ty, tx);
+        const int iy0 = ty * TH, ix0 = tx * TW;
+        const float *f = fbuf + fb * FPIX;
+        unsigned char *dstb = smem + buf * PATCH_BYTES;
+        const int grp = tid & 3;
+        for (int q = tid >> 2; q < NPIX; q += 128) {
+            const int pr = q / PWD, pcx = q - pr * PWD;
+            float a[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = pbias[c];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = f[(pr + ky) * FW + pcx + kx];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a[c] = fmaf(v, pw[(ky * 3 + kx) * 8 + c], a[c]);
+                }
+            const bool in = iy0 + pr < d.H && ix0 + pcx < d.W;           // beyond the (virtual) e11 map: zeros
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = in ? (a[c] < 0.f ? 0.f : a[c]) : 0.f;
+            *reinterpret_cast<uint4 *>(dstb + patch_off(q, grp)) = make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(a[4], a[5]), pack_bf2(a[6], a[7]));
+        }
+    };
+
     const int n_my = bis < g.n_tiles ? (g.n_tiles - bis + g.blocks_per_slice - 1) / g.blocks_per_slice : 0;
     const int n_steps = n_my * nchunks;
-    if (n_steps > 0) issue_patch(bis, 0, 0);
+    if constexpr (PRE) {
+        // pipeline: step s stages the frame patch of step s + 2, produces the patch of step s + 1, multiplies step s
+        if (n_steps > 0) stage_frame(bis, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (n_steps > 0) produce_patch(bis, 0, 0);
+        if (n_steps > 1) stage_frame(bis + g.blocks_per_slice, 1);
+    } else {
+        if (n_steps > 0) issue_patch(bis, 0, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -150,8 +221,16 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     f32x16 acc[ROWS][NTB];
     int t_cur = bis, cc = 0;
     for (int s = 0; s < n_steps; ++s) {
-        // the next step's patch flies under this step's MFMAs
-        {
+        // the next step's patch flies (DMA) or is computed (PRE) under this step's MFMAs
+        // PRE: every thread owns a share of the next patch / frame patch; even waves do theirs before their MFMAs, odd waves
+        // behind them, so the two waves of a SIMD keep its VALU and its matrix pipe busy at the same time
+        auto next_work = [&]() {
+            if (s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
+            if (s + 2 < n_steps) stage_frame(t_cur + 2 * g.blocks_per_slice, s & 1);
+        };
+        if constexpr (PRE) {
+            if ((wv & 1) == 0) next_work();
+        } else {
             int t_nx = t_cur, c_nx = cc + 1;
             if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
             if (s + 1 < n_steps) issue_patch(t_nx, c_nx, (s + 1) & 1);
@@ -261,6 +340,9 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                 }
             }
         }
+        if constexpr (PRE) {
+            if ((wv & 1) == 1) next_work();
+        }
         // the next patch has landed (this wave's pieces) and every wave is done reading this one
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -268,11 +350,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     }
 }
 
-template <int ROWS, int NTB, bool POOL>
+template <int ROWS, int NTB, bool POOL, bool PRE>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
-    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024;
-    auto kern = k_conv16<ROWS, NTB, POOL>;
+    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0);
+    auto kern = k_conv16<ROWS, NTB, POOL, PRE>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
@@ -297,7 +379,7 @@ bool conv16_applicable(const ConvDesc &d) {
     static const bool off = getenv("EVFLY_NO_CONV16") != nullptr;
     return !off && d.in_bf16 && d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 &&
            (d.C == 32 || d.C == 64) && d.Nc % 32 == 0 && !d.res && d.out_mode == OUT_ROWS && d.ldx % 8 == 0 && d.ldy % 8 == 0 &&
-           ((uintptr_t)d.x) % 16 == 0 && ((uintptr_t)d.y) % 16 == 0 && d.OW >= 1 && d.OH >= 1 &&
+           (d.pre_frames || ((uintptr_t)d.x) % 16 == 0) && ((uintptr_t)d.y) % 16 == 0 && d.OW >= 1 && d.OH >= 1 &&
            (int64_t)(d.H) * d.W * d.ldx * 2 < ((int64_t)1 << 31);
 }
 void conv16_pack_host(const float *w_oihw, int cout, int cin, bf16_t *out) {
@@ -350,7 +432,7 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
     // tile height: 16 rows (two per wave; needed for the fused pool) unless 8-row tiles waste fewer rows
     const bool pool = y_pool != nullptr;
     const int waste16 = cdiv(d.OH, 16) * 16 - d.OH, waste8 = cdiv(d.OH, 8) * 8 - d.OH;
-    const int rows = (pool || waste16 <= waste8 + 2) ? 2 : 1;
+    const int rows = (pool || d.pre_frames || waste16 <= waste8 + 2) ? 2 : 1;
     EVFLY_REQUIRE(!pool || (d.OH % 2 == 0 || true), "conv16: pool");
     Conv16Geom g{};
     const int TH = 8 * rows;
@@ -363,11 +445,16 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
     EVFLY_REQUIRE((int64_t)g.n_tiles < (1 << 24), "conv16: too many tiles");
     g.y_pool = y_pool;
     const bf16_t *w = static_cast<const bf16_t *>(wd);
-    if (rows == 2) {
-        if (ntb == 2) return pool ? launch16d<2, 2, true>(d, g, w, st) : launch16d<2, 2, false>(d, g, w, st);
-        return pool ? launch16d<2, 1, true>(d, g, w, st) : launch16d<2, 1, false>(d, g, w, st);
+    if (d.pre_frames) {     // fused first conv: C_in = 32, one frame channel, 16-row tiles, one output tile per block
+        EVFLY_REQUIRE(d.C == 32 && d.pre_cin == 1 && d.pre_w && d.pre_b && ntb == 1 && rows == 2, "conv16: the fused first-conv producer needs C_in = 32, "
+                      "one frame channel and C_out = 32");
+        return pool ? launch16d<2, 1, true, true>(d, g, w, st) : launch16d<2, 1, false, true>(d, g, w, st);
     }
-    return ntb == 2 ? launch16d<1, 2, false>(d, g, w, st) : launch16d<1, 1, false>(d, g, w, st);
+    if (rows == 2) {
+        if (ntb == 2) return pool ? launch16d<2, 2, true, false>(d, g, w, st) : launch16d<2, 2, false, false>(d, g, w, st);
+        return pool ? launch16d<2, 1, true, false>(d, g, w, st) : launch16d<2, 1, false, false>(d, g, w, st);
+    }
+    return ntb == 2 ? launch16d<1, 2, false, false>(d, g, w, st) : launch16d<1, 1, false, false>(d, g, w, st);
 }
 
 }  // namespace evfly

@@ -591,12 +591,12 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;
     }
-    EVFLY_REQUIRE(!d.pre_frames, "the fused first conv needs the Winograd path");
     if (f16 == IO16 && m->has(wname + ".wd") && (m->planning || conv16_applicable(d))) {   // bf16 pipeline, C_in <= 64: direct conv from an LDS patch
         if (pool_fused) *pool_fused = y_pool != nullptr;
-        RUN(m, pn.c_str(), igemm_flops(d), bytes + (y_pool ? 0.5 * d.M * cout : 0.0), conv16_launch(d, m->W(wname + ".wd"), y_pool, m->st));
+        RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes + (y_pool ? 0.5 * d.M * cout : 0.0), conv16_launch(d, m->W(wname + ".wd"), y_pool, m->st));
         return 0;
     }
+    EVFLY_REQUIRE(!d.pre_frames, "the fused first conv needs the Winograd / direct-convolution kernels");
     if (pool_fused) *pool_fused = false;
     RUN(m, pn.c_str(), igemm_flops(d), bytes, igemm_launch(d, m->st));
     return 0;
@@ -630,7 +630,10 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     // exact-fp32 mode: e11 (1 or 2 -> 32 channels, HBM-write-bound: 11.4 MB per frame) is never materialised; the
     // Winograd kernel of e12 computes its input patch from the raw frame while staging it
     static const bool no_fuse = getenv("EVFLY_NO_E11_FUSION") != nullptr;
-    const bool fuse_e11 = c.compute_dtype == EVFLY_DTYPE_F32 && m->has("e12.u") && !no_fuse;
+    // (bf16 pipeline: the direct-convolution kernel of e12 has the same producer, for one frame channel)
+    const bool fuse_e11 = !no_fuse && ((c.compute_dtype == EVFLY_DTYPE_F32 && m->has("e12.u")) ||
+                                       (m->act16 && m->has("e12.wd") && ((c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels) == 1 &&
+                                        getenv("EVFLY_NO_CONV16") == nullptr));
     float *e11 = fuse_e11 ? nullptr : m->alloc_act((int64_t)F * 258 * 344 * 32);
     if (!fuse_e11 && a16)
         RUN(m, "e11_direct", 2.0 * F * 258 * 344 * 32 * 9 * cin, F * (4.0 * 260 * 346 + 2.0 * 258 * 344 * 32),
