@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     // LDS: [patch buffer 0][patch buffer 1][weights of the slice: nchunks * 18 * NTB KiB]
     const int nchunks = d.C >> 5;
     unsigned char *wl = smem + 2 * PATCH_BYTES;
-    float *fbuf = reinterpret_cast<float *>(wl + (size_t)nchunks * 18 * NTB * 1024);      // PRE: [2][FPIX] formed frame patches
+    float *bl = reinterpret_cast<float *>(wl + (size_t)nchunks * 18 * NTB * 1024);        // bias of the slice (NTB * 32 floats, zero padded)
+    float *fbuf = bl + NTB * 32;                                                           // PRE: [2][FPIX] formed frame patches
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slice = blockIdx.x / g.blocks_per_slice, bis = blockIdx.x - slice * g.blocks_per_slice;
@@ -87,6 +88,8 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         for (int pc = wv; pc * 1024 < wbytes; pc += NWAVE)
             dma16((unsigned)(pc * 1024 + lane * 16), srd, __builtin_amdgcn_readfirstlane(wl0 + (unsigned)pc * 1024u));
     }
+
+    if (tid < NTB * 32) bl[tid] = (d.bias && n0 + tid < d.Nc) ? d.bias[n0 + tid] : 0.f;        // (published by the prologue barrier)
 
     // ---- per-lane patch geometry of this wave's DMA pieces: piece p covers patch pixels 16 p .. 16 p + 15; lane l holds
     // slot l & 3 of pixel 16 p + (l >> 2), i.e. logical chunk (l & 3) ^ ((pixel >> 2) & 3)
@@ -136,23 +139,36 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         }
     };
 
-    // ---- PRE: frame patch staging (global fp32 -> formed value -> LDS) and patch production
-    auto stage_frame = [&](int t, int fb) {
+    // ---- PRE: frame patch staging (global fp32 -> formed value -> LDS) and patch production. The frame values are requested
+    // early (frame_load, into registers) and written to LDS late (frame_store): a load-then-write loop would park the wave for a
+    // full memory round trip every step.
+    constexpr int FPT = (FPIX + 511) / 512;                            // frame-patch values per thread
+    float fval[PRE ? FPT : 1];
+    auto frame_load = [&](int t) {
         int img, ty, tx;
         tile_decode(t, img, ty, tx);
         const int fy0 = ty * TH, fx0 = tx * TW;                        // the frame is (H + 2) x (W + 2): frame pixel = e11 pixel + tap
-        float *f = fbuf + fb * FPIX;
-        for (int i = tid; i < FPIX; i += 512) {
+#pragma unroll
+        for (int u = 0; u < FPT; ++u) {
+            const int i = tid + u * 512;
             const int fy = i / FW, fx = i - fy * FW;
             const int gy = fy0 + fy, gx = fx0 + fx;
-            float v = (gy < d.H + 2 && gx < d.W + 2) ? d.pre_frames[((int64_t)img * (d.H + 2) + gy) * (d.W + 2) + gx] : 0.f;
+            fval[u] = (i < FPIX && gy < d.H + 2 && gx < d.W + 2) ? d.pre_frames[((int64_t)img * (d.H + 2) + gy) * (d.W + 2) + gx] : 0.f;
+        }
+    };
+    auto frame_store = [&](int fb) {
+        float *f = fbuf + fb * FPIX;
+#pragma unroll
+        for (int u = 0; u < FPT; ++u) {
+            const int i = tid + u * 512;
+            float v = fval[u];
             if (d.pre_apply_form) {                                     // learner_models.py:476-494 (ops16.hip form_value16)
                 if (fabsf(v) < d.pre_cutoff) v = 0.0f;
                 if (d.pre_form_bev == 2) v = v != 0.0f ? 1.0f : 0.0f;
                 else if (d.pre_form_bev == 1) v = fabsf(v);
                 else v = v > 0.0f ? v : 0.0f;
             }
-            f[i] = v;
+            if (i < FPIX) f[i] = v;
         }
     };
     // thread = (patch pixel tid >> 2 (+ 128 per pass), 8-channel group tid & 3): its 9 x 8 weights and 8 biases live in registers
@@ -196,40 +212,82 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     const int n_steps = n_my * nchunks;
     if constexpr (PRE) {
         // pipeline: step s stages the frame patch of step s + 2, produces the patch of step s + 1, multiplies step s
-        if (n_steps > 0) stage_frame(bis, 0);
+        if (n_steps > 0) { frame_load(bis); frame_store(0); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (n_steps > 0) produce_patch(bis, 0, 0);
-        if (n_steps > 1) stage_frame(bis + g.blocks_per_slice, 1);
+        if (n_steps > 1) { frame_load(bis + g.blocks_per_slice); frame_store(1); }
     } else {
         if (n_steps > 0) issue_patch(bis, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // bias of this lane's channels: n = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    float bv[NTB][16];
-#pragma unroll
-    for (int j = 0; j < NTB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            bv[j][r] = (d.bias && n < d.Nc) ? d.bias[n] : 0.f;
-        }
 
     const int fj = lane & 31, fh = lane >> 5;
+    bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
+    // lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: after the swaps lane l owns
+    // channels 0-7 and 16-23, lane l + 32 channels 8-15 and 24-31 (16 B each)
+    auto store_rows = [&](const unsigned (&p)[8], bf16_t *dst_px, bool ok, int nbase, int ncount) {
+        unsigned o[8];
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)          // quads (0, 1) and (2, 3)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(p[(2 * grp) * 2 + w], p[(2 * grp + 1) * 2 + w], false, false);
+                o[grp * 4 + w] = sw[0];          // lanes < 32: own quad 2 grp       | lanes >= 32: partner's quad 2 grp + 1
+                o[grp * 4 + 2 + w] = sw[1];      // lanes < 32: partner's quad 2 grp | lanes >= 32: own quad 2 grp + 1
+            }
+        if (!ok) return;
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            const int ch = grp * 16 + fh * 8;     // first of this lane's 8 channels inside the 32-channel tile
+            if (nbase + ch < ncount)
+                *reinterpret_cast<uint4 *>(dst_px + nbase + ch) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
+        }
+    };
+    // The finished tile is packed (bias, activation, bf16, pool) behind its MFMAs but STORED at the top of the next step, ahead
+    // of that step's DMA requests: with one block per CU nothing else hides the stores' acknowledgement, and the step-closing
+    // vmcnt(0) (which the DMA needs) would wait for it every step (measured: 12 k cycles per step for 2.3 k cycles of MFMAs).
+    unsigned pk[ROWS][NTB][8];           // packed bf16 pairs of the tile waiting to be stored: [row][n-tile][r-group 0..3][dword 0..1]
+    unsigned pm[POOL ? NTB : 1][8];
+    int st_tile = -1;
+    auto flush_tile = [&]() {
+        if (st_tile < 0) return;
+        int img, ty, tx;
+        tile_decode(st_tile, img, ty, tx);
+        const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
+        const bool col_ok = ox < d.OW;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int oy = oy0 + r;
+            const bool ok = col_ok && oy < d.OH;
+            bf16_t *dst_px = y16 + (((int64_t)img * d.OH + (ok ? oy : 0)) * d.OW + (ok ? ox : 0)) * d.ldy;
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) store_rows(pk[r][j], dst_px, ok, n0 + j * 32, d.Nc);
+        }
+        if constexpr (POOL && ROWS == 2) {
+            bf16_t *yp = reinterpret_cast<bf16_t *>(g.y_pool);
+            const int PHo = d.OH / 2, PWo = d.OW / 2;
+            const int py = oy0 >> 1, pxo = ox >> 1;
+            const bool pok = (fj & 1) == 0 && py < PHo && pxo < PWo;
+            bf16_t *dst_px = yp + (((int64_t)img * PHo + (pok ? py : 0)) * PWo + (pok ? pxo : 0)) * d.Nc;
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) store_rows(pm[j], dst_px, pok, n0 + j * 32, d.Nc);
+        }
+        st_tile = -1;
+    };
+
     f32x16 acc[ROWS][NTB];
     int t_cur = bis, cc = 0;
     for (int s = 0; s < n_steps; ++s) {
-        // the next step's patch flies (DMA) or is computed (PRE) under this step's MFMAs
+        flush_tile();                          // the previous tile's stores: acknowledged under this step's MFMAs
+        // the next step's patch flies (DMA) or is computed (PRE) under this step's MFMAs.
         // PRE: every thread owns a share of the next patch / frame patch; even waves do theirs before their MFMAs, odd waves
         // behind them, so the two waves of a SIMD keep its VALU and its matrix pipe busy at the same time
-        auto next_work = [&]() {
-            if (s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
-            if (s + 2 < n_steps) stage_frame(t_cur + 2 * g.blocks_per_slice, s & 1);
-        };
         if constexpr (PRE) {
-            if ((wv & 1) == 0) next_work();
+            if (s + 2 < n_steps) frame_load(t_cur + 2 * g.blocks_per_slice);
+            if ((wv & 1) == 0 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
         } else {
             int t_nx = t_cur, c_nx = cc + 1;
             if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
@@ -264,96 +322,63 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
                     for (int j = 0; j < NTB; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], px[r], acc[r][j], 0, 0, 0);
             }
+            // (fragment reads stay within two taps of their MFMAs: unbounded, the scheduler front-loads all 18 x (ROWS + NTB) reads
+            // of a step and the <2, 2> variants run out of registers)
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (PRE) {
+            if ((wv & 1) == 1 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
+            if (s + 2 < n_steps) frame_store(s & 1);
         }
         if (cc == nchunks - 1) {
-            // ---- epilogue of the tile: straight from the accumulators
-            int img, ty, tx;
-            tile_decode(t_cur, img, ty, tx);
-            const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
-            const bool col_ok = ox < d.OW;
-            bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
-            unsigned pk[ROWS][NTB][8];           // packed bf16 pairs: [r-group 0..3][dword 0..1]
+            // ---- the tile's results, packed straight from the accumulators (stored by flush_tile)
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                 for (int j = 0; j < NTB; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
-                        float v0 = acc[r][j][e] + bv[j][e], v1 = acc[r][j][e + 1] + bv[j][e + 1];
+                        // bias of this lane's channels n = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): four adjacent floats per r-group
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bl + j * 32 + 8 * (e >> 2) + 4 * fh);
+                        const float b0 = (e & 2) ? b4.z : b4.x, b1 = (e & 2) ? b4.w : b4.y;
+                        float v0 = acc[r][j][e] + b0, v1 = acc[r][j][e + 1] + b1;
                         if (d.act == ACT_RELU) { v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; }
                         else if (d.act != ACT_NONE) { v0 = apply_act(v0, d.act); v1 = apply_act(v1, d.act); }
                         pk[r][j][e >> 1] = pack_bf2(v0, v1);
                     }
-            // lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: after the swaps lane l
-            // owns channels 0-7 and 16-23, lane l + 32 channels 8-15 and 24-31 (16 B each)
-            auto store_rows = [&](const unsigned (&p)[8], bf16_t *dst_px, bool ok, int nbase, int ncount) {
-                unsigned o[8];
-#pragma unroll
-                for (int grp = 0; grp < 2; ++grp)          // quads (0, 1) and (2, 3)
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(p[(2 * grp) * 2 + w], p[(2 * grp + 1) * 2 + w], false, false);
-                        o[grp * 4 + w] = sw[0];          // lanes < 32: own quad 2 grp       | lanes >= 32: partner's quad 2 grp + 1
-                        o[grp * 4 + 2 + w] = sw[1];      // lanes < 32: partner's quad 2 grp | lanes >= 32: own quad 2 grp + 1
-                    }
-                if (!ok) return;
-#pragma unroll
-                for (int grp = 0; grp < 2; ++grp) {
-                    const int ch = grp * 16 + fh * 8;     // first of this lane's 8 channels inside the 32-channel tile
-                    if (nbase + ch < ncount)
-                        *reinterpret_cast<uint4 *>(dst_px + nbase + ch) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
-                }
-            };
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int oy = oy0 + r;
-                const bool ok = col_ok && oy < d.OH;
-                bf16_t *dst_px = y16 + (((int64_t)img * d.OH + (ok ? oy : 0)) * d.OW + (ok ? ox : 0)) * d.ldy;
-#pragma unroll
-                for (int j = 0; j < NTB; ++j) store_rows(pk[r][j], dst_px, ok, n0 + j * 32, d.Nc);
-            }
-            if (POOL && ROWS == 2) {
+            if constexpr (POOL && ROWS == 2) {
                 // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes.
-                // The max of bf16-rounded values is the rounded max (rounding is monotonic): pool the packed results.
-                bf16_t *yp = reinterpret_cast<bf16_t *>(g.y_pool);
-                const int PHo = d.OH / 2, PWo = d.OW / 2;
-                const int py = oy0 >> 1, pxo = ox >> 1;
-                const bool pok = (fj & 1) == 0 && py < PHo && pxo < PWo;
+                // The max of bf16-rounded values is the rounded max (rounding is monotonic): pool the packed results. NaN wins like
+                // in torch (fmaxf alone would drop it).
 #pragma unroll
-                for (int j = 0; j < NTB; ++j) {
-                    unsigned pm[8];
+                for (int j = 0; j < NTB; ++j)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const unsigned a = pk[0][j][e], b = pk[ROWS - 1][j][e];
-                        float lo = fmaxf(bf_lo(a), bf_lo(b)), hi = fmaxf(bf_hi(a), bf_hi(b));       // ReLU outputs: no NaN ordering issue beyond fmaxf's
-                        // NaN-propagating like torch: fmaxf drops NaN, put it back
+                        const unsigned a = pk[0][j][e], b = pk[1][j][e];
+                        float lo = fmaxf(bf_lo(a), bf_lo(b)), hi = fmaxf(bf_hi(a), bf_hi(b));
                         lo = (bf_lo(a) != bf_lo(a)) ? bf_lo(a) : (bf_lo(b) != bf_lo(b)) ? bf_lo(b) : lo;
                         hi = (bf_hi(a) != bf_hi(a)) ? bf_hi(a) : (bf_hi(b) != bf_hi(b)) ? bf_hi(b) : hi;
                         const float lo2 = __shfl_xor(lo, 1), hi2 = __shfl_xor(hi, 1);
                         float ml = fmaxf(lo, lo2), mh = fmaxf(hi, hi2);
                         ml = (lo != lo) ? lo : (lo2 != lo2) ? lo2 : ml;
                         mh = (hi != hi) ? hi : (hi2 != hi2) ? hi2 : mh;
-                        pm[e] = pack_bf2(ml, mh);
+                        pm[j][e] = pack_bf2(ml, mh);
                     }
-                    bf16_t *dst_px = yp + (((int64_t)img * PHo + (pok ? py : 0)) * PWo + (pok ? pxo : 0)) * d.Nc;
-                    store_rows(pm, dst_px, pok, n0 + j * 32, d.Nc);
-                }
             }
-        }
-        if constexpr (PRE) {
-            if ((wv & 1) == 1) next_work();
+            st_tile = t_cur;
         }
         // the next patch has landed (this wave's pieces) and every wave is done reading this one
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (++cc == nchunks) { cc = 0; t_cur += g.blocks_per_slice; }
     }
+    flush_tile();
 }
 
 template <int ROWS, int NTB, bool POOL, bool PRE>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
-    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0);
+    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + NTB * 128 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0);
     auto kern = k_conv16<ROWS, NTB, POOL, PRE>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;

@@ -46,18 +46,35 @@ __global__ __launch_bounds__(256) void k_gconv_gelu(const T *__restrict__ x, int
         reinterpret_cast<float4 *>(wl)[i] = reinterpret_cast<const float4 *>(wp + (size_t)slab * 4 * 576)[i];
     __syncthreads();
     constexpr int V = Elem<T>::V;                                   // elements per 16-B global vector: 4 (fp32) or 8 (bf16)
-    for (int i = threadIdx.x; i < FPB * hw * (32 / V); i += 256) {
-        const int fp = i / (32 / V), cv = i - fp * (32 / V);
-        const int f = FPB == 1 ? 0 : fp / hw, p = fp - f * hw;
-        if (img0 + f >= n_frames) continue;
-        const int oy = (int)__umulhi((unsigned)p, w_magic), ox = p - oy * W;          // p / W
-        const int q = (oy + 1) * PW + ox + 1;
-        float v[V];
-        Elem<T>::load(x + ((int64_t)(img0 + f) * hw + p) * Ce + slab * 32 + cv * V, v);
+    // the slab goes global -> registers -> LDS in batches of UN vectors per thread with ALL of a batch's loads in flight before the
+    // first LDS write: as a plain load-then-write loop every iteration waited a full memory round trip (11 per thread: three
+    // quarters of the kernel's time, whatever the arithmetic behind it did)
+    constexpr int UN = 6;
+    const int total = FPB * hw * (32 / V);
+    for (int base = threadIdx.x; base < total; base += 256 * UN) {
+        float v[UN][V];
+        int qoff[UN], cvv[UN];
 #pragma unroll
-        for (int e = 0; e < V; e += 4) {
-            const int c = cv * V + e;                                // channel of the slab: group c >> 3, half (c >> 2) & 1
-            *reinterpret_cast<float4 *>(tile + f * npix * 32 + gc_off(npix, c >> 3, q, (c >> 2) & 1)) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+        for (int u = 0; u < UN; ++u) {
+            const int i = base + u * 256;
+            const int ic = i < total ? i : total - 1;
+            const int fp = ic / (32 / V), cv = ic - fp * (32 / V);
+            const int f = FPB == 1 ? 0 : fp / hw, p = fp - f * hw;
+            const int fc = img0 + f < n_frames ? f : 0;                 // frames past the batch: re-read frame 0 (never stored)
+            const int oy = (int)__umulhi((unsigned)p, w_magic), ox = p - oy * W;          // p / W
+            qoff[u] = (i < total && img0 + f < n_frames) ? f * npix * 32 + ((oy + 1) * PW + ox + 1) : -1;
+            cvv[u] = cv;
+            Elem<T>::load(x + ((int64_t)(img0 + fc) * hw + p) * Ce + slab * 32 + cv * V, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (qoff[u] < 0) continue;
+            const int fo = qoff[u] / (npix * 32) * (npix * 32), q = qoff[u] - fo;
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const int c = cvv[u] * V + e;                        // channel of the slab: group c >> 3, half (c >> 2) & 1
+                *reinterpret_cast<float4 *>(tile + fo + gc_off(npix, c >> 3, q, (c >> 2) & 1)) = make_float4(v[u][e], v[u][e + 1], v[u][e + 2], v[u][e + 3]);
+            }
         }
     }
     __syncthreads();
