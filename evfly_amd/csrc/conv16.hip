@@ -281,13 +281,17 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     f32x16 acc[ROWS][NTB];
     int t_cur = bis, cc = 0;
     for (int s = 0; s < n_steps; ++s) {
-        flush_tile();                          // the previous tile's stores: acknowledged under this step's MFMAs
         // the next step's patch flies (DMA) or is computed (PRE) under this step's MFMAs.
         // PRE: every thread owns a share of the next patch / frame patch; even waves do theirs before their MFMAs, odd waves
-        // behind them, so the two waves of a SIMD keep its VALU and its matrix pipe busy at the same time
+        // behind them, so the two waves of a SIMD keep its VALU and its matrix pipe busy at the same time. The even waves
+        // produce FIRST, while their vector-memory queue is still empty: hipcc puts a vmcnt(0) into the producer loop as soon
+        // as a store or a frame load is outstanding, i.e. a full memory round trip in front of the arithmetic.
+        if constexpr (PRE) {
+            if ((wv & 1) == 0 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
+        }
+        flush_tile();                          // the previous tile's stores: acknowledged under this step's MFMAs
         if constexpr (PRE) {
             if (s + 2 < n_steps) frame_load(t_cur + 2 * g.blocks_per_slice);
-            if ((wv & 1) == 0 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
         } else {
             int t_nx = t_cur, c_nx = cc + 1;
             if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
@@ -332,20 +336,23 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         }
         if (cc == nchunks - 1) {
             // ---- the tile's results, packed straight from the accumulators (stored by flush_tile)
+            const bool relu = d.act == ACT_RELU;        // (conv16_applicable admits ACT_RELU / ACT_NONE only)
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
+            for (int j = 0; j < NTB; ++j) {
+                // bias of this lane's channels n = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): four adjacent floats per r-group
+                float4 b4[4];
 #pragma unroll
-                for (int j = 0; j < NTB; ++j)
+                for (int rg = 0; rg < 4; ++rg) b4[rg] = *reinterpret_cast<const float4 *>(bl + j * 32 + 8 * rg + 4 * fh);
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
-                        // bias of this lane's channels n = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): four adjacent floats per r-group
-                        const float4 b4 = *reinterpret_cast<const float4 *>(bl + j * 32 + 8 * (e >> 2) + 4 * fh);
-                        const float b0 = (e & 2) ? b4.z : b4.x, b1 = (e & 2) ? b4.w : b4.y;
+                        const float b0 = (e & 2) ? b4[e >> 2].z : b4[e >> 2].x, b1 = (e & 2) ? b4[e >> 2].w : b4[e >> 2].y;
                         float v0 = acc[r][j][e] + b0, v1 = acc[r][j][e + 1] + b1;
-                        if (d.act == ACT_RELU) { v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; }
-                        else if (d.act != ACT_NONE) { v0 = apply_act(v0, d.act); v1 = apply_act(v1, d.act); }
+                        v0 = (relu && v0 < 0.f) ? 0.f : v0; v1 = (relu && v1 < 0.f) ? 0.f : v1;
                         pk[r][j][e >> 1] = pack_bf2(v0, v1);
                     }
+            }
             if constexpr (POOL && ROWS == 2) {
                 // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes.
                 // The max of bf16-rounded values is the rounded max (rounding is monotonic): pool the packed results. NaN wins like
@@ -404,6 +411,7 @@ bool conv16_applicable(const ConvDesc &d) {
     static const bool off = getenv("EVFLY_NO_CONV16") != nullptr;
     return !off && d.in_bf16 && d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 &&
            (d.C == 32 || d.C == 64) && d.Nc % 32 == 0 && !d.res && d.out_mode == OUT_ROWS && d.ldx % 8 == 0 && d.ldy % 8 == 0 &&
+           (d.act == ACT_RELU || d.act == ACT_NONE) &&
            (d.pre_frames || ((uintptr_t)d.x) % 16 == 0) && ((uintptr_t)d.y) % 16 == 0 && d.OW >= 1 && d.OH >= 1 &&
            (int64_t)(d.H) * d.W * d.ldx * 2 < ((int64_t)1 << 31);
 }
