@@ -44,7 +44,7 @@ H, W = 260, 346
 PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, summarised per kernel family (first existing file wins)
-PMC_TRAFFIC = {"C2": ("r3_pmc_traffic.json", "r2_pmc_traffic.json"), "C5": ("r3_bf16_pmc_traffic.json",)}
+PMC_TRAFFIC = {"C2": ("r3_C2_pmc_traffic.json", "r2_pmc_traffic.json"), "C5": ("r3_C5_pmc_traffic.json",)}
 
 CONFIGS = {
     "C2": dict(streams=64, windows=5, epw=60_000, sensor=(260, 346), vit="tiny", dtype="f32", model="composite"),
@@ -291,8 +291,14 @@ def main():
         pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in PMC_TRAFFIC.get(a.config, ())) if os.path.exists(q)), None)
         if pmc and cfg == CONFIGS[a.config]:
             ks = json.load(open(pmc))["kernels"]
-            g = ks.get("wino_conv3x3") if dtype == "f32" else ks.get("igemm16_conv")
-            if g:
+            # fp32: the 17 Winograd launches; bf16 pipeline: the 3x3 convs run on two kernels (direct conv for C_in <= 64, implicit
+            # GEMM beyond; the GEMM family's count also holds the ViT / velpred convs, a rounding error in bytes)
+            fams = ["wino_conv3x3"] if dtype == "f32" else ["conv16_direct", "igemm16_conv"]
+            gs = [ks[f] for f in fams if f in ks]
+            g = None
+            if gs:
+                g = {k: sum(x[k] for x in gs) for k in ("fetch_bytes_per_step", "write_bytes_per_step")}
+                g["launches_per_step"] = 17
                 traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
                 tnote = ("HBM bytes per launch, mean over the %d conv3x3 launches of a step: (2 x FETCH_SIZE + WRITE_SIZE) from "
                          "profiles/%s; algorithmic = algorithmic.bytes_per_launch" % (g["launches_per_step"], os.path.basename(pmc)))
