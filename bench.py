@@ -373,12 +373,15 @@ def main():
             # and the latency of ONE stream's 16-frame sequence
             serial = sum(p["ms"] for p in prof if p["name"] in ("convlstm_h_gemm", "convlstm_gates"))
             xg = sum(p["ms"] for p in prof if p["name"] == "convlstm_x_gemm")
-            with torch.no_grad():
-                x1 = voxelizer.condition_frames(frames.view(B * T, Hs, Ws)[:T], out_hw=(H, W))
-                one_ms = time_stage(lambda: model.forward_streams(x1, None, 1, T), reps=5)
+            one_ms = None
+            if not a.no_stage_rates:
+                with torch.no_grad():
+                    x1 = voxelizer.condition_frames(frames.view(B * T, Hs, Ws)[:T], out_hw=(H, W))
+                    one_ms = time_stage(lambda: model.forward_streams(x1, None, 1, T), reps=5)
             out["convlstm"] = {"serial_critical_path_ms_per_step": round(serial, 3), "steps_in_series": T,
                                "batched_input_gemm_ms_per_step": round(xg, 3),
-                               "single_stream_sequence_ms": round(one_ms, 3), "single_stream_frames_per_s": round(T / (one_ms * 1e-3), 1),
+                               "single_stream_sequence_ms": round(one_ms, 3) if one_ms else None,
+                               "single_stream_frames_per_s": round(T / (one_ms * 1e-3), 1) if one_ms else None,
                                "note": f"serial = the {T} dependent (h-GEMM, gates) launch pairs of one {B}-stream chunk; single_stream = one stream's "
                                        f"{T}-frame sequence through the U-Net alone (latency-bound: {T} frames do not fill the chip)"}
         mf = sum(p["flops"] for p in prof if p["flops"])
