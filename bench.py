@@ -123,7 +123,11 @@ def cpu_baseline(sd, cfg, budget_s):
     res = {}
     try:
         one_stream(0)                                          # warm-up (oneDNN primitive caches)
-        for label, th, share in (("threads_1", 1, 0.45), ("threads_nproc", nproc, 0.55)):
+        # (oneDNN on a many-core host is slower with EVERY core on a T-frame batch than with a few: a middle count is timed too so
+        # that `value` is the host's best, not a strawman)
+        mid = max(1, min(16, nproc))
+        plan = [("threads_1", 1, 0.35), ("threads_nproc", nproc, 0.35)] + ([(f"threads_{mid}", mid, 0.3)] if mid not in (1, nproc) else [])
+        for label, th, share in plan:
             torch.set_num_threads(th)
             frames_done, dt, s = 0, 0.0, 0
             while dt < budget_s * share:
@@ -136,11 +140,12 @@ def cpu_baseline(sd, cfg, budget_s):
         om.use_trunk()
     best = max(res.values(), key=lambda r: r["value"])
     what = "U-Net + ConvLSTM" if cfg["model"] == "unet" else f"composite ({cfg['vit']} ViT)"
-    return {"value": best["value"], "unit": "event-frames/s", "cores": best["cores"], "kind": "port",
-            "threads_1": res["threads_1"], "threads_nproc": res["threads_nproc"],
-            "sample": f"streams of {T} windows x {epw} events at {hs}x{ws}: C voxelizer port + torch-CPU fp32 oracle forward of the {what}, "
-                      f"batch-as-time; {res['threads_1']['streams']} stream(s) at 1 thread ({res['threads_1']['seconds']} s), "
-                      f"{res['threads_nproc']['streams']} at {nproc} threads ({res['threads_nproc']['seconds']} s); `value` = the faster"}
+    out = {"value": best["value"], "unit": "event-frames/s", "cores": best["cores"], "kind": "port"}
+    out.update(res)
+    out["sample"] = (f"streams of {T} windows x {epw} events at {hs}x{ws}: C voxelizer port + torch-CPU fp32 oracle forward of the {what}, "
+                     f"batch-as-time; " + ", ".join(f"{r['streams']} stream(s) at {r['cores']} thread(s) ({r['seconds']} s)" for r in res.values()) +
+                     "; `value` = the fastest")
+    return out
 
 
 def main():

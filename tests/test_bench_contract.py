@@ -1,29 +1,47 @@
-"""The committed bench line (profiles/r2_bench.json, produced by `python bench.py` on the MI355X box) carries every
-field of the bench contract; guards against a refactor of bench.py dropping one."""
+"""The committed bench lines (profiles/r3_C*_bench.json, produced by `python bench.py [--config ..]` on the MI355X box) carry
+every field of the bench contract; guards against a refactor of bench.py dropping one."""
 import json
 import os
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line(name):
+    return json.loads(open(os.path.join(REPO, "profiles", name)).read().strip().splitlines()[-1])
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    b = json.load(open(os.path.join(REPO, "profiles", "r2_bench.json")))
+    b = _line("r3_C2_bench.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "step_mfma_util", "stage_rates"):
         assert k in b, k
     assert b["unit"] == "event-frames/s" and b["higher_is_better"] is True and b["scaling"] == "weak"
-    assert b["vs_baseline"] is None and b["dtype"] == "f32" and b["data"] == "synthetic" and "workload" in b["config"]
+    assert b["vs_baseline"] is None and b["dtype"] == "f32" and b["data"] == "synthetic" and b["config"]["workload"].startswith("C2:")
     assert abs(b["value"] - 320 * 1e3 / b["ms_per_step"]) < 1e-2 * b["value"]
     r = b["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_useful", "frac_algorithmic", "traffic", "hbm"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # `achieved` / `frac` count the flops the matrix cores issue; the direct-conv (algorithmic) rate sits beside them
-    assert 0 < r["frac"] < 1 and r["algorithmic"]["tflops"] > r["achieved"]                     # Winograd: issued < algorithmic
+    # `achieved` / `frac` count the flops the matrix cores issue; useful <= issued < peak < algorithmic (Winograd)
+    assert 0 < r["frac_useful"] <= r["frac"] < 1 < r["frac_algorithmic"] and r["algorithmic"]["tflops"] > r["achieved"]
+    assert 0 < b["step_mfma_util"] < 1
+    for k in ("v_only", "d_only", "p_only", "v_d_p"):
+        assert b["stage_rates"][k]["frames_per_s"] > 0
     c = b["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "threads_1", "threads_nproc"):
         assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["threads_1"]["cores"] == 1
+
+
+def test_committed_lines_of_the_other_baseline_configs():
+    """BASELINE.json configs[2..4] have a driver-form line each (C3 bf16 ViT-base at 480x640, C4 shard, C5 ConvLSTM seq-16)."""
+    c3, c4, c5 = _line("r3_C3_bench.json"), _line("r3_C4_bench.json"), _line("r3_C5_bench.json")
+    assert c3["dtype"] == "bf16" and c3["config"]["sensor"] == [480, 640] and c3["config"]["vit_trunk"] == "base" and c3["config"]["streams_per_gpu"] == 256
+    assert abs(c3["value"] - 2560 * 1e3 / c3["ms_per_step"]) < 1e-2 * c3["value"]
+    assert c4["config"]["streams_per_gpu"] == 256 and c4["config"]["windows"] == 5 and c4["config"]["vit_trunk"] == "base"
+    assert c5["dtype"] == "bf16" and c5["config"]["windows"] == 16 and c5["convlstm"]["steps_in_series"] == 16
+    for b in (c3, c4, c5):
+        assert "roofline" in b and "cpu_baseline" in b and b["value"] > 0
 
 
 def test_bench_source_keeps_the_contract_keys():
