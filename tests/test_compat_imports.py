@@ -11,6 +11,7 @@ def test_run_py_import_surface():
     code = textwrap.dedent(f"""
         import sys
         sys.path.insert(0, {os.path.join(REPO, 'evfly_amd', 'compat')!r})
+        from ev_utils import simple_evim                                    # run.py:24, verbatim
         from ev_utils import form_eventframe
         from learner import argparsing
         from learner_models import *
@@ -21,7 +22,7 @@ def test_run_py_import_surface():
                                       input_shape=[1, 1, 260, 346], velpred=0, enc_params={{}}, dec_params={{}}, fc_params={{}},
                                       form_BEV=2, evs_min_cutoff=0.15, skip_type='interp', is_deployment=False)
         assert sum(p.numel() for p in m.parameters()) == 13420336          # BASELINE.md: composite parameter count
-        assert isinstance(m.vitfly_vitlstm, vitfly_models.LSTMNetVIT) and callable(form_eventframe) and callable(argparsing) and callable(Aligner)
+        assert isinstance(m.vitfly_vitlstm, vitfly_models.LSTMNetVIT) and callable(form_eventframe) and callable(argparsing) and callable(Aligner) and callable(simple_evim)
         print('ok')
     """)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
