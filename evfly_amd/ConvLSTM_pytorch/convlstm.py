@@ -4,25 +4,13 @@ Same constructor arguments, state-dict keys (`cell_list.{i}.conv.weight`) and `f
 `forward(input_tensor (b, t, c, h, w) | (t, b, c, h, w), hidden_state=None) -> (layer_output_list, last_state_list)`
 with the Feb-2024 patch that accepts a hidden state (convlstm.py:142-149). Inside `OrigUNet` the recurrence runs in
 `evfly_unet_forward` (input-side GEMM batched over time, hidden-side GEMM + fused gate kernel per step); called on its
-own, `forward` runs the same kernels through the stateless operator entry points of the C ABI
-(`evfly_op_conv2d_nhwc` for conv(cat[x, h]) split into its x and h halves, `evfly_op_convlstm_gates`).
+own, `forward` runs the same kernels through `evfly_convlstm_forward` of the C ABI, one call per layer (conv(cat[x, h])
+split into its x and h halves on the device, the time loop inside the library).
 """
 import torch
 import torch.nn as nn
 
 from .. import _lib
-
-
-def _conv_nhwc(x, w_packed, bias, k, pad, res=None):
-    """y = conv2d(x (n,h,w,cin) NHWC, w_packed (cout,kh,kw,cin)) + bias (+ res), stride 1, fp32, on the current stream."""
-    L = _lib.lib()
-    n, h, w, cin = x.shape
-    cout = w_packed.shape[0]
-    y = torch.empty(n, h + 2 * pad[0] - k[0] + 1, w + 2 * pad[1] - k[1] + 1, cout, device=x.device, dtype=torch.float32)
-    assert pad[0] == pad[1], "evfly_op_conv2d_nhwc pads symmetrically"
-    _lib.check(L.evfly_op_conv2d_nhwc(_lib.ptr(x), n, h, w, cin, _lib.ptr(w_packed), _lib.ptr(bias), cout, k[0], k[1], 1, pad[0], 0,
-                                      _lib.ptr(res), _lib.ptr(y), 0, _lib.cur_stream()))
-    return y
 
 
 class ConvLSTMCell(nn.Module):
@@ -34,15 +22,6 @@ class ConvLSTMCell(nn.Module):
         self.padding = kernel_size[0] // 2, kernel_size[1] // 2
         self.conv = nn.Conv2d(in_channels=input_dim + hidden_dim, out_channels=4 * hidden_dim,
                               kernel_size=kernel_size, padding=self.padding, bias=bias)
-
-    def _packed(self, dev):
-        """conv weight (4*hid, cin + hid, kh, kw) split along its input channels (convlstm.py:41: cat([x, h])) into the two
-        [cout][kh][kw][c] operands of the kernels."""
-        w = self.conv.weight.detach().to(dev, torch.float32)
-        wx = w[:, :self.input_dim].permute(0, 2, 3, 1).contiguous()
-        wh = w[:, self.input_dim:].permute(0, 2, 3, 1).contiguous()
-        b = self.conv.bias.detach().to(dev, torch.float32).contiguous() if self.conv.bias is not None else None
-        return wx, wh, b
 
     def init_hidden(self, batch_size, image_size):                       # convlstm.py:55-58
         height, width = image_size
@@ -90,14 +69,14 @@ class ConvLSTM(nn.Module):
                 cs = c0.to("cuda", torch.float32).permute(0, 2, 3, 1).contiguous().clone()
             else:
                 hs = torch.zeros(b, h, w, hid, device="cuda"); cs = torch.zeros_like(hs)
-            wx, wh, bias = cell._packed("cuda")
-            # input half of conv(cat[x, h]) for every time step at once (+ bias), hidden half per step with it as the addend
-            zx = _conv_nhwc(cur.reshape(b * seq_len, h, w, -1), wx, bias, cell.kernel_size, cell.padding).reshape(b, seq_len, h, w, 4 * hid)
+            kh, kw = cell.kernel_size
+            wt = cell.conv.weight.detach().to("cuda", torch.float32).contiguous()
+            bias = cell.conv.bias.detach().to("cuda", torch.float32).contiguous() if cell.conv.bias is not None else None
+            cin = cur.shape[-1]
+            ws = torch.empty(int(L.evfly_convlstm_workspace_bytes(b, seq_len, h, w, cin, hid, kh, kw)), device="cuda", dtype=torch.uint8)
             outs = torch.empty(b, seq_len, h, w, hid, device="cuda")
-            for t in range(seq_len):                                                 # :161-164
-                z = _conv_nhwc(hs, wh, None, cell.kernel_size, cell.padding, res=zx[:, t].contiguous())
-                _lib.check(L.evfly_op_convlstm_gates(_lib.ptr(z), b * h * w, hid, _lib.ptr(cs), _lib.ptr(hs), _lib.cur_stream()))
-                outs[:, t] = hs
+            _lib.check(L.evfly_convlstm_forward(_lib.ptr(cur), b, seq_len, h, w, cin, _lib.ptr(wt), _lib.ptr(bias), hid, kh, kw,
+                                                _lib.ptr(hs), _lib.ptr(cs), _lib.ptr(outs), _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
             cur = outs
             layer_output_list.append(outs.permute(0, 1, 4, 2, 3).to(dev_in))          # (b, t, hidden, h, w)
             last_state_list.append([hs.permute(0, 3, 1, 2).to(dev_in), cs.permute(0, 3, 1, 2).to(dev_in)])

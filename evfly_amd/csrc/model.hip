@@ -1378,6 +1378,68 @@ extern "C" int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, f
     return num_out == 1 ? launch_velpred_vec(y, rows, 1, vel, as_stream(stream)) : launch_velpred_vec2(y, rows, 2, vel, as_stream(stream));
 }
 
+// ---------------------------------------------------------------------------------------- stand-alone ConvLSTM layer
+// workspace: [wx 4hid x ldx][wh 4hid x ldh][zx b*t*h*w x 4hid][z b*h*w x 4hid], each rounded up to 256 B
+namespace {
+struct ClstmWs { int ldx, ldh; int64_t o_wx, o_wh, o_zx, o_z, bytes; };
+ClstmWs clstm_ws(int b, int t, int h, int w, int cin, int hid, int kh, int kw) {
+    ClstmWs s;
+    s.ldx = round_up(kh * kw * cin, 32); s.ldh = round_up(kh * kw * hid, 32);
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    const int64_t co = 4 * (int64_t)hid, px = (int64_t)h * w;
+    s.o_wx = 0;
+    s.o_wh = s.o_wx + up(co * s.ldx * 4);
+    s.o_zx = s.o_wh + up(co * s.ldh * 4);
+    s.o_z = s.o_zx + up((int64_t)b * t * px * co * 4);
+    s.bytes = s.o_z + up((int64_t)b * px * co * 4);
+    return s;
+}
+}  // namespace
+
+extern "C" int64_t evfly_convlstm_workspace_bytes(int b, int t, int h, int w, int cin, int hid, int kh, int kw) {
+    if (b <= 0 || t <= 0 || h <= 0 || w <= 0 || cin <= 0 || hid <= 0 || kh <= 0 || kw <= 0) return 0;
+    return clstm_ws(b, t, h, w, cin, hid, kh, kw).bytes;
+}
+
+extern "C" int evfly_convlstm_forward(const float *x, int b, int t, int h, int w, int cin, const float *weight, const float *bias,
+                                      int hid, int kh, int kw, float *h_state, float *c_state, float *out, void *workspace,
+                                      int64_t workspace_bytes, void *stream) {
+    EVFLY_REQUIRE(x && weight && h_state && c_state && out && workspace, "convlstm_forward: null argument");
+    EVFLY_REQUIRE(b > 0 && t > 0 && h > 0 && w > 0 && cin > 0 && hid > 0, "convlstm_forward: empty argument");
+    EVFLY_REQUIRE(kh == kw && (kh & 1), "convlstm_forward: the kernels pad symmetrically (odd square kernel_size)");
+    const ClstmWs s = clstm_ws(b, t, h, w, cin, hid, kh, kw);
+    EVFLY_REQUIRE(workspace_bytes >= s.bytes, "convlstm_forward: workspace smaller than evfly_convlstm_workspace_bytes");
+    hipStream_t st = as_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    float *wx = reinterpret_cast<float *>(ws + s.o_wx), *wh = reinterpret_cast<float *>(ws + s.o_wh);
+    float *zx = reinterpret_cast<float *>(ws + s.o_zx), *z = reinterpret_cast<float *>(ws + s.o_z);
+    const int co = 4 * hid, taps = kh * kw;
+    if (int rc = launch_split_w(weight, co, cin + hid, 0, cin, taps, s.ldx, wx, st)) return rc;
+    if (int rc = launch_split_w(weight, co, cin + hid, cin, hid, taps, s.ldh, wh, st)) return rc;
+    const int64_t px = (int64_t)h * w;
+    // input half of conv(cat[x, h]) + bias for every time step at once (convlstm.py:41 split along the input channels)
+    ConvDesc d;
+    d.x = x; d.ldx = cin; d.NI = b * t; d.H = h; d.W = w; d.C = cin; d.w = wx; d.ldw = s.ldx; d.bias = bias;
+    d.KH = kh; d.KW = kw; d.stride = 1; d.pad = kh / 2;
+    conv_finish(d);
+    d.Nc = co; d.res = nullptr; d.ldres = co; d.act = EVFLY_ACT_NONE; d.y = zx; d.ldy = co; d.dtype = EVFLY_DTYPE_F32;
+    if (int rc = igemm_launch(d, st)) return rc;
+    // hidden half per step with the input half as the addend, then the cell (convlstm.py:161-164, :44-51)
+    ConvDesc dh;
+    dh.x = h_state; dh.ldx = hid; dh.NI = b; dh.H = h; dh.W = w; dh.C = hid; dh.w = wh; dh.ldw = s.ldh; dh.bias = nullptr;
+    dh.KH = kh; dh.KW = kw; dh.stride = 1; dh.pad = kh / 2;
+    conv_finish(dh);
+    dh.Nc = co; dh.ldres = co; dh.act = EVFLY_ACT_NONE; dh.y = z; dh.ldy = co; dh.dtype = EVFLY_DTYPE_F32;
+    for (int k = 0; k < t; ++k) {
+        // output row (image i, pixel p) of step k takes row (i * t + k) * px + p of zx as its addend
+        dh.res = zx + (int64_t)k * px * co; dh.res_rpi = (int)px; dh.res_img_rows = (int64_t)t * px;
+        if (int rc = igemm_launch(dh, st)) return rc;
+        if (int rc = launch_convlstm_gates(z, (int64_t)b * px, hid, c_state, h_state, out + (int64_t)k * px * hid, (int)px, (int64_t)t * px, st))
+            return rc;
+    }
+    return 0;
+}
+
 extern "C" int evfly_op_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *stream) {
     EVFLY_REQUIRE(z && c && h && rows > 0 && hid > 0, "op_convlstm_gates: null or empty argument");
     return launch_convlstm_gates(z, rows, hid, c, h, nullptr, 1, 0, as_stream(stream));

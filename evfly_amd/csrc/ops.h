@@ -17,6 +17,8 @@ int launch_velpred_vec(const float *y, int64_t rows, int64_t ldy, float *vel, hi
 int launch_velpred_vec2(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st);
 // [cout][tap][cin] -> [cout][ld] in the kernel's K order (igemm.h conv_k_index), zero padded (any cin)
 int launch_repack_w(const float *w, int cout, int ntaps, int cin, int ld, float *out, hipStream_t st);
+// nn.Conv2d weight (cout, ctot, kh, kw), input channels [c0, c0 + cn) only -> [cout][ld] in the same K order
+int launch_split_w(const float *w, int cout, int ctot, int c0, int cn, int ntaps, int ld, float *out, hipStream_t st);
 // bilinear resize (F.interpolate / nn.Upsample); y pixel stride ldy, written at channel offset 0 of y.
 // pre: 0 none, 1 clip(2*v, 0, 1) applied to every source sample (learner_models.py:634)
 // excl_h x excl_w > 0: skip the output pixels whose four taps lie inside one excl_h x excl_w region of the source grid

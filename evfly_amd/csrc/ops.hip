@@ -160,6 +160,25 @@ __global__ __launch_bounds__(256) void k_repack_w(const float *__restrict__ w, i
     }
 }
 
+// nn.Conv2d weight (cout, ctot, kh, kw) restricted to input channels [c0, c0 + cn) -> [cout][ld] in the K order of
+// igemm.h conv_k_index, zero padded: the x and h halves of ConvLSTMCell.conv (convlstm.py:41 convolves cat([x, h]))
+__global__ __launch_bounds__(256) void k_split_w(const float *__restrict__ w, int cout, int ctot, int c0, int cn, int ntaps, int ld,
+                                                 float *__restrict__ out) {
+    const int K = ntaps * cn;
+    const int64_t total = (int64_t)cout * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int o = (int)(i / ld), k = (int)(i - (int64_t)o * ld);
+        float v = 0.f;
+        if (k < K) {
+            int tap, c;
+            if (cn % 32 == 0) { const int q = k >> 5, cc = q / ntaps; tap = q - cc * ntaps; c = cc * 32 + (k & 31); }
+            else { tap = k / cn; c = k - tap * cn; }
+            v = w[((int64_t)o * ctot + c0 + c) * ntaps + tap];
+        }
+        out[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bilinear
 // ATen upsample_bilinear2d (aten/src/ATen/native/UpSample.h area_pixel_compute_* + cpu/UpSampleKernel.cpp):
 // fp32 scale, source index, lambdas (bilinear_src_index, common.h); result = wh0*(ww0*v00 + ww1*v01) + wh1*(ww0*v10 + ww1*v11).
@@ -592,6 +611,12 @@ int launch_velpred_vec(const float *y, int64_t rows, int64_t ldy, float *vel, hi
 
 int launch_velpred_vec2(const float *y, int64_t rows, int64_t ldy, float *vel, hipStream_t st) {
     hipLaunchKernelGGL(k_velpred_vec2, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, y, rows, ldy, vel);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_split_w(const float *w, int cout, int ctot, int c0, int cn, int ntaps, int ld, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_split_w, dim3(grid_for((int64_t)cout * ld, 256)), dim3(256), 0, st, w, cout, ctot, c0, cn, ntaps, ld, out);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

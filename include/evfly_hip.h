@@ -315,6 +315,19 @@ int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, float *vel, 
  * pre-activations of conv(cat[x, h]); c, h (rows, hid) updated in place (c = f*c + i*g, h = o*tanh(c)). */
 int evfly_op_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *stream);
 
+/* One ConvLSTM layer over a sequence: ConvLSTM.forward's inner loops learner/ConvLSTM_pytorch/convlstm.py:151-169 with
+ * ConvLSTMCell.forward :38-53 as the body. x (b, t, h, w, cin) NHWC fp32; weight / bias = the cell's nn.Conv2d parameters as
+ * the state dict holds them (`cell_list.{i}.conv.weight` (4*hid, cin + hid, kh, kw), bias (4*hid) or NULL); h_state /
+ * c_state (b, h, w, hid) hold the incoming state (zeros for hidden_state=None, :142-149) and are updated in place to the
+ * last step's [h, c]; out (b, t, h, w, hid) receives h of every step (layer_output, :166). The input half of
+ * conv(cat[x, h]) runs once for all b*t frames, the hidden half per step with it as the addend, the gates in one kernel.
+ * workspace: device memory of at least evfly_convlstm_workspace_bytes(...) bytes (0 for invalid geometry). kh == kw, odd
+ * ('same' padding kernel_size // 2 as :17). Stacked layers: call once per layer with the previous `out` as x. */
+int64_t evfly_convlstm_workspace_bytes(int b, int t, int h, int w, int cin, int hid, int kh, int kw);
+int evfly_convlstm_forward(const float *x, int b, int t, int h, int w, int cin, const float *weight, const float *bias,
+                           int hid, int kh, int kw, float *h_state, float *c_state, float *out, void *workspace,
+                           int64_t workspace_bytes, void *stream);
+
 /* The same operator in the bf16 pipeline (compute_dtype EVFLY_DTYPE_BF16): x, res, y are bf16 NHWC tensors (raw
  * bits in uint16_t), cin % 32 == 0; w_packed / bias stay fp32 (the weights are rounded to bf16 once, like
  * evfly_model_finalize does); fp32 accumulation, one rounding of the result. */
