@@ -1372,6 +1372,22 @@ extern "C" int evfly_op_pool2d_nhwc(const float *x, int n, int h, int w, int c, 
     return launch_pool2d(x, n, h, w, c, k, stride, type, negate, y, as_stream(stream));
 }
 
+// MixFFN middle (ViTsubmodules.py:92-116: nn.Conv2d(E, E, 3, padding=1, groups=E/8) + nn.GELU()) as a stateless operator: the weight is
+// repacked per group on the device into the scratch buffer, then the same kernels the model handles launch
+extern "C" int evfly_op_grouped_conv_gelu(const void *x, int n, int h, int w, int ce, const float *weight, const float *bias, void *y,
+                                          int bf16, void *stream) {
+    EVFLY_REQUIRE(x && weight && bias && y && n > 0, "op_grouped_conv_gelu: null or empty argument");
+    EVFLY_REQUIRE(ce % 8 == 0, "op_grouped_conv_gelu: channels must be a multiple of 8 (groups of 8)");
+    if (!gconv_fits(h, w, ce)) {
+        if (bf16) return launch16_grouped_conv_gelu(x, n, h, w, ce, weight, bias, y, as_stream(stream));
+        return launch_grouped_conv_gelu(static_cast<const float *>(x), n, h, w, ce, weight, bias, static_cast<float *>(y), as_stream(stream));
+    }
+    void *wp = nullptr;
+    if (int rc = scratch_get((size_t)ce * 72 * 4, &wp, as_stream(stream), 1)) return rc;
+    if (int rc = gconv_pack_device(weight, ce, static_cast<float *>(wp), as_stream(stream))) return rc;
+    return launch_gconv_gelu(x, n, h, w, ce, static_cast<const float *>(wp), bias, y, bf16 != 0, as_stream(stream));
+}
+
 extern "C" int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, float *vel, void *stream) {
     EVFLY_REQUIRE(y && vel && rows > 0, "op_velpred_vec: null or empty argument");
     EVFLY_REQUIRE(num_out == 1 || num_out == 2, "op_velpred_vec: num_out must be 1 or 2 (3 is the identity)");

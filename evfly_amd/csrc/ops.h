@@ -47,6 +47,7 @@ int launch_grouped_conv_gelu(const float *x, int n, int H, int W, int Ce, const 
 // wp = gconv_pack_host(depthwise.weight): [Ce / 8][9 taps][8 co][8 ci]. gconv_fits: the frame's padded slab fits the LDS tile.
 bool gconv_fits(int H, int W, int Ce);
 void gconv_pack_host(const float *w, int Ce, float *out);
+int gconv_pack_device(const float *w, int Ce, float *out, hipStream_t st);
 int launch_gconv_gelu(const void *x, int n, int H, int W, int Ce, const float *wp, const float *bias, void *y, bool bf16, hipStream_t st);
 int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st);
 // x517 assembly (vitfly_models.py:144): cols [512] = desvel/10, [513..516] = quat (or 1,0,0,0), rest of the pad 0

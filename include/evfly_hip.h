@@ -307,6 +307,12 @@ int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin, const flo
 int evfly_op_pool2d_nhwc(const float *x, int n, int h, int w, int c, int k, int stride, int type, int negate,
                          float *y, void *stream);
 
+/* MixFFN's middle learner/ViTsubmodules.py:92-116 (`self.depthwise = nn.Conv2d(E, E, 3, padding=1, groups=E // 8)` followed by
+ * nn.GELU(), erf form): x, y (n, h, w, ce) NHWC, fp32 (bf16 == 0) or bf16 raw bits (bf16 != 0: bf16 operands on the matrix
+ * cores, fp32 accumulation, one rounding of the result); weight (ce, 8, 3, 3) and bias (ce) fp32 as the state dict holds them. */
+int evfly_op_grouped_conv_gelu(const void *x, int n, int h, int w, int ce, const float *weight, const float *bias, void *y,
+                               int bf16, void *stream);
+
 /* Tail of VelPredictor.forward learner/learner_models.py:309-334 for num_out 1 / 2 (3 is the identity):
  * y (rows, num_out) -> vel (rows, 3) = [sqrt(clip(1 - y^2, 0, 1)), y, 0]  /  [sqrt(clip(1 - y0^2 - y1^2, 0, 1)), y0, y1]. */
 int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, float *vel, void *stream);

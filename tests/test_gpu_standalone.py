@@ -140,3 +140,36 @@ def test_tap_of_partial_encoder_map_is_an_error(gpu_device):
     assert net.hip().tap("e5").shape == (1, 8, 13, 512)
     with pytest.raises(RuntimeError, match="partial"):
         net.hip().tap("e2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(5, 15, 23, 128), (7, 8, 12, 256), (3, 9, 10, 64), (2, 5, 3, 32), (4, 1, 7, 32), (1, 30, 45, 32)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_op_grouped_conv_gelu(gpu_device, shape, bf16):
+    """MixFFN's middle (ViTsubmodules.py:92-116: grouped 3x3 conv, groups of 8, + erf-GELU) through evfly_op_grouped_conv_gelu:
+    the 4x4 MFMA kernel (ragged strips, odd heights, frames past the tile) against torch's conv2d + gelu. fp32: the fp32
+    bar of DESIGN section 4; bf16: operands rounded to bf16, fp32 accumulation, one rounding of the result."""
+    import torch.nn.functional as F
+    from evfly_amd import _lib
+    n, h, w, ce = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, h, w, ce, generator=g)
+    wt = torch.randn(ce, 8, 3, 3, generator=g) * (2.0 / 72) ** 0.5
+    b = torch.randn(ce, generator=g) * 0.1
+    xd = x.to(gpu_device)
+    xi = xd.to(torch.bfloat16) if bf16 else xd
+    y = torch.empty_like(xi)
+    L = _lib.lib()
+    wd, bd = wt.to(gpu_device), b.to(gpu_device)
+    _lib.check(L.evfly_op_grouped_conv_gelu(_lib.ptr(xi), n, h, w, ce, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), int(bf16), _lib.cur_stream()))
+    torch.cuda.synchronize()
+    xr = xi.float().cpu() if bf16 else x
+    wr = wt.to(torch.bfloat16).float() if bf16 else wt
+    ref = F.gelu(F.conv2d(xr.permute(0, 3, 1, 2).double(), wr.double(), b.double(), padding=1, groups=ce // 8)).permute(0, 2, 3, 1)
+    err = ((y.float().cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < (6e-3 if bf16 else 2e-6), err
+    # the same call again: bit-identical
+    y2 = torch.empty_like(xi)
+    _lib.check(L.evfly_op_grouped_conv_gelu(_lib.ptr(xi), n, h, w, ce, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y2), int(bf16), _lib.cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16 if bf16 else torch.int32), y2.view(torch.int16 if bf16 else torch.int32))
