@@ -1,6 +1,11 @@
 // Frame conditioning (gfx950): uint8 decode, centre crop, exact per-frame quantile of |v| by
 // LDS radix select (no sort), scale + clip. One 1024-thread block per frame; the frame is
 // re-read from L2 for each of the three select passes (11 + 11 + 10 key bits; 360 KB at 260x346).
+// Histogram updates are plain LDS atomics (ds_add_u32, no return value) into FOUR copies of every bin (copy = lane & 3,
+// adjacent banks): event frames hold few distinct values, so the lanes of a wave mostly hit one bin -- the copies cut that
+// serialisation by four inside the LDS unit, and a pixel costs ~8 instructions per pass. (Round 2 aggregated equal bins
+// per wave with ballot / shuffle loops: ~100 wave instructions per 64 pixels and pass, instruction-issue bound at 0.31 ms
+// per 320 frames.)
 //
 // Replaces evfly_ros/run.py:334-336,345-350,247-253 (twins envtest/ros/run_competition.py:485-495,
 // learner/dataloading.py:512-523).
@@ -14,6 +19,7 @@ constexpr int kCondThreads = 1024;
 constexpr int kCondBins = 2048;     // 11 key bits per select pass (three passes over the frame instead of four 8-bit ones)
 constexpr int kBatch = 6;   // columns fetched per lane before binning (6 x 64 >= 346)
 constexpr int kRows = 2;    // rows fetched per wave before binning
+constexpr int kFlat = 6;    // 16-B vectors fetched per thread before binning (uncropped fp32 frames)
 
 struct CondArgs {
     const uint8_t *u8;
@@ -29,12 +35,15 @@ __device__ __forceinline__ float cond_load(const CondArgs &a, int frame, int r, 
     return a.f32[src];
 }
 
-__global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned hist[2][kCondBins];
+// (<= 64 registers: two 1024-thread blocks per CU, so that 320 frames are resident at once on 256 CUs)
+__global__ __launch_bounds__(kCondThreads, 8) void k_condition(CondArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned hist[2][kCondBins][4];
     __shared__ unsigned prefix[2], kth[2], wsum[16];
     const int frame = blockIdx.x;
     const int n_px = a.out_h * a.out_w;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool flat = a.f32 && a.in_w == a.out_w && a.in_h == a.out_h && (n_px & 3) == 0 && ((uintptr_t)a.f32 & 15) == 0 &&
+                      ((uintptr_t)a.dst & 15) == 0;
     float q = 1.0f;
     if (a.quantile > 0.0f) {
         // torch.quantile (linear): rank = q * (n-1) in fp32, below = floor, above = ceil,
@@ -46,18 +55,44 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
             kth[0] = (unsigned)below;
             kth[1] = (unsigned)ceilf(rank);
         }
+        __syncthreads();
         for (int pass = 0; pass < 3; ++pass) {
             // key bits [31:21], [20:10], [9:0] of |v| (bit 31 is 0)
             const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0, bits = pass == 2 ? 10 : 11;
-            for (int i = threadIdx.x; i < 2 * kCondBins; i += kCondThreads) (&hist[0][0])[i] = 0u;
-            __syncthreads();
             const unsigned p0 = prefix[0], p1 = prefix[1];
-            // wave w walks rows w, w+16, ...; lanes walk the columns (no per-element division). Trip counts are
-            // wave-uniform: the ballots below need the whole wave.
+            const bool same = p0 == p1;                              // both ranks still in one bin: one histogram serves both
+            for (int i = threadIdx.x; i < (same ? 1 : 2) * kCondBins; i += kCondThreads)
+                reinterpret_cast<uint4 *>(&hist[0][0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+            auto bin = [&](float v, bool live) {
+                const unsigned key = __float_as_uint(fabsf(v));
+                const unsigned hi = pass == 0 ? 0u : key >> (shift + bits);
+                const unsigned byte = (key >> shift) & ((1u << bits) - 1u);
+                if (live && hi == p0) atomicAdd(&hist[0][byte][lane & 3], 1u);
+                if (!same && live && hi == p1) atomicAdd(&hist[1][byte][lane & 3], 1u);
+            };
+            if (flat) {
+                // no crop, fp32 frames: the frame is one aligned array -- kFlat 16-B loads in flight per thread, then binned
+                const float4 *src = reinterpret_cast<const float4 *>(a.f32 + (int64_t)frame * n_px);
+                const int n4 = n_px >> 2;
+                for (int i0 = threadIdx.x; i0 < n4; i0 += kFlat * kCondThreads) {
+                    float4 v[kFlat];
+#pragma unroll
+                    for (int k = 0; k < kFlat; ++k) {
+                        const int i = i0 + k * kCondThreads;
+                        v[k] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kFlat; ++k) {
+                        const bool live = i0 + k * kCondThreads < n4;
+                        bin(v[k].x, live); bin(v[k].y, live); bin(v[k].z, live); bin(v[k].w, live);
+                    }
+                }
+            } else
+            // wave w walks rows w, w+16, ...; lanes walk the columns (no per-element division).
             // two rows (kRows x kBatch loads) are in flight per iteration: the walk is L2-latency bound
             for (int r0 = wave; r0 < a.out_h; r0 += kRows * (kCondThreads / 64))
               for (int c0 = 0; c0 < a.out_w; c0 += 64 * kBatch) {
-                // (ballots / LDS atomics keep hipcc from pipelining the loop: fetch the batch first, then bin it)
                 float vals[kRows][kBatch];
 #pragma unroll
                 for (int rr = 0; rr < kRows; ++rr) {
@@ -72,29 +107,7 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
                 for (int rr = 0; rr < kRows; ++rr) {
                 const bool row_live = r0 + rr * (kCondThreads / 64) < a.out_h;           // wave-uniform
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) {
-                    const bool live = row_live && c0 + 64 * k + lane < a.out_w;
-                    const unsigned key = live ? __float_as_uint(fabsf(vals[rr][k])) : 0u;
-                    unsigned hi = pass == 0 ? 0u : key >> (shift + bits);
-                    if (!live) hi = 0xffffffffu;                     // matches no prefix (prefixes have < 32 bits)
-                    const unsigned byte = (key >> shift) & ((1u << bits) - 1u);
-                    // wave-aggregated histogram update: event frames have few distinct values (k * 0.2), so most
-                    // lanes of a wave hit the same bin; one atomic per distinct (target, byte), not one per lane
-                    unsigned tag = (hi == p0 ? 0x800u : 0u) | (hi == p1 ? 0x1000u : 0u);
-                    tag = tag ? (tag | byte) : 0u;
-                    unsigned long long todo = __ballot(tag != 0u);
-                    while (todo) {
-                        const int leader = __ffsll((long long)todo) - 1;
-                        const unsigned t = __shfl(tag, leader);
-                        const unsigned long long same = __ballot(tag == t);
-                        if (lane == leader) {
-                            const unsigned c = (unsigned)__popcll(same);
-                            if (t & 0x800u) atomicAdd(&hist[0][t & 0x7ffu], c);
-                            if (t & 0x1000u) atomicAdd(&hist[1][t & 0x7ffu], c);
-                        }
-                        todo &= ~same;
-                    }
-                }
+                for (int k = 0; k < kBatch; ++k) bin(vals[rr][k], row_live && c0 + 64 * k + lane < a.out_w);
                 }
               }
             __syncthreads();
@@ -102,7 +115,12 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
             // inclusive scan + the eight wave totals through LDS (a single lane walking the bins was a 25 k-cycle dependent
             // chain of LDS reads per pass with the other 1022 threads parked at the barrier)
             const int j = threadIdx.x >> 9, b4 = (threadIdx.x & 511) * 4;
-            const uint4 c4 = *reinterpret_cast<const uint4 *>(&hist[j][b4]);
+            uint4 c4;
+            {
+                const uint4 *hp = reinterpret_cast<const uint4 *>(&hist[same ? 0 : j][b4][0]);      // four bins x four copies
+                const uint4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
+                c4 = make_uint4(h0.x + h0.y + h0.z + h0.w, h1.x + h1.y + h1.z + h1.w, h2.x + h2.y + h2.z + h2.w, h3.x + h3.y + h3.z + h3.w);
+            }
             const unsigned kk = kth[j], mine = c4.x + c4.y + c4.z + c4.w;
             unsigned incl = mine;
 #pragma unroll
@@ -138,6 +156,32 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
     // iteration, hipcc waits for every load -- and with it for the previous store's acknowledgement: ~90 serialised memory
     // round trips per thread and frame)
     float *dst = a.dst + (int64_t)frame * n_px;
+    auto scale = [&](float v) {
+        if (a.quantile > 0.0f) {
+            v = v / q;                                   // run.py:253; IEEE division (0/0 = NaN survives)
+            v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);  // torch.clip keeps NaN
+        }
+        return v;
+    };
+    if (flat) {
+        const float4 *src = reinterpret_cast<const float4 *>(a.f32 + (int64_t)frame * n_px);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        const int n4 = n_px >> 2;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += kFlat * kCondThreads) {
+            float4 v[kFlat];
+#pragma unroll
+            for (int k = 0; k < kFlat; ++k) {
+                const int i = i0 + k * kCondThreads;
+                v[k] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < kFlat; ++k) {
+                const int i = i0 + k * kCondThreads;
+                if (i < n4) d4[i] = make_float4(scale(v[k].x), scale(v[k].y), scale(v[k].z), scale(v[k].w));
+            }
+        }
+        return;
+    }
     for (int r = wave; r < a.out_h; r += kCondThreads / 64)
         for (int c0 = 0; c0 < a.out_w; c0 += 64 * kBatch) {
             float vals[kBatch];
@@ -149,12 +193,7 @@ __global__ __launch_bounds__(kCondThreads) void k_condition(CondArgs a) {
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
                 const int c = c0 + 64 * k + lane;
-                float v = vals[k];
-                if (a.quantile > 0.0f) {
-                    v = v / q;                                   // run.py:253; IEEE division (0/0 = NaN survives)
-                    v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);  // torch.clip keeps NaN
-                }
-                if (c < a.out_w) dst[r * a.out_w + c] = v;
+                if (c < a.out_w) dst[r * a.out_w + c] = scale(vals[k]);
             }
         }
 }
