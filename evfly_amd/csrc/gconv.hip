@@ -20,7 +20,7 @@
 #include "bf16.h"
 
 // Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 no tile DMA, 2 no stores, 4 no GELU,
-// 8 no MFMAs. The shipped library is built with 0.
+// 8 no MFMAs, 16 no LDS window reads. The shipped library is built with 0.
 #ifndef EVFLY_GM_ABL
 #define EVFLY_GM_ABL 0
 #endif
@@ -206,6 +206,7 @@ template <typename T> struct GcWin;
 template <> struct GcWin<float> {
     float v[8];
     __device__ __forceinline__ void load(const unsigned char *p) {
+        if constexpr (kGmAbl & 16) { for (int e = 0; e < 8; ++e) v[e] = 1.f + e; asm volatile("" : "+v"(v[0]), "+v"(v[4])); return; }
         const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 16);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
@@ -213,6 +214,7 @@ template <> struct GcWin<float> {
 template <> struct GcWin<bf16_t> {
     gc_s16x4 v[2];
     __device__ __forceinline__ void load(const unsigned char *p) {
+        if constexpr (kGmAbl & 16) { v[0] = gc_s16x4{(short)0x3f80, (short)0x3f80, (short)0x4000, (short)0x4000}; v[1] = v[0]; asm volatile("" : "+v"(v[0]), "+v"(v[1])); return; }
         const uint4 a = *reinterpret_cast<const uint4 *>(p);
         v[0] = *reinterpret_cast<const gc_s16x4 *>(&a.x); v[1] = *reinterpret_cast<const gc_s16x4 *>(&a.z);
     }

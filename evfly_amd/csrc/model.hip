@@ -934,6 +934,16 @@ static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W,
         float *x1 = m->alloc_act(rows * C);   // x = x + attn(x)   (:144)
         if (int rc = linear(m, "vit_linear", NL + "fin", att, rows, C, C, C, ACT_NONE, xcur, C, x1, C, a16 ? (IO16 | RES16) : 0)) return rc;
         // --- MixFFN (:98-120)
+        const bool last = l == c.vit_layers[s] - 1;
+        float *xn = (last && y_out) ? y_out : m->alloc_act(rows * C);
+        if (!a16 && mixffn_fused_fits(h, w, C, E)) {
+            // x = LayerNorm(x + ffn(x)) in one kernel, the hidden tensor in LDS (mitblock.hip)
+            RUN(m, "vit_mixffn_fused", 2.0 * rows * E * (2.0 * C + 72), 8.0 * rows * C,
+                launch_mixffn_fused(x1, n, h, w, C, E, m->W(NL + "mlp1.w"), m->W(NL + "mlp1.b"), m->W(NL + "dw.wp"), m->W(NL + "dw.b"),
+                                    m->W(NL + "mlp2.w"), m->W(NL + "mlp2.b"), m->W(NL + "ln.g"), m->W(NL + "ln.beta"), xn, st));
+            xcur = xn;
+            continue;
+        }
         float *h1 = m->alloc_act(rows * E);
         if (int rc = linear(m, "vit_linear", NL + "mlp1", x1, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E, io)) return rc;
         float *h2 = m->alloc_act(rows * E);
@@ -948,8 +958,6 @@ static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W,
             launch_grouped_conv_gelu(h1, n, h, w, E, m->W(NL + "dw.w"), m->W(NL + "dw.b"), h2, st));
         float *x2 = m->alloc_act(rows * C);   // x = x + ffn(x)    (:145)
         if (int rc = linear(m, "vit_linear", NL + "mlp2", h2, rows, E, E, C, ACT_NONE, x1, C, x2, C, a16 ? (IO16 | RES16) : 0)) return rc;
-        const bool last = l == c.vit_layers[s] - 1;
-        float *xn = (last && y_out) ? y_out : m->alloc_act(rows * C);
         if (int rc = layernorm(x2, rows, NL + "ln.g", NL + "ln.beta", xn)) return rc;
         xcur = xn;
     }
