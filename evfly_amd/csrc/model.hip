@@ -936,14 +936,6 @@ static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W,
         // --- MixFFN (:98-120)
         const bool last = l == c.vit_layers[s] - 1;
         float *xn = (last && y_out) ? y_out : m->alloc_act(rows * C);
-        if (!a16 && mixffn_fused_fits(h, w, C, E)) {
-            // x = LayerNorm(x + ffn(x)) in one kernel, the hidden tensor in LDS (mitblock.hip)
-            RUN(m, "vit_mixffn_fused", 2.0 * rows * E * (2.0 * C + 72), 8.0 * rows * C,
-                launch_mixffn_fused(x1, n, h, w, C, E, m->W(NL + "mlp1.w"), m->W(NL + "mlp1.b"), m->W(NL + "dw.wp"), m->W(NL + "dw.b"),
-                                    m->W(NL + "mlp2.w"), m->W(NL + "mlp2.b"), m->W(NL + "ln.g"), m->W(NL + "ln.beta"), xn, st));
-            xcur = xn;
-            continue;
-        }
         float *h1 = m->alloc_act(rows * E);
         if (int rc = linear(m, "vit_linear", NL + "mlp1", x1, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E, io)) return rc;
         float *h2 = m->alloc_act(rows * E);

@@ -48,12 +48,6 @@ int launch_grouped_conv_gelu(const float *x, int n, int H, int W, int Ce, const 
 bool gconv_fits(int H, int W, int Ce);
 void gconv_pack_host(const float *w, int Ce, float *out);
 int gconv_pack_device(const float *w, int Ce, float *out, hipStream_t st);
-// mitblock.hip: y = LayerNorm(x1 + mlp2(GELU(grouped3x3(mlp1(x1))))) of one Mix-Transformer block, one workgroup per frame with the
-// tokens and the hidden tensor in LDS (fp32, C in {32, 64}, E % 32 == 0, H x W tokens that fit one CU's LDS). W1 (E, C), W2 (C, E)
-// row-major, wp = gconv_pack_host(depthwise.weight).
-bool mixffn_fused_fits(int H, int W, int C, int E);
-int launch_mixffn_fused(const float *x1, int n, int H, int W, int C, int E, const float *W1, const float *b1, const float *wp, const float *dwb,
-                        const float *W2, const float *b2, const float *ln_g, const float *ln_b, float *y, hipStream_t st);
 int launch_gconv_gelu(const void *x, int n, int H, int W, int Ce, const float *wp, const float *bias, void *y, bool bf16, hipStream_t st);
 int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st);
 // x517 assembly (vitfly_models.py:144): cols [512] = desvel/10, [513..516] = quat (or 1,0,0,0), rest of the pad 0
