@@ -85,6 +85,11 @@ def _assert_bf16_close(got, ref):
     (5, 12, 70, 64, 32, 3, 1, 0, 1, False),
     (300, 10, 36, 32, 32, 3, 1, 0, 1, False),    # more tiles than persistent blocks: every block walks several tiles
     (2, 72, 152, 64, 32, 3, 1, 0, 1, False),     # d41's geometry
+    # large-M problems (thousands of tiles, ragged last M tile, every XCD slot many times over)
+    (70, 60, 81, 128, 128, 3, 1, 0, 1, False),   # e32's geometry at 70 frames
+    (200, 27, 37, 128, 256, 3, 1, 1, 0, True),   # padding + residual
+    (300, 29, 39, 128, 256, 3, 1, 0, 1, False),  # e41's geometry
+    (100, 45, 45, 512, 128, 1, 1, 0, 2, True),   # Linear K = 512 + residual
 ])
 def test_conv_bf16_pipeline_kernel(gpu_device, case):
     n, h, w, cin, cout, k, stride, pad, act, with_res = case
