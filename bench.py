@@ -183,15 +183,17 @@ def main():
     n_events = int(batch["offsets"][-1])
     del batch
     desvel = torch.full((B * T, 1), 4.0, device="cuda")                            # run.py:255
-    frames = torch.empty(B, T, Hs, Ws, device="cuda")
+    # sensor larger than the model's 260 x 346 (C3): the centre crop of run.py:345-350 is the voxelizer's region of interest
+    roi = None if (Hs, Ws) == (H, W) else voxelizer.centre_crop_roi(Hs, Ws, (H, W))
+    frames = torch.empty(B, T, H, W, device="cuda")
     counts = shard_row_counts(world * B, world, T)                                  # every rank: B streams (weak scaling)
     vel_host = torch.empty(world * B * T, 3).pin_memory() if composite else None    # §8d: "velocity rows on host-visible memory"
     hip = model.hip()
     L = hip._L
 
     def step():
-        voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames)
-        x = voxelizer.condition_frames(frames.view(B * T, Hs, Ws), out_hw=(H, W))    # centre crop when the sensor is larger
+        voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi)
+        x = voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W))
         if not composite:                                                             # C5: depth maps stay in HBM
             depth, _, _ = model.forward_streams(x, None, B, T)
             return depth
@@ -253,9 +255,9 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     with torch.no_grad():
-        vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames))
-        cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, Hs, Ws), out_hw=(H, W)))
-    vox_bytes = 13.0 * n_events + 4.0 * B * T * Hs * Ws        # read events once, write frames once
+        vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi))
+        cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W)))
+    vox_bytes = 13.0 * n_events + 4.0 * B * T * H * W          # read events once, write the (cropped) frames once
 
     def families(recs):
         fam = {}
@@ -273,7 +275,7 @@ def main():
     ms_per_step = 1e3 * dt / a.steps
     trunk = "reference-size ViT" if cfg["vit"] == "tiny" else "ViT-base trunk (widths 128/256, heads 4/8, 4+4 layers)"
     what = (f"OrigUNet+ConvLSTM -> LSTMNetVIT ({trunk})" if composite else "OrigUNet+ConvLSTM only (depth)")
-    crop = "" if (Hs, Ws) == (H, W) else f" voxelized at {Hs}x{Ws}, centre-cropped to 260x346,"
+    crop = "" if (Hs, Ws) == (H, W) else f" voxelized at {Hs}x{Ws}, centre-cropped to 260x346 (the voxelizer's region of interest),"
     out = {
         "metric": "event-frames/sec (260x346, 5 bins) event->depth->velocity fwd (voxelize + U-Net/ConvLSTM + ViT/LSTM)",
         "value": round(frames_per_step * a.steps / dt, 2), "unit": "event-frames/s",
@@ -358,7 +360,7 @@ def main():
             fper = B * T
             rates = {"v_only": {"frames_per_s": round(fper / ((vox_ms + cond_ms) * 1e-3), 1), "ms": round(vox_ms + cond_ms, 4), "what": "voxelize + crop/q97 conditioning"}}
             with torch.no_grad():
-                x = voxelizer.condition_frames(frames.view(B * T, Hs, Ws), out_hw=(H, W))
+                x = voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W))
                 unet = model.origunet if composite else model
                 unet.set_compute_dtype(dtype)
                 d_ms = time_stage(lambda: unet.forward_streams(x, None, B, T), reps=3)
@@ -381,7 +383,7 @@ def main():
             one_ms = None
             if not a.no_stage_rates:
                 with torch.no_grad():
-                    x1 = voxelizer.condition_frames(frames.view(B * T, Hs, Ws)[:T], out_hw=(H, W))
+                    x1 = voxelizer.condition_frames(frames.view(B * T, H, W)[:T], out_hw=(H, W))
                     one_ms = time_stage(lambda: model.forward_streams(x1, None, 1, T), reps=5)
             out["convlstm"] = {"serial_critical_path_ms_per_step": round(serial, 3), "steps_in_series": T,
                                "batched_input_gemm_ms_per_step": round(xg, 3),

@@ -48,6 +48,8 @@ SIGNATURES = {
     "evfly_last_error": (C.c_char_p, []),
     "evfly_voxelize_windows": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_d, c_d,
                                      c_p, c_p, c_p, c_p]),
+    "evfly_voxelize_windows_roi": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d,
+                                         c_p, c_p, c_p, c_p]),
     "evfly_eventframe_rows_f64": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_d, c_d, c_i64, c_d, c_d,
                                         c_p, c_p, c_p, c_p]),
     "evfly_accumulate_u8": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),

@@ -88,6 +88,7 @@ struct VoxArgs {
     const int *unsorted;
     int64_t n_total;
     int n_streams, T, H, W, pol_mode, rows_per_band, n_bands, n_frames;
+    int rtop, rleft, RH, RW;      // region of interest of the H x W histogram that is accumulated and written: frames are (RH, RW)
     double pos_thresh, neg_thresh;
     float *f32;
     double *f64;
@@ -126,9 +127,9 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
         lo = s0; hi = s1;
     }
 
-    const int r0 = band * a.rows_per_band;
-    const int r1 = min(a.H, r0 + a.rows_per_band);
-    const int cells = (r1 - r0) * a.W;
+    const int r0 = band * a.rows_per_band;                 // band rows [r0, r1) of the region of interest
+    const int r1 = min(a.RH, r0 + a.rows_per_band);
+    const int cells = (r1 - r0) * a.RW;
     const int words = GENERAL ? 2 * cells : cells;
     for (int i = threadIdx.x; i < words; i += kVoxThreads) lds[i] = 0u;
     __syncthreads();
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
             const unsigned ey = (ys[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
             const int ep = (int)(int8_t)(((k < 4 ? pv.x : pv.y) >> ((k & 3) * 8)) & 0xffu);
             // np.histogram2d: the right-most edge is inclusive (x == W counts in column W-1)
-            const int cx = min((int)ex, a.W - 1), cy = min((int)ey, a.H - 1);
-            bool ok = (i >= lo) && (i < hi) && (int)ex <= a.W && (int)ey <= a.H && cy >= r0 && cy < r1;
+            // (the region of interest is cut out of that histogram: bins first, then the crop, as run.py:345-350 does)
+            const int cx = min((int)ex, a.W - 1) - a.rleft, cy = min((int)ey, a.H - 1) - a.rtop;
+            bool ok = (i >= lo) && (i < hi) && (int)ex <= a.W && (int)ey <= a.H && cy >= r0 && cy < r1 && cx >= 0 && cx < a.RW;
             if (GENERAL && timed && ok) {
                 const int64_t tt = a.t[i];
                 ok = (tt >= e0) && (tt < e1);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
             const bool pos = ep > 0;
             const bool neg = a.pol_mode == EVFLY_POL_PM1 ? (ep < 0) : (ep == 0);
             if (ok && (pos || neg)) {
-                const int cell = (cy - r0) * a.W + cx;
+                const int cell = (cy - r0) * a.RW + cx;
                 if (GENERAL) atomicAdd(&lds[pos ? cell : cells + cell], 1u);
                 else atomicAdd(&lds[cell], pos ? 1u : 0x10000u);
             }
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
     }
     __syncthreads();
 
-    const int64_t fbase = (int64_t)frame * a.H * a.W + (int64_t)r0 * a.W;
+    const int64_t fbase = (int64_t)frame * a.RH * a.RW + (int64_t)r0 * a.RW;
     for (int i = threadIdx.x; i < cells; i += kVoxThreads) {
         unsigned P, N;
         if (GENERAL) { P = lds[i]; N = lds[cells + i]; }
@@ -188,9 +190,9 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
         if (a.f32) a.f32[fbase + i] = (float)f;
         if (a.f64) a.f64[fbase + i] = f;
         if (a.counts) {
-            const int64_t cb = (int64_t)frame * 2 * a.H * a.W + (int64_t)r0 * a.W + i;
+            const int64_t cb = (int64_t)frame * 2 * a.RH * a.RW + (int64_t)r0 * a.RW + i;
             a.counts[cb] = (int32_t)P;
-            a.counts[cb + (int64_t)a.H * a.W] = (int32_t)N;
+            a.counts[cb + (int64_t)a.RH * a.RW] = (int32_t)N;
         }
     }
 }
@@ -396,14 +398,27 @@ extern "C" int evfly_voxelize_windows(const uint16_t *x, const uint16_t *y, cons
                                       const int64_t *window_edges, int n_windows, int height, int width,
                                       int polarity_mode, double pos_thresh, double neg_thresh, float *frames_f32,
                                       double *frames_f64, int32_t *counts_i32, void *stream) {
+    return evfly_voxelize_windows_roi(x, y, t, p, n_events, stream_offsets, n_streams, window_edges, n_windows, height, width, 0, 0, height,
+                                      width, polarity_mode, pos_thresh, neg_thresh, frames_f32, frames_f64, counts_i32, stream);
+}
+
+extern "C" int evfly_voxelize_windows_roi(const uint16_t *x, const uint16_t *y, const int64_t *t, const int8_t *p,
+                                          int64_t n_events, const int64_t *stream_offsets, int n_streams,
+                                          const int64_t *window_edges, int n_windows, int height, int width, int roi_top,
+                                          int roi_left, int roi_height, int roi_width, int polarity_mode, double pos_thresh,
+                                          double neg_thresh, float *frames_f32, double *frames_f64, int32_t *counts_i32,
+                                          void *stream) {
     EVFLY_REQUIRE(n_streams > 0 && n_windows > 0 && height > 0 && width > 0, "voxelize: empty geometry");
+    EVFLY_REQUIRE(roi_top >= 0 && roi_left >= 0 && roi_height > 0 && roi_width > 0 && roi_top + roi_height <= height &&
+                  roi_left + roi_width <= width, "voxelize: region of interest (%d, %d, %d, %d) outside the %d x %d histogram", roi_top,
+                  roi_left, roi_height, roi_width, height, width);
     EVFLY_REQUIRE(n_events >= 0, "voxelize: negative event count");
     EVFLY_REQUIRE(polarity_mode == EVFLY_POL_PM1 || polarity_mode == EVFLY_POL_01, "voxelize: bad polarity_mode %d",
                   polarity_mode);
     EVFLY_REQUIRE(((uintptr_t)x | (uintptr_t)y | (uintptr_t)t | (uintptr_t)p) % 16 == 0,
                   "voxelize: x, y, t, p must be 16-byte aligned");
     EVFLY_REQUIRE(stream_offsets && window_edges, "voxelize: null offsets / edges");
-    EVFLY_REQUIRE((int64_t)width * 4 <= kMaxLds / 2, "voxelize: width %d too large for one LDS row band", width);
+    EVFLY_REQUIRE((int64_t)roi_width * 4 <= kMaxLds / 2, "voxelize: width %d too large for one LDS row band", roi_width);
     hipStream_t st = as_stream(stream);
     const int n_frames = n_streams * n_windows;
 
@@ -430,12 +445,13 @@ extern "C" int evfly_voxelize_windows(const uint16_t *x, const uint16_t *y, cons
     a.unsorted = unsorted; a.n_total = n_events; a.n_streams = n_streams; a.T = n_windows; a.H = height; a.W = width;
     a.pol_mode = polarity_mode; a.n_frames = n_frames; a.pos_thresh = pos_thresh; a.neg_thresh = neg_thresh;
     a.f32 = frames_f32; a.f64 = frames_f64; a.counts = counts_i32;
+    a.rtop = roi_top; a.rleft = roi_left; a.RH = roi_height; a.RW = roi_width;
     const int groups = cdiv(n_frames, kNumXCD);
     for (int general = 0; general < 2; ++general) {
-        const int bytes_per_row = width * (general ? 8 : 4);
+        const int bytes_per_row = roi_width * (general ? 8 : 4);
         const int rows_max = kMaxLds / bytes_per_row;
-        a.n_bands = cdiv(height, rows_max);
-        a.rows_per_band = cdiv(height, a.n_bands);
+        a.n_bands = cdiv(roi_height, rows_max);
+        a.rows_per_band = cdiv(roi_height, a.n_bands);
         const int lds_bytes = (int)align_up((size_t)a.rows_per_band * bytes_per_row, 16);
         const dim3 grid(groups * kNumXCD * a.n_bands);
         if (general) {

@@ -29,11 +29,24 @@ def upload_events(batch):
                 offsets=_dev(batch["offsets"], torch.int64), edges=_dev(batch["edges"], torch.int64))
 
 
-def voxelize_windows(ev, H, W, polarity="pm1", pos_thresh=0.2, neg_thresh=0.2, out="f32", frames=None):
+def centre_crop_roi(H, W, out_hw):
+    """(top, left, h, w) of evfly_ros/run.py:349-350's centre crop `[H//2 - h//2 : H//2 + h//2, W//2 - w//2 : W//2 + w//2]`."""
+    h, w = out_hw
+    if h % 2 or w % 2:
+        raise ValueError("run.py's centre crop takes h // 2 rows / w // 2 columns on either side: even sizes only")
+    return (0 if h == H else H // 2 - h // 2, 0 if w == W else W // 2 - w // 2, h, w)
+
+
+def voxelize_windows(ev, H, W, polarity="pm1", pos_thresh=0.2, neg_thresh=0.2, out="f32", frames=None, roi=None):
     """ev: dict of device tensors x,y (u16 bits in int16), t i64, p i8, offsets (B+1), edges (B,T+1).
     out: "f32" | "f64" | "counts" or a tuple of them. Returns the requested device tensors
-    (B,T,H,W) / (B,T,2,H,W) in that order. `frames` may pre-supply the f32 output buffer."""
+    (B,T,H,W) / (B,T,2,H,W) in that order. `frames` may pre-supply the f32 output buffer.
+    roi = (top, left, h, w): only that region of every (H, W) histogram is accumulated and returned ((B,T,h,w) tensors) --
+    the crop of run.py:345-350 (`centre_crop_roi`) folded into the voxelizer; identical to slicing the full frames."""
     L = _lib.lib()
+    top, left, rh, rw = (0, 0, H, W) if roi is None else (int(v) for v in roi)
+    Hf, Wf = H, W
+    H, W = rh, rw
     outs = (out,) if isinstance(out, str) else tuple(out)
     B = ev["offsets"].numel() - 1
     T = ev["edges"].shape[-1] - 1
@@ -48,10 +61,11 @@ def voxelize_windows(ev, H, W, polarity="pm1", pos_thresh=0.2, neg_thresh=0.2, o
             bufs[o] = torch.empty(B, T, 2, H, W, device=dev, dtype=torch.int32)
         else:
             raise ValueError(o)
-    _lib.check(L.evfly_voxelize_windows(_lib.ptr(ev["x"]), _lib.ptr(ev["y"]), _lib.ptr(ev["t"]), _lib.ptr(ev["p"]),
-                                        ev["x"].numel(), _lib.ptr(ev["offsets"]), B, _lib.ptr(ev["edges"]), T, H, W,
-                                        POL[polarity], float(pos_thresh), float(neg_thresh), _lib.ptr(bufs["f32"]),
-                                        _lib.ptr(bufs["f64"]), _lib.ptr(bufs["counts"]), _lib.cur_stream()))
+    _lib.check(L.evfly_voxelize_windows_roi(_lib.ptr(ev["x"]), _lib.ptr(ev["y"]), _lib.ptr(ev["t"]), _lib.ptr(ev["p"]),
+                                            ev["x"].numel(), _lib.ptr(ev["offsets"]), B, _lib.ptr(ev["edges"]), T, Hf, Wf,
+                                            top, left, rh, rw, POL[polarity], float(pos_thresh), float(neg_thresh),
+                                            _lib.ptr(bufs["f32"]), _lib.ptr(bufs["f64"]), _lib.ptr(bufs["counts"]),
+                                            _lib.cur_stream()))
     res = tuple(bufs[o] for o in outs)
     return res[0] if isinstance(out, str) else res
 

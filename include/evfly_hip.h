@@ -63,6 +63,19 @@ int evfly_voxelize_windows(const uint16_t *x, const uint16_t *y, const int64_t *
                            float *frames_f32, double *frames_f64, int32_t *counts_i32,
                            void *stream);
 
+/* The same with a region of interest: the (height, width) histogram of every window is formed as above (bins first: an
+ * event at x == width still counts in column width - 1) and rows [roi_top, roi_top + roi_height), columns [roi_left,
+ * roi_left + roi_width) of it are written -- frames are (n_streams * n_windows, roi_height, roi_width), counts likewise.
+ * evfly_ros/run.py:345-350 crops the sensor-size event frame to the model's 260 x 346 before conditioning it; with the
+ * crop as the region of interest the rows and columns outside it are never accumulated or written (480 x 640 sensor:
+ * three LDS row bands per frame instead of eight). evfly_voxelize_windows == the region (0, 0, height, width). */
+int evfly_voxelize_windows_roi(const uint16_t *x, const uint16_t *y, const int64_t *t, const int8_t *p,
+                               int64_t n_events, const int64_t *stream_offsets, int n_streams,
+                               const int64_t *window_edges, int n_windows, int height, int width, int roi_top,
+                               int roi_left, int roi_height, int roi_width, int polarity_mode, double pos_thresh,
+                               double neg_thresh, float *frames_f32, double *frames_f64, int32_t *counts_i32,
+                               void *stream);
+
 /* Replaces form_eventframe utils/ev_utils.py:113-161 on its native input: `rows` is the (n, 4)
  * row-major float64 array [t_ns, x, y, p] (non-integer and out-of-range coordinates allowed;
  * np.histogram2d semantics incl. the inclusive right edge x == width).

@@ -81,6 +81,38 @@ def test_sensor_size_thresholds_and_01(gpu_device):
     assert np.array_equal(f64, ovox.signed_frame(want[:, :, 0], want[:, :, 1], 0.3, 0.1))
 
 
+@pytest.mark.parametrize("roi", ["centre", (0, 0, 480, 640), (477, 3, 3, 637), (100, 639, 64, 1)])
+def test_region_of_interest_equals_crop(gpu_device, roi):
+    """evfly_voxelize_windows_roi == slicing the full-size result (run.py:345-350 crops the sensor-size frame): the centre crop to
+    260x346, the whole frame, regions touching the last row / column (the inclusive right-most histogram edge lands in them), in
+    both kernels (a hot window > 65535 events and an unsorted stream included), f32 / f64 / counts."""
+    from evfly_amd import voxelizer
+    B, T, Hh, Ww = 3, 4, 480, 640
+    batch = syn.make_batch(B, T, Hh, Ww, events_per_window=30_000, seed_base=311)
+    rs = np.random.RandomState(5)
+    o0, o1 = int(batch["offsets"][0]), int(batch["offsets"][1])
+    perm = rs.permutation(o1 - o0) + o0                          # stream 0 unsorted
+    for k in ("x", "y", "t", "p"):
+        batch[k][o0:o1] = batch[k][perm]
+    batch["x"][::13] = Ww; batch["y"][::17] = Hh                 # on the inclusive edges
+    s1 = int(batch["offsets"][1]); e = batch["edges"][1]
+    hot = np.flatnonzero((batch["t"][s1:int(batch["offsets"][2])] >= e[1]) & (batch["t"][s1:int(batch["offsets"][2])] < e[2]))
+    assert hot.size > 20_000
+    ev = voxelizer.upload_events(batch)
+    f32, f64, cnt = voxelizer.voxelize_windows(ev, Hh, Ww, out=("f32", "f64", "counts"))
+    r = voxelizer.centre_crop_roi(Hh, Ww, (260, 346)) if roi == "centre" else roi
+    if roi == "centre":
+        assert r == (110, 147, 260, 346)
+    g32, g64, gcnt = voxelizer.voxelize_windows(ev, Hh, Ww, out=("f32", "f64", "counts"), roi=r)
+    t, l, h, w = r
+    assert g32.shape == (B, T, h, w) and gcnt.shape == (B, T, 2, h, w)
+    assert torch.equal(g32, f32[:, :, t:t + h, l:l + w]) and torch.equal(g64, f64[:, :, t:t + h, l:l + w])
+    assert torch.equal(gcnt, cnt[:, :, :, t:t + h, l:l + w])
+    assert int(gcnt.sum()) > 0
+    with pytest.raises(RuntimeError, match="region of interest"):
+        voxelizer.voxelize_windows(ev, Hh, Ww, roi=(300, 0, 200, 640))
+
+
 def test_unsorted_ragged_hot_and_empty(gpu_device):
     """General path: an unsorted stream, a window with > 65535 events, an empty stream, ragged
     lengths, events outside every window and outside the sensor."""
