@@ -713,17 +713,23 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             if (int rc = launch_f32_to_bf16(hs, (int64_t)S * rpi * hid, h16, st)) return rc;
         }
         for (int t = 0; t < T; ++t) {
+            // fresh streams (no incoming state): h0 = 0, so conv(h0) contributes exactly nothing to step 0 -- its GEMM is skipped
+            // and the cell reads zx[:, 0] in place
+            const bool skip0 = t == 0 && !h_state;
+            const float *zt = skip0 ? zx : z;
+            const int64_t zrows = skip0 ? (int64_t)T * rpi : 0;
             ConvDesc d; d.x = a16 ? h16 : hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W("clstm.wh"); d.ldw = hid;
             conv_finish(d); d.Nc = 4 * hid; d.y = z; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             d.res = zx + (int64_t)t * rpi * 4 * hid; d.ldres = 4 * hid; d.res_rpi = rpi; d.res_img_rows = (int64_t)T * rpi;
+            if (!skip0)
             RUN(m, "convlstm_h_gemm", igemm_flops(d), d.M * (a16 ? 2.0 : 4.0) * hid + d.M * 32.0 * hid + (a16 ? 2.0 : 4.0) * 4.0 * hid * hid,
                 igemm_launch(d, st));
             if (a16)
                 RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
-                    launch16_convlstm_gates(z, (int64_t)S * rpi, hid, cs, hs, h16, m->eoff(hseq, (int64_t)t * rpi * hid), rpi, (int64_t)T * rpi, st));
+                    launch16_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, h16, m->eoff(hseq, (int64_t)t * rpi * hid), rpi, (int64_t)T * rpi, st, zrows));
             else
             RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
-                launch_convlstm_gates(z, (int64_t)S * rpi, hid, cs, hs, hseq + (int64_t)t * rpi * hid, rpi, (int64_t)T * rpi, st));
+                launch_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, hseq + (int64_t)t * rpi * hid, rpi, (int64_t)T * rpi, st, zrows));
         }
         y5 = hseq;
         m->tap("e5_lstm", hseq, F, 8, 13, 512, a16);

@@ -241,12 +241,14 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 
 __global__ __launch_bounds__(256) void k_convlstm_gates(const float *__restrict__ z, int64_t rows, int hid,
                                                         float *__restrict__ c, float *__restrict__ h,
-                                                        float *__restrict__ h_copy, int rpi, int64_t copy_img_rows) {
+                                                        float *__restrict__ h_copy, int rpi, int64_t copy_img_rows, int64_t z_img_rows) {
     const int64_t total = rows * hid;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / hid;
         const int j = (int)(i - r * hid);
-        const float *zr = z + r * 4 * hid;
+        // z_img_rows > 0: the pre-activations are read in place from a [group][z_img_rows] tensor (zx of step 0: h0 = 0)
+        const int64_t zrow = z_img_rows > 0 ? (r / rpi) * z_img_rows + r % rpi : r;
+        const float *zr = z + zrow * 4 * hid;
         const float gi = sigmoidf_(zr[j]), gf = sigmoidf_(zr[hid + j]), go = sigmoidf_(zr[2 * hid + j]);
         const float gg = tanhf(zr[3 * hid + j]);                           // convlstm.py:44-48 (i, f, o, g)
         const float cn = gf * c[i] + gi * gg;                             // :50
@@ -663,9 +665,9 @@ int launch_crop(const float *x, int n, int Hi, int Wi, int C, int top, int left,
 }
 
 int launch_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, float *h_copy, int rpi,
-                          int64_t copy_img_rows, hipStream_t st) {
+                          int64_t copy_img_rows, hipStream_t st, int64_t z_img_rows) {
     hipLaunchKernelGGL(k_convlstm_gates, dim3(grid_for(rows * hid, 256)), dim3(256), 0, st, z, rows, hid, c, h, h_copy, rpi,
-                       copy_img_rows);
+                       copy_img_rows, z_img_rows);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

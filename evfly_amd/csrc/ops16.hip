@@ -141,13 +141,14 @@ __global__ __launch_bounds__(256) void k16_crop(const uint4 *__restrict__ x, int
 __device__ __forceinline__ float sigmoid16(float v) { return 1.0f / (1.0f + expf(-v)); }
 __global__ __launch_bounds__(256) void k16_convlstm_gates(const float *__restrict__ z, int64_t rows, int hid, float *__restrict__ c,
                                                            float *__restrict__ h, bf16_t *__restrict__ h16, bf16_t *__restrict__ h_copy,
-                                                           int rpi, int64_t copy_img_rows) {
+                                                           int rpi, int64_t copy_img_rows, int64_t z_img_rows) {
     const int h4 = hid / 4;
     const int64_t total = rows * h4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / h4;
         const int j = (int)(i - r * h4) * 4;
-        const float *zr = z + r * 4 * hid + j;
+        const int64_t zrow = z_img_rows > 0 ? (r / rpi) * z_img_rows + r % rpi : r;      // (k_convlstm_gates)
+        const float *zr = z + zrow * 4 * hid + j;
         const float4 zi = *reinterpret_cast<const float4 *>(zr), zf = *reinterpret_cast<const float4 *>(zr + hid);
         const float4 zo = *reinterpret_cast<const float4 *>(zr + 2 * hid), zg = *reinterpret_cast<const float4 *>(zr + 3 * hid);
         const float4 c0 = *reinterpret_cast<const float4 *>(c + r * hid + j);
@@ -463,10 +464,10 @@ int launch16_crop(const void *x, int n, int Hi, int Wi, int C, int top, int left
 }
 
 int launch16_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *h16, void *h_copy, int rpi,
-                            int64_t copy_img_rows, hipStream_t st) {
+                            int64_t copy_img_rows, hipStream_t st, int64_t z_img_rows) {
     EVFLY_REQUIRE(hid % 4 == 0, "gates16: hid %% 4");
     hipLaunchKernelGGL(k16_convlstm_gates, dim3(grid16(rows * hid / 4, 256)), dim3(256), 0, st, z, rows, hid, c, h, static_cast<bf16_t *>(h16),
-                       static_cast<bf16_t *>(h_copy), rpi, copy_img_rows);
+                       static_cast<bf16_t *>(h_copy), rpi, copy_img_rows, z_img_rows);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
