@@ -50,6 +50,9 @@ SIGNATURES = {
                                      c_p, c_p, c_p, c_p]),
     "evfly_voxelize_windows_roi": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d,
                                          c_p, c_p, c_p, c_p]),
+    "evfly_voxel_prepare": (c_i, [c_p, c_i64, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "evfly_voxelize_windows_prepared": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d,
+                                              c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "evfly_eventframe_rows_f64": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_d, c_d, c_i64, c_d, c_d,
                                         c_p, c_p, c_p, c_p]),
     "evfly_accumulate_u8": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),

@@ -408,7 +408,40 @@ extern "C" int evfly_voxelize_windows_roi(const uint16_t *x, const uint16_t *y, 
                                           int roi_left, int roi_height, int roi_width, int polarity_mode, double pos_thresh,
                                           double neg_thresh, float *frames_f32, double *frames_f64, int32_t *counts_i32,
                                           void *stream) {
+    return evfly_voxelize_windows_prepared(x, y, t, p, n_events, stream_offsets, n_streams, window_edges, n_windows, height, width, roi_top,
+                                           roi_left, roi_height, roi_width, polarity_mode, pos_thresh, neg_thresh, nullptr, nullptr, 0,
+                                           frames_f32, frames_f64, counts_i32, stream);
+}
+
+// Pass 1 on its own: the per-stream sortedness flags and the window -> event-range table depend on the timestamps and the
+// window edges only, i.e. they are a property of an uploaded batch, not of a voxelization call.
+extern "C" int evfly_voxel_prepare(const int64_t *t, int64_t n_events, const int64_t *stream_offsets, int n_streams,
+                                   const int64_t *window_edges, int n_windows, int *unsorted_out, int64_t *starts_out, void *stream) {
+    EVFLY_REQUIRE(n_streams > 0 && n_windows > 0 && n_events >= 0, "voxel_prepare: empty geometry");
+    EVFLY_REQUIRE(stream_offsets && window_edges && unsorted_out && starts_out, "voxel_prepare: null argument");
+    hipStream_t st = as_stream(stream);
+    EVFLY_HIP(hipMemsetAsync(unsorted_out, 0, (size_t)n_streams * 4, st));
+    if (n_events > 0) {
+        const int blocks = (int)std::min<int64_t>(8 * kNumCU, cdiv(cdiv(n_events, 4), 256));
+        hipLaunchKernelGGL(k_check_sorted, dim3(blocks), dim3(256), 0, st, t, n_events, stream_offsets, n_streams, unsorted_out);
+        EVFLY_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_window_ranges, dim3(cdiv(n_streams * (n_windows + 1), 128)), dim3(128), 0, st, t, stream_offsets, window_edges,
+                       n_streams, n_windows, starts_out);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t *y, const int64_t *t, const int8_t *p,
+                                               int64_t n_events, const int64_t *stream_offsets, int n_streams,
+                                               const int64_t *window_edges, int n_windows, int height, int width, int roi_top,
+                                               int roi_left, int roi_height, int roi_width, int polarity_mode, double pos_thresh,
+                                               double neg_thresh, const int *prepared_unsorted, const int64_t *prepared_starts,
+                                               int skip_kernels, float *frames_f32, double *frames_f64, int32_t *counts_i32,
+                                               void *stream) {
     EVFLY_REQUIRE(n_streams > 0 && n_windows > 0 && height > 0 && width > 0, "voxelize: empty geometry");
+    EVFLY_REQUIRE((prepared_unsorted == nullptr) == (prepared_starts == nullptr), "voxelize: pass both prepared tables or neither");
+    EVFLY_REQUIRE(skip_kernels >= 0 && skip_kernels <= 2 && (skip_kernels == 0 || prepared_starts), "voxelize: skip_kernels needs the prepared tables");
     EVFLY_REQUIRE(roi_top >= 0 && roi_left >= 0 && roi_height > 0 && roi_width > 0 && roi_top + roi_height <= height &&
                   roi_left + roi_width <= width, "voxelize: region of interest (%d, %d, %d, %d) outside the %d x %d histogram", roi_top,
                   roi_left, roi_height, roi_width, height, width);
@@ -422,23 +455,18 @@ extern "C" int evfly_voxelize_windows_roi(const uint16_t *x, const uint16_t *y, 
     hipStream_t st = as_stream(stream);
     const int n_frames = n_streams * n_windows;
 
-    // scratch: starts[n_streams*(T+1)] i64 | unsorted[n_streams] i32
-    void *scr = nullptr;
-    const size_t starts_bytes = align_up((size_t)n_streams * (n_windows + 1) * 8, 256);
-    if (int rc = scratch_get(starts_bytes + align_up((size_t)n_streams * 4, 256), &scr, st)) return rc;
-    int64_t *starts = (int64_t *)scr;
-    int *unsorted = (int *)((char *)scr + starts_bytes);
-    EVFLY_HIP(hipMemsetAsync(unsorted, 0, (size_t)n_streams * 4, st));
-
-    if (n_events > 0) {
-        const int blocks = (int)std::min<int64_t>(8 * kNumCU, cdiv(cdiv(n_events, 4), 256));
-        hipLaunchKernelGGL(k_check_sorted, dim3(blocks), dim3(256), 0, st, t, n_events, stream_offsets, n_streams,
-                           unsorted);
-        EVFLY_LAUNCH_CHECK();
+    const int64_t *starts = prepared_starts;
+    const int *unsorted = prepared_unsorted;
+    if (!starts) {
+        // scratch: starts[n_streams*(T+1)] i64 | unsorted[n_streams] i32
+        void *scr = nullptr;
+        const size_t starts_bytes = align_up((size_t)n_streams * (n_windows + 1) * 8, 256);
+        if (int rc = scratch_get(starts_bytes + align_up((size_t)n_streams * 4, 256), &scr, st)) return rc;
+        if (int rc = evfly_voxel_prepare(t, n_events, stream_offsets, n_streams, window_edges, n_windows, (int *)((char *)scr + starts_bytes),
+                                         (int64_t *)scr, stream)) return rc;
+        starts = (const int64_t *)scr;
+        unsorted = (const int *)((char *)scr + starts_bytes);
     }
-    hipLaunchKernelGGL(k_window_ranges, dim3(cdiv(n_streams * (n_windows + 1), 128)), dim3(128), 0, st, t,
-                       stream_offsets, window_edges, n_streams, n_windows, starts);
-    EVFLY_LAUNCH_CHECK();
 
     VoxArgs a{};
     a.x = x; a.y = y; a.t = t; a.p = p; a.offs = stream_offsets; a.edges = window_edges; a.starts = starts;
@@ -448,6 +476,7 @@ extern "C" int evfly_voxelize_windows_roi(const uint16_t *x, const uint16_t *y, 
     a.rtop = roi_top; a.rleft = roi_left; a.RH = roi_height; a.RW = roi_width;
     const int groups = cdiv(n_frames, kNumXCD);
     for (int general = 0; general < 2; ++general) {
+        if (skip_kernels == general + 1) continue;      // the caller knows from evfly_voxel_prepare's tables that this kernel owns no frame
         const int bytes_per_row = roi_width * (general ? 8 : 4);
         const int rows_max = kMaxLds / bytes_per_row;
         a.n_bands = cdiv(roi_height, rows_max);

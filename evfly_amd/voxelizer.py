@@ -20,13 +20,34 @@ def _dev(a, dtype):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
 
 
-def upload_events(batch):
-    """SoA numpy batch (evfly_amd.synthetic.make_batch layout) -> dict of device tensors."""
+def upload_events(batch, prepare=True):
+    """SoA numpy batch (evfly_amd.synthetic.make_batch layout) -> dict of device tensors. prepare: also run the voxelizer's pass 1
+    once (`evfly_voxel_prepare`: per-stream sortedness, window -> event ranges) and keep its tables with the upload -- they depend
+    on t / offsets / edges only; `voxelize_windows` then reads no timestamps of sorted streams. Mutating ev["t"] / ev["edges"]
+    afterwards needs `prepare_events(ev)` again (or `ev.pop("starts")`)."""
     _lib.lib()
-    return dict(x=_dev(batch["x"].view(np.int16) if isinstance(batch["x"], np.ndarray) else batch["x"], torch.int16),
-                y=_dev(batch["y"].view(np.int16) if isinstance(batch["y"], np.ndarray) else batch["y"], torch.int16),
-                t=_dev(batch["t"], torch.int64), p=_dev(batch["p"], torch.int8),
-                offsets=_dev(batch["offsets"], torch.int64), edges=_dev(batch["edges"], torch.int64))
+    ev = dict(x=_dev(batch["x"].view(np.int16) if isinstance(batch["x"], np.ndarray) else batch["x"], torch.int16),
+              y=_dev(batch["y"].view(np.int16) if isinstance(batch["y"], np.ndarray) else batch["y"], torch.int16),
+              t=_dev(batch["t"], torch.int64), p=_dev(batch["p"], torch.int8),
+              offsets=_dev(batch["offsets"], torch.int64), edges=_dev(batch["edges"], torch.int64))
+    return prepare_events(ev) if prepare else ev
+
+
+def prepare_events(ev):
+    """Attach evfly_voxel_prepare's tables to an uploaded batch: ev["unsorted"] (B,) int32, ev["starts"] (B, T+1) int64 and
+    ev["skip_kernels"] (read back once: 2 when every stream is sorted and no window holds more than 65 535 events, 1 when no
+    window can take the 16-bit kernel, else 0)."""
+    L = _lib.lib()
+    B = ev["offsets"].numel() - 1
+    T = ev["edges"].shape[-1] - 1
+    uns = torch.empty(B, device=ev["t"].device, dtype=torch.int32)
+    starts = torch.empty(B, T + 1, device=ev["t"].device, dtype=torch.int64)
+    _lib.check(L.evfly_voxel_prepare(_lib.ptr(ev["t"]), ev["t"].numel(), _lib.ptr(ev["offsets"]), B, _lib.ptr(ev["edges"]), T,
+                                     _lib.ptr(uns), _lib.ptr(starts), _lib.cur_stream()))
+    fast = (uns == 0)[:, None] & ((starts[:, 1:] - starts[:, :-1]) <= 65535)      # frames of the 16-bit kernel (voxel.hip kFastMax)
+    ev["unsorted"], ev["starts"] = uns, starts
+    ev["skip_kernels"] = 2 if bool(fast.all()) else (1 if not bool(fast.any()) else 0)
+    return ev
 
 
 def centre_crop_roi(H, W, out_hw):
@@ -61,11 +82,14 @@ def voxelize_windows(ev, H, W, polarity="pm1", pos_thresh=0.2, neg_thresh=0.2, o
             bufs[o] = torch.empty(B, T, 2, H, W, device=dev, dtype=torch.int32)
         else:
             raise ValueError(o)
-    _lib.check(L.evfly_voxelize_windows_roi(_lib.ptr(ev["x"]), _lib.ptr(ev["y"]), _lib.ptr(ev["t"]), _lib.ptr(ev["p"]),
-                                            ev["x"].numel(), _lib.ptr(ev["offsets"]), B, _lib.ptr(ev["edges"]), T, Hf, Wf,
-                                            top, left, rh, rw, POL[polarity], float(pos_thresh), float(neg_thresh),
-                                            _lib.ptr(bufs["f32"]), _lib.ptr(bufs["f64"]), _lib.ptr(bufs["counts"]),
-                                            _lib.cur_stream()))
+    prep = "starts" in ev
+    _lib.check(L.evfly_voxelize_windows_prepared(_lib.ptr(ev["x"]), _lib.ptr(ev["y"]), _lib.ptr(ev["t"]), _lib.ptr(ev["p"]),
+                                                 ev["x"].numel(), _lib.ptr(ev["offsets"]), B, _lib.ptr(ev["edges"]), T, Hf, Wf,
+                                                 top, left, rh, rw, POL[polarity], float(pos_thresh), float(neg_thresh),
+                                                 _lib.ptr(ev["unsorted"]) if prep else None, _lib.ptr(ev["starts"]) if prep else None,
+                                                 ev.get("skip_kernels", 0) if prep else 0,
+                                                 _lib.ptr(bufs["f32"]), _lib.ptr(bufs["f64"]), _lib.ptr(bufs["counts"]),
+                                                 _lib.cur_stream()))
     res = tuple(bufs[o] for o in outs)
     return res[0] if isinstance(out, str) else res
 

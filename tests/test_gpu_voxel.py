@@ -73,8 +73,10 @@ def test_full_c2_batch_size_independent_properties(gpu_device):
 
 def test_sensor_size_thresholds_and_01(gpu_device):
     """C3-shaped: 480x640, T=10, {0,1} polarity convention, unequal thresholds."""
+    from evfly_amd import voxelizer
     B, T, Hh, Ww = 2, 10, 480, 640
     batch = syn.make_batch(B, T, Hh, Ww, events_per_window=50_000, polarity="01", seed_base=77)
+    assert voxelizer.upload_events(batch)["skip_kernels"] == 2          # sorted, every window <= 65 535 events: the general kernel is not launched
     f32, f64, counts = _vox(batch, Hh, Ww, polarity="01", pos_thresh=0.3, neg_thresh=0.1)
     want = ovox.batch_window_counts(batch, Hh, Ww, mode="all")
     assert np.array_equal(counts, want)
@@ -99,7 +101,13 @@ def test_region_of_interest_equals_crop(gpu_device, roi):
     hot = np.flatnonzero((batch["t"][s1:int(batch["offsets"][2])] >= e[1]) & (batch["t"][s1:int(batch["offsets"][2])] < e[2]))
     assert hot.size > 20_000
     ev = voxelizer.upload_events(batch)
+    assert ev["skip_kernels"] == 0 and int(ev["unsorted"][0]) == 1 and int(ev["unsorted"][1:].sum()) == 0      # both kernels own frames
     f32, f64, cnt = voxelizer.voxelize_windows(ev, Hh, Ww, out=("f32", "f64", "counts"))
+    # the tables of evfly_voxel_prepare kept with the upload == pass 1 inside every call
+    ev0 = voxelizer.upload_events(batch, prepare=False)
+    assert "starts" not in ev0
+    for a, b in zip(voxelizer.voxelize_windows(ev0, Hh, Ww, out=("f32", "f64", "counts")), (f32, f64, cnt)):
+        assert torch.equal(a, b)
     r = voxelizer.centre_crop_roi(Hh, Ww, (260, 346)) if roi == "centre" else roi
     if roi == "centre":
         assert r == (110, 147, 260, 346)
