@@ -352,7 +352,10 @@ def main():
                               for p in layers if p["name"].startswith(dom["name"] + "/")]
         out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_GBs_algorithmic": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
                          "voxelize_frac_of_hbm_peak": round(vox_bytes / (vox_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms, 3)}
+                         "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms, 3),
+                         "voxelize_note": "the events are resident (uploaded before the timed region) together with the voxelizer's pass-1 "
+                                          "tables (evfly_voxel_prepare: per-stream sortedness, window -> event ranges; they depend on the "
+                                          "timestamps and edges only): a step accumulates and writes the frames"}
         if not a.no_stage_rates:
             # labelled per-stage rates ("publish both P-only and V+D+P"): each stage alone on the same batch,
             # inputs resident, torch events on the launch stream. V = voxelize + condition, D = OrigUNet + ConvLSTM,
