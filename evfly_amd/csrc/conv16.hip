@@ -171,15 +171,25 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             if (i < FPIX) f[i] = v;
         }
     };
-    // thread = (patch pixel tid >> 2 (+ 128 per pass), 8-channel group tid & 3): its 9 x 8 weights and 8 biases live in registers
-    float pw[PRE ? 72 : 1], pbias[PRE ? 8 : 1];
+    // The first conv runs on the matrix cores too: per 32 patch pixels ONE v_mfma_f32_32x32x16_bf16 with the roles of the main
+    // loop (A = the 32 channels' weights over K = 9 taps padded to 16, B = the pixels' nine frame values), the bias as the
+    // accumulator's initial value. Lane (n = lane & 31, half = lane >> 5): A = taps 8 half .. 8 half + 7 of channel n (tap 8 and
+    // seven zeros in the upper half), B = the same taps of pixel 32 tile + n gathered from the staged frame patch and rounded to
+    // bf16 -- the frame is an operand of a bf16 MFMA like every other activation of this pipeline (form_BEV = 2 frames are 0 / 1:
+    // exact). D leaves a lane as the main loop's tiles do (one pixel, channel quads {0-3, 8-11, 16-19, 24-27} + 4 half): ReLU, edge
+    // mask, one rounding, v_permlane32_swap -> two 16-B chunks of the pixel's 64 B in the patch. (Round 3 start: 72 v_fma_f32 + 9
+    // LDS reads per pixel and 8-channel group on the VALU, ~7 k of the fused layer's 15 k cycles per tile step.)
+    bf16x8 pwa = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 pbias16;
     if constexpr (PRE) {
+        const int ch = lane & 31, kh = lane >> 5;
+        float wv8[8];
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int e = 0; e < 8; ++e) { const int t = 8 * kh + e; wv8[e] = t < 9 ? d.pre_w[t * 32 + ch] : 0.f; }
+        const uint4 wp4 = make_uint4(pack_bf2(wv8[0], wv8[1]), pack_bf2(wv8[2], wv8[3]), pack_bf2(wv8[4], wv8[5]), pack_bf2(wv8[6], wv8[7]));
+        pwa = *reinterpret_cast<const bf16x8 *>(&wp4);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) pw[t * 8 + c] = d.pre_w[t * 32 + (tid & 3) * 8 + c];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) pbias[c] = d.pre_b[(tid & 3) * 8 + c];
+        for (int r = 0; r < 16; ++r) pbias16[r] = d.pre_b[(r & 3) + 8 * (r >> 2) + 4 * kh];
     }
     auto produce_patch = [&](int t, int fb, int buf) {
         int img, ty, tx;
@@ -187,24 +197,41 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         const int iy0 = ty * TH, ix0 = tx * TW;
         const float *f = fbuf + fb * FPIX;
         unsigned char *dstb = smem + buf * PATCH_BYTES;
-        const int grp = tid & 3;
-        for (int q = tid >> 2; q < NPIX; q += 128) {
-            const int pr = q / PWD, pcx = q - pr * PWD;
-            float a[8];
+        const int pn = lane & 31, kh = lane >> 5;
+        constexpr int NMT = (NPIX + 31) / 32;
+        for (int mt = wv; mt < NMT; mt += NWAVE) {
+            const int q = mt * 32 + pn, qc = q < NPIX ? q : NPIX - 1;
+            const int pr = qc / PWD, pcx = qc - pr * PWD;
+            const float *fp = f + pr * FW + pcx;
+            float v[8];
+            if (kh == 0) {
+                v[0] = fp[0]; v[1] = fp[1]; v[2] = fp[2]; v[3] = fp[FW]; v[4] = fp[FW + 1]; v[5] = fp[FW + 2]; v[6] = fp[2 * FW]; v[7] = fp[2 * FW + 1];
+            } else {
+                v[0] = fp[2 * FW + 2];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = pbias[c];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float v = f[(pr + ky) * FW + pcx + kx];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) a[c] = fmaf(v, pw[(ky * 3 + kx) * 8 + c], a[c]);
-                }
+                for (int e = 1; e < 8; ++e) v[e] = 0.f;
+            }
+            const uint4 b4 = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            const f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pwa, *reinterpret_cast<const bf16x8 *>(&b4), pbias16, 0, 0, 0);
             const bool in = iy0 + pr < d.H && ix0 + pcx < d.W;           // beyond the (virtual) e11 map: zeros
+            unsigned pkd[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = in ? (a[c] < 0.f ? 0.f : a[c]) : 0.f;
-            *reinterpret_cast<uint4 *>(dstb + patch_off(q, grp)) = make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(a[4], a[5]), pack_bf2(a[6], a[7]));
+            for (int k = 0; k < 8; ++k) {
+                const float x0 = in ? (a[2 * k] < 0.f ? 0.f : a[2 * k]) : 0.f, x1 = in ? (a[2 * k + 1] < 0.f ? 0.f : a[2 * k + 1]) : 0.f;
+                pkd[k] = pack_bf2(x0, x1);
+            }
+            // pkd[2 g], pkd[2 g + 1] = channel quad g of this half (channels 8 g + 4 kh .. + 3): the swaps hand every lane 8
+            // adjacent channels twice -- lanes < 32: chunks 0 and 2 of the pixel, lanes >= 32: chunks 1 and 3
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                unsigned o[4];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pkd[(2 * grp) * 2 + w], pkd[(2 * grp + 1) * 2 + w], false, false);
+                    o[w] = sw[0]; o[2 + w] = sw[1];
+                }
+                if (q < NPIX) *reinterpret_cast<uint4 *>(dstb + patch_off(q, grp * 2 + kh)) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
         }
     };
 
