@@ -62,6 +62,10 @@ struct ConvDesc {
     // with skip_y: write y only along the borders of each block's region (first / last row and column) -- all that the
     // resize of the remaining skip pixels reads. For callers whose only other reader of y is the fused pool.
     int skip_bands = 0;
+    // optional 1x1 consumer of the Winograd 3x3 kernel (Nc == ldy == 32): dot_y[pixel] = dot_b[0] + sum_c act(y)[pixel][c] * dot_w[c]
+    // INSTEAD of y (the U-Net's unet_out on d42's output, learner_models.py:583: the 32-channel map is never written)
+    const float *dot_w = nullptr, *dot_b = nullptr;
+    float *dot_y = nullptr;
     // optional fused producer (Winograd kernel, C == 32 only): x is not read; input pixel (iy, ix) is
     // relu(conv3x3(form(pre_frames))[iy][ix]) of the FIRST U-Net conv (learner_models.py:476-494,533), computed on
     // the fly while the patch is staged. pre_frames (NI, H + 2, W + 2) raw conditioned frames, pre_w [9 * cin][32],

@@ -80,6 +80,8 @@ struct evfly_model {
     size_t esz() const { return act16 ? 2 : 4; }           // bytes per activation element
     bool full_encoder_outputs = false;
     bool bands_used = false;   // the last forward left "e1".."e4" partial
+    bool dot_used = false;     // the last forward fused unet_out into d42: "d4" was not written
+    struct { const float *w = nullptr, *b = nullptr; float *y = nullptr; bool done = false; } dot;     // request for the next conv()
 
     ~evfly_model() {
         if (wdev) (void)hipFree(wdev);
@@ -573,7 +575,15 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
         extra_flops = 2.0 * n * H * W * C * 9 * m->pre.cin;
         m->pre.frames = nullptr;
     }
+    const bool want_dot = m->dot.y != nullptr;
+    float *const dot_y = m->dot.y;
+    m->dot.y = nullptr; m->dot.done = false;
     if (!f16 && wino_applicable(d) && m->has(wname + ".u")) {  // Winograd F(2x2,3x3): 2.25x fewer MFMA flops
+        if (want_dot && cout == 32 && ldy == 32 && !y_pool && !skip_y) {      // 1x1 consumer in the epilogue instead of the map
+            d.dot_w = m->dot.w; d.dot_b = m->dot.b; d.dot_y = dot_y;
+            m->dot.done = true;
+            if (!m->planning) m->dot_used = true;
+        }
         d.y_pool = y_pool;                                     // nn.MaxPool2d(2,2): one window per Winograd tile
         if (pool_fused) *pool_fused = y_pool != nullptr;
         if (skip_y && skip_region) {                           // 'interp' skip: resampled from the tile in LDS where the taps allow
@@ -619,7 +629,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
                       float *vp_c = nullptr) {
     const auto &c = m->cfg;
     const int F = S * T;
-    if (!m->planning) m->bands_used = false;
+    if (!m->planning) { m->bands_used = false; m->dot_used = false; }
     const int cin = (c.form_bev == 1 || c.form_bev == 2) ? 1 : c.num_in_channels;
     const int apply_form = (c.num_in_channels == 2 || c.form_bev > 0) ? 1 : 0;   // learner_models.py:523
     hipStream_t st = m->st;
@@ -647,6 +657,8 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     // kernel in the decoder loop below writes the rest). EVFLY_NO_SKIP_FUSION: the resize kernel writes everything.
     static const int small[4][2] = {{16, 26}, {24, 44}, {40, 80}, {72, 152}};
     static const bool no_skip_fuse = getenv("EVFLY_NO_SKIP_FUSION") != nullptr;
+    static const bool no_dot_fuse = getenv("EVFLY_NO_OUT_FUSION") != nullptr;      // A/B switch: unet_out as its own kernel
+    float *up_fused = nullptr;                                                      // unet_out's map when d42's kernel wrote it
     const bool run_decoder = !(c.is_deployment && !(c.velpred == 1 || c.velpred == 11));
     float *cats[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // by decoder level 1..4
     int skip_region[5][2] = {};                                            // block region of the fused producer (0: not fused)
@@ -803,15 +815,21 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         if (int rc = conv(m, "conv3x3", n1, cat, F, uh, uw, ccat, ccat, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, co, nullptr, nullptr, nullptr,
                           0, 0, 0, nullptr, io)) return rc;
         float *b = m->alloc_act((int64_t)F * (uh - 4) * (uw - 4) * co);
+        if (l == 4 && !a16 && !m->full_encoder_outputs && !no_dot_fuse) {      // unet_out in d42's epilogue (fp32 Winograd path)
+            up_fused = upconv_out ? upconv_out : m->alloc((int64_t)F * 68 * 148);
+            m->dot.w = m->W("out.w"); m->dot.b = m->W("out.b"); m->dot.y = up_fused;
+        }
         if (int rc = conv(m, "conv3x3", n2, a, F, uh - 2, uw - 2, co, co, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, co, nullptr, nullptr, nullptr,
                           0, 0, 0, nullptr, io)) return rc;
+        if (l == 4 && !m->dot.done) up_fused = nullptr;
         dcur = b; dh = uh - 4; dw = uw - 4; dc = co;
         static const char *tn[4] = {"d1", "d2", "d3", "d4"};
         m->tap(tn[l - 1], b, F, dh, dw, dc, a16);
     }
     // ---- unet_out (1x1, 32 -> 1) and form_output (:496-508)
-    float *up = upconv_out ? upconv_out : m->alloc((int64_t)F * 68 * 148);
-    if (a16) RUN(m, "unet_out", 2.0 * F * 68 * 148 * 32, F * 68.0 * 148 * (2.0 * 32 + 4), launch16_dot_out(dcur, (int64_t)F * 68 * 148, 32, m->W("out.w"), m->W("out.b"), up, st));
+    float *up = up_fused ? up_fused : upconv_out ? upconv_out : m->alloc((int64_t)F * 68 * 148);
+    if (up_fused) {}
+    else if (a16) RUN(m, "unet_out", 2.0 * F * 68 * 148 * 32, F * 68.0 * 148 * (2.0 * 32 + 4), launch16_dot_out(dcur, (int64_t)F * 68 * 148, 32, m->W("out.w"), m->W("out.b"), up, st));
     else
     RUN(m, "unet_out", 2.0 * F * 68 * 148 * 32, 4.0 * F * 68 * 148 * 33, launch_dot_out(dcur, (int64_t)F * 68 * 148, 32, m->W("out.w"), m->W("out.b"), up, st));
     float *dp = depth_out ? depth_out : m->alloc((int64_t)F * c.input_h * c.input_w);
@@ -1253,6 +1271,9 @@ extern "C" int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_
     EVFLY_REQUIRE(m && name && dst_host, "tap: null argument");
     auto it = m->taps.find(name);
     EVFLY_REQUIRE(it != m->taps.end(), "tap '%s' was not produced by the last forward", name);
+    EVFLY_REQUIRE(!(m->dot_used && name[0] == 'd' && name[1] == '4' && name[2] == 0),
+                  "tap 'd4': partial -- the last forward fused unet_out into d42's kernel and did not write the 32-channel map "
+                  "(EVFLY_FULL_ENCODER_OUTPUTS=1 or EVFLY_NO_OUT_FUSION=1 keep it)");
     EVFLY_REQUIRE(!(m->bands_used && name[0] == 'e' && name[1] >= '1' && name[1] <= '4' && name[2] == 0),
                   "tap '%s' is partial: the last forward stored only the block-border pixels of the full-resolution encoder maps "
                   "(fused 'interp' skip). Set EVFLY_FULL_ENCODER_OUTPUTS=1 before the handle is created to keep them complete", name);

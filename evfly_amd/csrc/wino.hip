@@ -625,7 +625,22 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         return e.y != 0xffffffffu && (int)(e.y & 0xffu) < hrem && (int)((e.y >> 8) & 0xffu) < wrem && (int)((e.y >> 16) & 0xffu) < irem && nrem > 0 &&
                (!bands || (e.y & (1u << 24))) && !(kAbl & 4);
     };
-    if (vec) {
+    if (d.dot_y) {
+        // fused 1x1 conv to one channel: the eight threads of a pixel (4 channels each) reduce their partial dot products with
+        // three lane exchanges; the 32-channel map itself is not stored. Pixel index = float offset / 32 (ldy == 32).
+        const float4 w4 = *reinterpret_cast<const float4 *>(d.dot_w + (tid & 7) * 4);
+        const float b0 = d.dot_b[0];
+        float *dbase = d.dot_y + ((uint64_t)(unsigned)img0 * (unsigned)(d.OH * d.OW) + (unsigned)(oy0 * d.OW + ox0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(ot + (tid + q * NTHR) * 4);
+            float sdot = fmaf(v.w, w4.w, fmaf(v.z, w4.z, fmaf(v.y, w4.y, v.x * w4.x)));
+            sdot += __shfl_xor(sdot, 1);
+            sdot += __shfl_xor(sdot, 2);
+            sdot += __shfl_xor(sdot, 4);
+            if ((tid & 7) == 0 && store_ok(se[q])) dbase[se[q].x >> 5] = sdot + b0;
+        }
+    } else if (vec) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (store_ok(se[q])) *reinterpret_cast<float4 *>(ybase + se[q].x) = *reinterpret_cast<const float4 *>(ot + (tid + q * NTHR) * 4);

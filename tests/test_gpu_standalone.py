@@ -140,6 +140,9 @@ def test_tap_of_partial_encoder_map_is_an_error(gpu_device):
     assert net.hip().tap("e5").shape == (1, 8, 13, 512)
     with pytest.raises(RuntimeError, match="partial"):
         net.hip().tap("e2")
+    with pytest.raises(RuntimeError, match="partial"):          # d42's map: consumed by the fused unet_out, never written
+        net.hip().tap("d4")
+    assert net.hip().tap("d3").shape[0] == 1
 
 
 @pytest.mark.gpu
