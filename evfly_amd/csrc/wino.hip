@@ -72,6 +72,7 @@ struct WinoGeom {
     int ngroups;                // DMA groups of 8 pixels (<= ND * waves: the kernel issues ND pieces per wave)
     int ntiles;                 // IMGS * TY * TX  (<= 32 * MT)
     int bx, by, bi;             // blocks along x, y, image groups
+    int ty_off, tx_off;         // tile origin of the region this launch covers (split plans: a second launch with its own arrangement)
     int n_nt, cpx, n_btiles;
     int mPWh, mPH, mTX, mPer;    // floor(v / x) == (v * m) >> 20 for the small v used here (m = 1048576 / x + 1)
     unsigned u_nnt, u_bx, u_by;  // floor(2^32 / x) + 1 for x = n_nt, bx, by (unused for x = 1)
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     WINO_TS(8);
     const int rowq = udiv(bt, g.bx, g.u_bx), bxi = bt - rowq * g.bx;
     const int big = udiv(rowq, g.by, g.u_by), byi = rowq - big * g.by;
-    const int img0 = big * g.IMGS, ty0 = byi * g.TY, tx0 = bxi * g.TX;
+    const int img0 = big * g.IMGS, ty0 = g.ty_off + byi * g.TY, tx0 = g.tx_off + bxi * g.TX;
     const int n0 = nt * 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs
@@ -767,9 +768,9 @@ __global__ void k_wino_weights(const float *__restrict__ w, int cout, int cin, i
 }
 
 // MT: M-tiles per block; max_px: patch budget (pixels) of one LDS buffer
-bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
+// (tiles_y x tiles_x: the tile grid of the region to cover, at tile offset (ty_off, tx_off) of the map)
+bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px, int tiles_y, int tiles_x, int ty_off, int tx_off) {
     const int slots = 32 * MT;
-    const int tiles_y = cdiv(d.OH, 2), tiles_x = cdiv(d.OW, 2);
     // cost of a plan ~ launched work: every block pays its tile slots (MFMA time, used or not) and its patch pixels
     // (DMA + LDS traffic; ~5 px per tile for a square arrangement, far more for thin ones)
     double best = -1;
@@ -785,6 +786,7 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px) {
             }
     if (best < 0) return false;
     g.cost = best;
+    g.ty_off = ty_off; g.tx_off = tx_off;
     g.PH = 2 * g.TY + 2; g.PW = 2 * g.TX + 2;
     g.npix = g.IMGS * g.PH * g.PW;
     g.ngroups = cdiv(g.npix, 8);
@@ -842,16 +844,19 @@ namespace {
 // pixels), patch buffers
 struct WinoCfg { int MT, ND, nbuf; int max_px() const { return ND * MT * 32; } };
 
-struct WinoPlan { WinoCfg c; WinoGeom g; double exec_flops, efficiency; bool ok; };
+struct WinoRegion { WinoCfg c; WinoGeom g; };
+// one launch per region: the whole map, or two regions (a column or a row split of the tile grid) with their own arrangements
+struct WinoPlan { WinoRegion r[2]; int nreg; double exec_flops, efficiency; bool ok; WinoCfg c; WinoGeom g; };      // c, g = r[0] (unsplit plans)
 
 // 512-thread blocks (64 tiles, two 40 KB patch buffers, two blocks per CU) unless the 256-thread block (32 tiles, two
 // 24 KB buffers, three blocks per CU) fills its tile slots much better (e51: 40 tiles per image). EVFLY_WINO_MT = 1 / 2
 // forces one. Single-chunk layers on the non-persistent kernel (the fused first conv) need one buffer only.
-WinoPlan make_plan(const ConvDesc &d) {
+bool plan_region(const ConvDesc &d, int tiles_y, int tiles_x, int ty_off, int tx_off, WinoRegion &out) {
     static const int force = getenv("EVFLY_WINO_MT") ? atoi(getenv("EVFLY_WINO_MT")) : 0;
     const WinoCfg c2{2, 5, 2}, c1{1, 6, 2};
     WinoGeom g1, g2;
-    const bool ok1 = plan(d, g1, c1.MT, c1.max_px()), ok2 = plan(d, g2, c2.MT, c2.max_px());
+    const bool ok1 = plan(d, g1, c1.MT, c1.max_px(), tiles_y, tiles_x, ty_off, tx_off);
+    const bool ok2 = plan(d, g2, c2.MT, c2.max_px(), tiles_y, tiles_x, ty_off, tx_off);
     bool use2;
     if (force) use2 = force == 2 ? ok2 : !ok1;
     // single-chunk layers (C_in = 32: e12, e21, d42): 64 MFMAs per wave between a cold patch and the output transform --
@@ -862,16 +867,41 @@ WinoPlan make_plan(const ConvDesc &d) {
     // the cost ratio says wherever it fills its tile slots better (cost ratio -> time ratio: d12 0.99 -> 0.93, d22 0.96 -> 0.90,
     // e51 0.90 -> 0.80; tools/scripts/mt_sweep.sh): any real cost advantage takes it
     else use2 = ok1 && ok2 ? !(g1.cost < 0.995 * g2.cost) : ok2;
+    out.c = use2 ? c2 : c1;
+    out.g = use2 ? g2 : g1;
+    return use2 ? ok2 : ok1;
+}
+
+// Split plans: rectangular blocks of TY x TX tiles (x IMGS images) leave the last block row / column of a map partly empty
+// -- 11 % of the issued MFMAs over the 17 layers in round 2 (e41: 17 %, d21: 20 %). A map whose tile grid does not factor well
+// is covered by TWO launches instead, a column or a row split, each region with the arrangement that fits it (e41's 14 x 19
+// tiles: 16 columns as 2 x 16-tile blocks, 3 columns as 3-image x 7 x 3 blocks: 83 % -> 99.7 % of the slots used). Blocks of
+// the first region that hang over the split compute (and store) tiles of the second again: same values. Not for launches with a
+// fused 'interp' skip (the resize kernel's share is defined by ONE uniform block grid) nor with the fused first conv.
+WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
+    static const bool no_split = getenv("EVFLY_WINO_NO_SPLIT") != nullptr;      // A/B switch
+    const int ty = cdiv(d.OH, 2), tx = cdiv(d.OW, 2);
     WinoPlan p;
-    p.ok = use2 ? ok2 : ok1;
-    p.c = use2 ? c2 : c1;
-    p.g = use2 ? g2 : g1;
+    p.nreg = 1;
+    p.ok = plan_region(d, ty, tx, 0, 0, p.r[0]);
+    if (p.ok && allow_split && !no_split) {
+        double best = p.r[0].g.cost * 0.97;          // a second launch has to pay for itself
+        for (int dir = 0; dir < 2; ++dir)
+            for (int s = 1; s < (dir ? ty : tx); ++s) {
+                WinoRegion a, b;
+                const bool oka = dir ? plan_region(d, s, tx, 0, 0, a) : plan_region(d, ty, s, 0, 0, a);
+                const bool okb = dir ? plan_region(d, ty - s, tx, s, 0, b) : plan_region(d, ty, tx - s, 0, s, b);
+                if (oka && okb && a.g.cost + b.g.cost < best) { best = a.g.cost + b.g.cost; p.r[0] = a; p.r[1] = b; p.nreg = 2; }
+            }
+    }
+    p.c = p.r[0].c; p.g = p.r[0].g;
+    p.exec_flops = p.efficiency = 0;
     if (p.ok) {
+        double slots = 0;
+        for (int i = 0; i < p.nreg; ++i) slots += (double)p.r[i].g.n_btiles * 32.0 * p.r[i].c.MT;
         // matrix-core flops the launch issues: 16 positions x tile slots x 32-channel slices x C_in, times 2
-        p.exec_flops = 2.0 * 16.0 * ((double)p.g.n_btiles * 32.0 * p.c.MT) * ((double)p.g.n_nt * 32.0) * d.C;
-        p.efficiency = (double)d.NI * cdiv(d.OH, 2) * cdiv(d.OW, 2) / (32.0 * p.c.MT * p.g.n_btiles);
-    } else {
-        p.exec_flops = p.efficiency = 0;
+        p.exec_flops = 2.0 * 16.0 * slots * ((double)p.g.n_nt * 32.0) * d.C;
+        p.efficiency = (double)d.NI * ty * tx / slots;
     }
     return p;
 }
@@ -879,11 +909,12 @@ WinoPlan make_plan(const ConvDesc &d) {
 // plans depend on the geometry only: searched once per (NI, OH, OW, C, Nc)
 const WinoPlan &cached_plan(const ConvDesc &d) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int>, WinoPlan> cache;
+    static std::map<std::tuple<int, int, int, int, int, int>, WinoPlan> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc);
+    const bool allow_split = !d.skip_y && !d.pre_frames;
+    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, (int)allow_split);
     auto it = cache.find(key);
-    if (it == cache.end()) it = cache.emplace(key, make_plan(d)).first;
+    if (it == cache.end()) it = cache.emplace(key, make_plan(d, allow_split)).first;
     return it->second;
 }
 
@@ -963,13 +994,13 @@ void build_store_tables(const WinoGeom &g, int nthr, int OH, int OW, int64_t ldy
 
 // one device allocation per (geometry, pitches, device), living as long as the library
 struct WinoTables { const uint2 *tab; const int4 *ftab; const uint2 *stab, *ptab; };
-int plan_tables(const ConvDesc &d, const WinoPlan &p, WinoTables *out) {
+int plan_tables(const ConvDesc &d, const WinoRegion &p, WinoTables *out) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int, int64_t, int64_t, int>, WinoTables> cache;
+    static std::map<std::tuple<std::tuple<int, int, int, int, int, int64_t, int64_t, int>, int, int, int, int>, WinoTables> cache;
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, d.ldx, d.ldy, dev);
+    const auto key = std::make_tuple(std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, d.ldx, d.ldy, dev), p.c.MT, p.g.IMGS, p.g.TY, p.g.TX);
     auto it = cache.find(key);
     if (it == cache.end()) {
         const int MT = p.c.MT, npieces = p.c.ND * 4 * MT, nthr = 256 * MT;
@@ -998,7 +1029,7 @@ int plan_tables(const ConvDesc &d, const WinoPlan &p, WinoTables *out) {
 }
 
 template <int MT, int ND, bool ONE, bool PRE, int ACT>
-int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
+int launch_act(const ConvDesc &d, const float *U, const WinoRegion &p, hipStream_t st) {
     const WinoGeom &g = p.g;
     // patch buffer(s); the epilogue reuses them for the exchange sets (MT x 24 KB) + the transposed tile (MT x 16 KB)
     const int buf = ND * 4 * MT * 1024;
@@ -1032,7 +1063,7 @@ int launch_act(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t
 }
 
 template <int MT, int ND, bool ONE, bool PRE>
-int launch(const ConvDesc &d, const float *U, const WinoPlan &p, hipStream_t st) {
+int launch(const ConvDesc &d, const float *U, const WinoRegion &p, hipStream_t st) {
     return d.act == ACT_RELU ? launch_act<MT, ND, ONE, PRE, ACT_RELU>(d, U, p, st) : launch_act<MT, ND, ONE, PRE, -1>(d, U, p, st);
 }
 
@@ -1052,12 +1083,9 @@ void wino_block_region(const ConvDesc &d, int *rh, int *rw) {
 }
 
 int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
-    const WinoPlan &p = cached_plan(d);
-    EVFLY_REQUIRE(p.ok, "wino: no tile plan");
-    EVFLY_REQUIRE(p.g.ngroups <= p.c.ND * 4 * p.c.MT, "wino: patch exceeds the DMA piece budget");
+    const WinoPlan &pl = cached_plan(d);
+    EVFLY_REQUIRE(pl.ok, "wino: no tile plan");
     EVFLY_REQUIRE(((uintptr_t)U) % 16 == 0, "wino: U not aligned");
-    EVFLY_REQUIRE((int64_t)p.g.n_btiles * p.g.n_nt < (1 << 21) && p.g.bx < 2048 && p.g.by < 2048 && p.g.n_nt < 2048,
-                  "wino: grid too large for the 32-bit magic divisions");
     EVFLY_REQUIRE((int64_t)d.OH * d.OW * d.ldy < (1 << 24) && (int64_t)d.H * d.W * d.ldx < (1 << 24),
                   "wino: image larger than 2^24 floats (24-bit index arithmetic)");
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
@@ -1068,9 +1096,19 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
         EVFLY_REQUIRE(rh > 0, "wino: this skip geometry cannot be fused (ask wino_block_region first)");
     }
     const bool one = d.C == 32, pre = d.pre_frames != nullptr;
-    if (p.c.MT == 2)
-        return !one ? launch<2, 5, false, false>(d, U, p, st) : pre ? launch<2, 5, true, true>(d, U, p, st) : launch<2, 5, true, false>(d, U, p, st);
-    return !one ? launch<1, 6, false, false>(d, U, p, st) : pre ? launch<1, 6, true, true>(d, U, p, st) : launch<1, 6, true, false>(d, U, p, st);
+    for (int i = 0; i < pl.nreg; ++i) {
+        const WinoRegion &p = pl.r[i];
+        EVFLY_REQUIRE(p.g.ngroups <= p.c.ND * 4 * p.c.MT, "wino: patch exceeds the DMA piece budget");
+        EVFLY_REQUIRE((int64_t)p.g.n_btiles * p.g.n_nt < (1 << 21) && p.g.bx < 2048 && p.g.by < 2048 && p.g.n_nt < 2048,
+                      "wino: grid too large for the 32-bit magic divisions");
+        int rc;
+        if (p.c.MT == 2)
+            rc = !one ? launch<2, 5, false, false>(d, U, p, st) : pre ? launch<2, 5, true, true>(d, U, p, st) : launch<2, 5, true, false>(d, U, p, st);
+        else
+            rc = !one ? launch<1, 6, false, false>(d, U, p, st) : pre ? launch<1, 6, true, true>(d, U, p, st) : launch<1, 6, true, false>(d, U, p, st);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 }  // namespace evfly
