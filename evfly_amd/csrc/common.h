@@ -59,4 +59,34 @@ __device__ __forceinline__ void bilinear_src_index(int dst, int in_size, int out
 constexpr int kNumCU = 256;
 constexpr int kMaxLds = 160 * 1024;
 
+// Block regions of the Winograd launch(es) that produced a map and resampled the 'interp' skip from their tiles: region 0's
+// rh0 x rw0 blocks tile the map from (0, 0); with a split plan (dir 0: columns, 1: rows) region 1's rh1 x rw1 blocks tile it
+// from source pixel `pos` on along that axis (pos is a multiple of region 0's block size: no block straddles the split). A
+// skip pixel was written by the producer iff its (up to) four taps lie inside ONE block; the resize kernel writes the others.
+struct SkipGrid {
+    int rh0 = 0, rw0 = 0;     // 0: nothing fused
+    int dir = -1, pos = 0;
+    int rh1 = 0, rw1 = 0;
+    // taps a0 <= a1 along one axis (a1 - a0 in {0, 1}): both inside one block of that axis' grid?
+    __host__ __device__ bool axis_inside(int a0, int a1, bool rows) const {
+        if (a1 == a0) return true;
+        const bool split_axis = dir == (rows ? 1 : 0);
+        if (split_axis && a0 >= pos) return (a1 - pos) % (rows ? rh1 : rw1) != 0;
+        return a1 % (rows ? rh0 : rw0) != 0;                       // (a1 == pos starts a region: pos % size == 0)
+    }
+    // the other axis' block size depends on which side of the split the pixel lies
+    __host__ __device__ bool inside(int y0, int y1, int x0, int x1) const {
+        if (rh0 == 0) return false;
+        if (dir < 0) return axis_inside(y0, y1, true) && axis_inside(x0, x1, false);
+        if (dir == 1) {        // row split: rows decide the region, columns use that region's width
+            if (!axis_inside(y0, y1, true)) return false;
+            const int rw = y0 >= pos ? rw1 : rw0;
+            return x1 == x0 || x1 % rw != 0;
+        }
+        if (!axis_inside(x0, x1, false)) return false;
+        const int rh = x0 >= pos ? rh1 : rh0;
+        return y1 == y0 || y1 % rh != 0;
+    }
+};
+
 }  // namespace evfly

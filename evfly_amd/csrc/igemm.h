@@ -55,7 +55,7 @@ struct ConvDesc {
     // optional third output of the Winograd 3x3 kernel (U-Net 'interp' skip, learner_models.py:514): the bilinear resample
     // (align_corners = False) of the activated output to skip_h x skip_w, channel n of pixel (img, sy, sx) at
     // skip_y[((img * skip_h + sy) * skip_w + sx) * skip_ld + n]. The kernel writes the pixels whose four taps lie inside
-    // one block's output region (wino_block_region); launch_bilinear(..., excl_h, excl_w) writes the others from y.
+    // one block's output region (wino_skip_grid); launch_bilinear(..., grid) writes the others from y.
     float *skip_y = nullptr;
     int skip_h = 0, skip_w = 0;
     int64_t skip_ld = 0;
@@ -122,7 +122,9 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st);
 double wino_exec_flops(const ConvDesc &d);     // MFMA flops one launch issues (its algorithmic count is igemm_flops)
 // output pixels (rows, columns) one block of the plan covers; (0, 0) when d.skip_y is set but that skip geometry cannot be
 // resampled in the kernel (the caller then clears skip_y and lets launch_bilinear write everything)
-void wino_block_region(const ConvDesc &d, int *rh, int *rw);
+// block regions of the launch(es) wino_launch(d) will run, for a d with skip_y / skip_h / skip_w set (rh0 == 0: this skip
+// geometry cannot be fused)
+void wino_skip_grid(const ConvDesc &d, SkipGrid *g);
 
 // algorithmic work of one launch (for the profile / roofline accounting)
 inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }

@@ -556,7 +556,7 @@ enum : int { IN16 = 1, OUT16 = 2, RES16 = 4, IO16 = IN16 | OUT16 };
 int conv(evfly_model *m, const char *pname, const std::string &wname, const float *x, int n, int H, int W, int C,
          int64_t ldx, int cout, int kh, int kw, int stride, int pad, int act, const float *res, int64_t ldres, float *y,
          int64_t ldy, float *y_pool = nullptr, bool *pool_fused = nullptr, float *skip_y = nullptr, int skip_h = 0, int skip_w = 0,
-         int64_t skip_ld = 0, int *skip_region = nullptr, int f16 = 0) {
+         int64_t skip_ld = 0, SkipGrid *skip_region = nullptr, int f16 = 0) {
     ConvDesc d;
     d.x = x; d.ldx = ldx; d.NI = n; d.H = H; d.W = W; d.C = C;
     d.in_bf16 = (f16 & IN16) != 0; d.out_bf16 = (f16 & OUT16) != 0; d.res_bf16 = (f16 & RES16) != 0;
@@ -588,8 +588,8 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
         if (pool_fused) *pool_fused = y_pool != nullptr;
         if (skip_y && skip_region) {                           // 'interp' skip: resampled from the tile in LDS where the taps allow
             d.skip_y = skip_y; d.skip_h = skip_h; d.skip_w = skip_w; d.skip_ld = skip_ld;
-            wino_block_region(d, &skip_region[0], &skip_region[1]);
-            if (skip_region[0] == 0) d.skip_y = nullptr;
+            wino_skip_grid(d, skip_region);
+            if (skip_region->rh0 == 0) d.skip_y = nullptr;
             // the map's other readers: the 2x2 pool (fused above) and the debug taps "e1".."e4"
             d.skip_bands = d.skip_y && y_pool && !m->full_encoder_outputs;
             if (d.skip_bands && !m->planning) m->bands_used = true;
@@ -661,7 +661,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     float *up_fused = nullptr;                                                      // unet_out's map when d42's kernel wrote it
     const bool run_decoder = !(c.is_deployment && !(c.velpred == 1 || c.velpred == 11));
     float *cats[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // by decoder level 1..4
-    int skip_region[5][2] = {};                                            // block region of the fused producer (0: not fused)
+    SkipGrid skip_region[5];                                               // block regions of the fused producer (rh0 == 0: not fused)
     if (run_decoder && c.skip_type == EVFLY_SKIP_INTERP && !no_skip_fuse)
         for (int l = 1; l <= 4; ++l) cats[l] = m->alloc_act((int64_t)F * small[l - 1][0] * small[l - 1][1] * 2 * (512 >> l));
     const float *cur = e11;
@@ -692,7 +692,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         float *skip_dst = l < 4 ? cats[dl] : nullptr;
         if (int rc = conv(m, "conv3x3", names[l][1], cur, F, H, W, C, C, chans[l], 3, 3, 1, 0, ACT_RELU, nullptr, 0, b, chans[l],
                           pooled, &pool_done, skip_dst, skip_dst ? small[dl - 1][0] : 0, skip_dst ? small[dl - 1][1] : 0, 2 * chans[l],
-                          skip_dst ? skip_region[dl] : nullptr, io)) return rc;
+                          skip_dst ? &skip_region[dl] : nullptr, io)) return rc;
         cur = b; H -= 2; W -= 2; C = chans[l];
         lv[l] = Lvl{H, W, C, b};
         static const char *tn[5] = {"e1", "e2", "e3", "e4", "e5"};
@@ -794,10 +794,10 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
                 }
                 return cnt;
             };
-            const int rs = straddling(enc.H, uh, skip_region[l][0]), cs = straddling(enc.W, uw, skip_region[l][1]);
+            const int rs = straddling(enc.H, uh, skip_region[l].rh0), cs = straddling(enc.W, uw, skip_region[l].rw0);
             const double rest = (double)uh * uw - (double)(uh - rs) * (uw - cs);
             RUN(m, "skip_bilinear", 0, 4.0 * F * rest * co * 5,
-                launch_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, 0, st, skip_region[l][0], skip_region[l][1]));
+                launch_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, 0, st, skip_region[l]));
         }
         else if (c.skip_type == EVFLY_SKIP_CROP)    // centre crop (:512)
             RUN(m, "skip_crop", 0, 4.0 * F * uh * uw * co * 2,

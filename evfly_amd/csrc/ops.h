@@ -21,10 +21,10 @@ int launch_repack_w(const float *w, int cout, int ntaps, int cin, int ld, float 
 int launch_split_w(const float *w, int cout, int ctot, int c0, int cn, int ntaps, int ld, float *out, hipStream_t st);
 // bilinear resize (F.interpolate / nn.Upsample); y pixel stride ldy, written at channel offset 0 of y.
 // pre: 0 none, 1 clip(2*v, 0, 1) applied to every source sample (learner_models.py:634)
-// excl_h x excl_w > 0: skip the output pixels whose four taps lie inside one excl_h x excl_w region of the source grid
+// excl (SkipGrid, common.h): skip the output pixels whose four taps lie inside one block region of the source grid
 // (regions tile it from (0, 0)): the Winograd kernel that produced x wrote them already (ConvDesc::skip_y)
 int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, float *y, int Ho, int Wo, int64_t ldy,
-                    int align_corners, int pre, hipStream_t st, int excl_h = 0, int excl_w = 0);
+                    int align_corners, int pre, hipStream_t st, SkipGrid excl = SkipGrid());
 // centre crop of the skip tensor (skip_type == 'crop', learner_models.py:512)
 int launch_crop(const float *x, int n, int Hi, int Wi, int C, int top, int left, float *y, int Ho, int Wo, int64_t ldy,
                 hipStream_t st);

@@ -192,16 +192,14 @@ __device__ __forceinline__ float pre_op(float v, int pre) {
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, int n, int Hi, int Wi, int C, int64_t ldx,
                                                   float *__restrict__ y, int Ho, int Wo, int64_t ldy, int align, int pre,
-                                                  float sh, float sw, int excl_h, int excl_w, unsigned cv_magic) {
+                                                  float sh, float sw, SkipGrid excl, unsigned cv_magic) {
     const int CV = C / VEC;
     for (int row = blockIdx.x; row < n * Ho; row += gridDim.x) {
         const int img = row / Ho, oy = row - img * Ho;
         int y0, y1;
         float hy0, hy1;
         bilinear_src_index(oy, Hi, Ho, sh, align, y0, y1, hy0, hy1);
-        // excl_h x excl_w: the producer's block regions tile the source from (0, 0); it already wrote every pixel whose
-        // taps lie inside one of them (y1 - y0, x1 - x0 in {0, 1}: the taps split iff the second one starts a region)
-        const bool row_inside = excl_h && (y1 == y0 || y1 % excl_h != 0);
+        // excl: the producer's block regions (SkipGrid); it already wrote every pixel whose taps lie inside one of them
         const float *b0 = x + ((int64_t)img * Hi + y0) * Wi * ldx, *b1 = x + ((int64_t)img * Hi + y1) * Wi * ldx;
         float *orow = y + (int64_t)row * Wo * ldy;
         for (int i = threadIdx.x; i < Wo * CV; i += 256) {
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, i
             int x0, x1;
             float wx0, wx1;
             bilinear_src_index(ox, Wi, Wo, sw, align, x0, x1, wx0, wx1);
-            if (row_inside && (x1 == x0 || x1 % excl_w != 0)) continue;
+            if (excl.inside(y0, y1, x0, x1)) continue;
             const float *p00 = b0 + (int64_t)x0 * ldx + c, *p01 = b0 + (int64_t)x1 * ldx + c;
             const float *p10 = b1 + (int64_t)x0 * ldx + c, *p11 = b1 + (int64_t)x1 * ldx + c;
             float *o = orow + (int64_t)ox * ldy + c;
@@ -630,7 +628,7 @@ int launch_repack_w(const float *w, int cout, int ntaps, int cin, int ld, float 
 }
 
 int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, float *y, int Ho, int Wo, int64_t ldy,
-                    int align_corners, int pre, hipStream_t st, int excl_h, int excl_w) {
+                    int align_corners, int pre, hipStream_t st, SkipGrid excl) {
     // area_pixel_compute_scale<float>
     float sh, sw;
     if (align_corners) {
@@ -646,10 +644,10 @@ int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, f
     const unsigned grid = (unsigned)std::min<int64_t>((int64_t)n * Ho, 1 << 20);
     if (C % 4 == 0)
         hipLaunchKernelGGL(k_bilinear<4>, dim3(grid), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy, align_corners, pre, sh, sw,
-                           excl_h, excl_w, cv_magic);
+                           excl, cv_magic);
     else
         hipLaunchKernelGGL(k_bilinear<1>, dim3(grid), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy, align_corners, pre, sh, sw,
-                           excl_h, excl_w, cv_magic);
+                           excl, cv_magic);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

@@ -878,6 +878,11 @@ bool plan_region(const ConvDesc &d, int tiles_y, int tiles_x, int ty_off, int tx
 // tiles: 16 columns as 2 x 16-tile blocks, 3 columns as 3-image x 7 x 3 blocks: 83 % -> 99.7 % of the slots used). Blocks of
 // the first region that hang over the split compute (and store) tiles of the second again: same values. Not for launches with a
 // fused 'interp' skip (the resize kernel's share is defined by ONE uniform block grid) nor with the fused first conv.
+// at most 32 candidate skip rows and 32 columns per block (one half-wave each lists them)
+bool skip_region_ok(const ConvDesc &d, const WinoGeom &g) {
+    return 2 * g.TY * (double)d.skip_h / d.OH + 4 <= 32 && 2 * g.TX * (double)d.skip_w / d.OW + 4 <= 32;
+}
+
 WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
     static const bool no_split = getenv("EVFLY_WINO_NO_SPLIT") != nullptr;      // A/B switch
     const int ty = cdiv(d.OH, 2), tx = cdiv(d.OW, 2);
@@ -885,13 +890,16 @@ WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
     p.nreg = 1;
     p.ok = plan_region(d, ty, tx, 0, 0, p.r[0]);
     if (p.ok && allow_split && !no_split) {
-        double best = p.r[0].g.cost * 0.97;          // a second launch has to pay for itself
+        double best = p.r[0].g.cost * 0.95;          // a second launch has to pay for itself (a predicted 3 % measured as a wash on e22)
         for (int dir = 0; dir < 2; ++dir)
             for (int s = 1; s < (dir ? ty : tx); ++s) {
                 WinoRegion a, b;
                 const bool oka = dir ? plan_region(d, s, tx, 0, 0, a) : plan_region(d, ty, s, 0, 0, a);
                 const bool okb = dir ? plan_region(d, ty - s, tx, s, 0, b) : plan_region(d, ty, tx - s, 0, s, b);
-                if (oka && okb && a.g.cost + b.g.cost < best) { best = a.g.cost + b.g.cost; p.r[0] = a; p.r[1] = b; p.nreg = 2; }
+                if (!oka || !okb) continue;
+                // fused skip: no block of the first region may straddle the split (SkipGrid), both regions within the candidate budget
+                if (d.skip_y && (s % (dir ? a.g.TY : a.g.TX) != 0 || !skip_region_ok(d, a.g) || !skip_region_ok(d, b.g))) continue;
+                if (a.g.cost + b.g.cost < best) { best = a.g.cost + b.g.cost; p.r[0] = a; p.r[1] = b; p.nreg = 2; }
             }
     }
     p.c = p.r[0].c; p.g = p.r[0].g;
@@ -911,8 +919,9 @@ const WinoPlan &cached_plan(const ConvDesc &d) {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int, int, int>, WinoPlan> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const bool allow_split = !d.skip_y && !d.pre_frames;
-    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, (int)allow_split);
+    const bool allow_split = !d.pre_frames;
+    // (a fused skip constrains the split: keyed by the skip size too)
+    const auto key = std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, !allow_split ? -1 : d.skip_y ? d.skip_h * 4096 + d.skip_w : 0);
     auto it = cache.find(key);
     if (it == cache.end()) it = cache.emplace(key, make_plan(d, allow_split)).first;
     return it->second;
@@ -1073,13 +1082,20 @@ double wino_efficiency(const ConvDesc &d) { return cached_plan(d).efficiency; }
 
 double wino_exec_flops(const ConvDesc &d) { return cached_plan(d).exec_flops; }
 
-void wino_block_region(const ConvDesc &d, int *rh, int *rw) {
+void wino_skip_grid(const ConvDesc &d, SkipGrid *sg) {
+    *sg = SkipGrid();
     const WinoPlan &p = cached_plan(d);
-    *rh = 2 * p.g.TY; *rw = 2 * p.g.TX;
-    // the kernel lists at most 32 candidate skip rows and 32 columns per block (one half-wave each)
-    if (d.skip_y && (d.skip_h <= 0 || d.skip_w <= 0 || *rh * (double)d.skip_h / d.OH + 4 > 32 || *rw * (double)d.skip_w / d.OW + 4 > 32 ||
-                     d.skip_ld % 4 != 0 || ((uintptr_t)d.skip_y) % 16 != 0 || d.Nc % 4 != 0 || (int64_t)d.skip_h * d.skip_w * d.skip_ld >= ((int64_t)1 << 31)))
-        *rh = *rw = 0;
+    if (!p.ok || !d.skip_y || d.skip_h <= 0 || d.skip_w <= 0 || d.skip_ld % 4 != 0 || ((uintptr_t)d.skip_y) % 16 != 0 || d.Nc % 4 != 0 ||
+        (int64_t)d.skip_h * d.skip_w * d.skip_ld >= ((int64_t)1 << 31))
+        return;
+    for (int i = 0; i < p.nreg; ++i)
+        if (!skip_region_ok(d, p.r[i].g)) return;
+    sg->rh0 = 2 * p.r[0].g.TY; sg->rw0 = 2 * p.r[0].g.TX;
+    if (p.nreg == 2) {
+        sg->dir = p.r[1].g.ty_off > 0 ? 1 : 0;
+        sg->pos = 2 * (sg->dir ? p.r[1].g.ty_off : p.r[1].g.tx_off);
+        sg->rh1 = 2 * p.r[1].g.TY; sg->rw1 = 2 * p.r[1].g.TX;
+    }
 }
 
 int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
@@ -1091,9 +1107,9 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
     EVFLY_REQUIRE(!d.pre_frames || (d.C == 32 && d.pre_w && d.pre_b && (d.pre_cin == 1 || d.pre_cin == 2)),
                   "wino: the fused first-conv producer needs C == 32 and 1 or 2 frame channels");
     if (d.skip_y) {
-        int rh = 0, rw = 0;
-        wino_block_region(d, &rh, &rw);
-        EVFLY_REQUIRE(rh > 0, "wino: this skip geometry cannot be fused (ask wino_block_region first)");
+        SkipGrid sg;
+        wino_skip_grid(d, &sg);
+        EVFLY_REQUIRE(sg.rh0 > 0, "wino: this skip geometry cannot be fused (ask wino_skip_grid first)");
     }
     const bool one = d.C == 32, pre = d.pre_frames != nullptr;
     for (int i = 0; i < pl.nreg; ++i) {
