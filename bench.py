@@ -305,9 +305,10 @@ def main():
             g = None
             if gs:
                 g = {k: sum(x[k] for x in gs) for k in ("fetch_bytes_per_step", "write_bytes_per_step")}
-                g["launches_per_step"] = 17
+                # kernel launches of the family per step (17 conv layers; Winograd split plans run two launches for some of them)
+                g["launches_per_step"] = max(1, round(dom["launches"] / a.steps))
                 traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
-                tnote = ("HBM bytes per launch, mean over the %d conv3x3 launches of a step: (2 x FETCH_SIZE + WRITE_SIZE) from "
+                tnote = ("HBM bytes per launch, mean over the %d conv3x3 kernel launches of a step (17 layers): (2 x FETCH_SIZE + WRITE_SIZE) from "
                          "profiles/%s; algorithmic = algorithmic.bytes_per_launch" % (g["launches_per_step"], os.path.basename(pmc)))
         if dom["flops"]:
             # `achieved` = the flops the matrix cores EXECUTE per second in this kernel family (exec_flops, from the launch plans);

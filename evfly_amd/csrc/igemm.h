@@ -125,6 +125,8 @@ double wino_exec_flops(const ConvDesc &d);     // MFMA flops one launch issues (
 // block regions of the launch(es) wino_launch(d) will run, for a d with skip_y / skip_h / skip_w set (rh0 == 0: this skip
 // geometry cannot be fused)
 void wino_skip_grid(const ConvDesc &d, SkipGrid *g);
+// kernel launches wino_launch(d) issues: 1, or 2 with a split plan
+int wino_launch_count(const ConvDesc &d);
 
 // algorithmic work of one launch (for the profile / roofline accounting)
 inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }

@@ -36,6 +36,7 @@ struct Tap {
 struct ProfRec {
     std::string name;
     double flops, bytes, exec, useful;
+    int launches;               // kernel launches behind the site (2: a Winograd split plan)
     hipEvent_t e0, e1;
 };
 struct ProfAgg {
@@ -135,10 +136,12 @@ struct evfly_model {
     // fused first-conv producer for the next conv() call (consumed and cleared there; Winograd path only)
     struct { const float *frames = nullptr, *w = nullptr, *b = nullptr; int cin = 0, form_bev = 0, apply_form = 0; float cutoff = 0.f; } pre;
     double next_exec = 0, next_useful = 0;   // set by conv() before RUN when the kernel issues fewer flops than the algorithmic count
+    int next_launches = 1;
     int prof_begin(const char *name, double flops, double bytes) {
         const double ex = next_exec > 0 ? next_exec : flops;
         const double us = next_useful > 0 ? next_useful : flops;
-        next_exec = 0; next_useful = 0;
+        const int nl = next_launches;
+        next_exec = 0; next_useful = 0; next_launches = 1;
         prof_skipped = false;
         if (!profiling || planning) return 0;
         if (!prof_filter.empty() && std::strncmp(name, prof_filter.c_str(), prof_filter.size()) != 0) { prof_skipped = true; return 0; }
@@ -147,7 +150,7 @@ struct evfly_model {
             EVFLY_HIP(hipEventCreate(&e));
             ev_pool.push_back(e);
         }
-        ProfRec r{name, flops, bytes, ex, us, ev_pool[ev_used], ev_pool[ev_used + 1]};
+        ProfRec r{name, flops, bytes, ex, us, nl, ev_pool[ev_used], ev_pool[ev_used + 1]};
         ev_used += 2;
         EVFLY_HIP(hipEventRecord(r.e0, st));
         prof.push_back(r);
@@ -167,7 +170,7 @@ struct evfly_model {
             ProfAgg *a = nullptr;
             for (auto &x : agg) if (x.name == r.name) a = &x;
             if (!a) { agg.push_back(ProfAgg{r.name}); a = &agg.back(); }
-            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->exec += r.exec; a->useful += r.useful; a->launches += 1;
+            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->exec += r.exec; a->useful += r.useful; a->launches += r.launches;
         }
         prof.clear();
         ev_used = 0;
@@ -597,6 +600,7 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
         if (!m->planning && m->profiling) {                                    // only a profiled launch consumes them
             m->next_exec = wino_exec_flops(d);
             m->next_useful = igemm_flops(d) * (16.0 / 36.0);
+            m->next_launches = wino_launch_count(d);
         }
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes, wino_launch(d, m->W(wname + ".u"), m->st));
         return 0;

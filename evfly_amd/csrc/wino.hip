@@ -1082,6 +1082,8 @@ double wino_efficiency(const ConvDesc &d) { return cached_plan(d).efficiency; }
 
 double wino_exec_flops(const ConvDesc &d) { return cached_plan(d).exec_flops; }
 
+int wino_launch_count(const ConvDesc &d) { return cached_plan(d).nreg; }
+
 void wino_skip_grid(const ConvDesc &d, SkipGrid *sg) {
     *sg = SkipGrid();
     const WinoPlan &p = cached_plan(d);
