@@ -19,6 +19,7 @@
 #include "bf16.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace evfly {
@@ -762,7 +763,16 @@ template <int VEC, int PREC>
 int launch_by_n(const ConvDesc &d, hipStream_t st) {
     static const int nbuf = getenv("EVFLY_IGEMM_NBUF") ? atoi(getenv("EVFLY_IGEMM_NBUF")) : 2;
     if (nbuf == 2) {
-        if (d.Nc % 128 == 0) return launch_cfg<128, 128, 2, 2, VEC, PREC, 2>(d, st);
+        if (d.Nc % 128 == 0) {
+            // few 128 x 128 tiles per CU (ConvLSTM h-GEMM: 832 tiles = 3.25 per CU, i.e. CUs with 4 and CUs with 3): 64-row tiles
+            // halve the granule (6.5 per CU: 7 and 6), the fp32 MFMA is nowhere near LDS-bound
+            static const int small = getenv("EVFLY_IGEMM_64") ? atoi(getenv("EVFLY_IGEMM_64")) : 1;
+            const int64_t t128 = (int64_t)cdiv(d.M, 128) * (d.Nc / 128);
+            const double per_cu = (double)t128 / kNumCU;
+            if (small && PREC == 0 && per_cu < 6.0 && per_cu > 1.0 && std::ceil(per_cu) / per_cu > 1.12)
+                return launch_cfg<64, 128, 2, 2, VEC, PREC, 2>(d, st);
+            return launch_cfg<128, 128, 2, 2, VEC, PREC, 2>(d, st);
+        }
         if (d.Nc > 32) return launch_cfg<256, 64, 4, 1, VEC, PREC, 2>(d, st);
         return launch_cfg<256, 32, 4, 1, VEC, PREC, 2>(d, st);
     }
