@@ -890,7 +890,7 @@ WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
     p.nreg = 1;
     p.ok = plan_region(d, ty, tx, 0, 0, p.r[0]);
     if (p.ok && allow_split && !no_split) {
-        double best = p.r[0].g.cost * 0.95;          // a second launch has to pay for itself (a predicted 3 % measured as a wash on e22)
+        double best = p.r[0].g.cost * 0.97;          // a second launch has to pay for itself (e32 at a cost ratio of 0.963: -5.7 %)
         for (int dir = 0; dir < 2; ++dir)
             for (int s = 1; s < (dir ? ty : tx); ++s) {
                 WinoRegion a, b;
