@@ -46,3 +46,17 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_centre_crop_roi_is_run_py_crop():
+    """voxelizer.centre_crop_roi == the slice of evfly_ros/run.py:349-350 (`[H//2 - h//2 : H//2 + h//2, W//2 - w//2 : W//2 + w//2]`)."""
+    import numpy as np
+    from evfly_amd.voxelizer import centre_crop_roi
+    import pytest
+    for (H, W, h, w) in ((480, 640, 260, 346), (260, 346, 260, 346), (481, 641, 260, 346), (300, 400, 2, 4)):
+        a = np.arange(H * W).reshape(H, W)
+        want = a[H // 2 - h // 2: H // 2 + h // 2, W // 2 - w // 2: W // 2 + w // 2]
+        t, l, rh, rw = centre_crop_roi(H, W, (h, w))
+        assert (rh, rw) == (h, w) and np.array_equal(a[t:t + rh, l:l + rw], want)
+    with pytest.raises(ValueError):
+        centre_crop_roi(480, 640, (261, 346))
