@@ -42,6 +42,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -846,7 +847,8 @@ struct WinoCfg { int MT, ND, nbuf; int max_px() const { return ND * MT * 32; } }
 
 struct WinoRegion { WinoCfg c; WinoGeom g; };
 // one launch per region: the whole map, or two regions (a column or a row split of the tile grid) with their own arrangements
-struct WinoPlan { WinoRegion r[2]; int nreg; double exec_flops, efficiency; bool ok; WinoCfg c; WinoGeom g; };      // c, g = r[0] (unsplit plans)
+constexpr int kMaxRegions = 4;
+struct WinoPlan { WinoRegion r[kMaxRegions]; int nreg; double exec_flops, efficiency; bool ok; WinoCfg c; WinoGeom g; };      // c, g = r[0] (unsplit plans)
 
 // 512-thread blocks (64 tiles, two 40 KB patch buffers, two blocks per CU) unless the 256-thread block (32 tiles, two
 // 24 KB buffers, three blocks per CU) fills its tile slots much better (e51: 40 tiles per image). EVFLY_WINO_MT = 1 / 2
@@ -890,17 +892,60 @@ WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
     p.nreg = 1;
     p.ok = plan_region(d, ty, tx, 0, 0, p.r[0]);
     if (p.ok && allow_split && !no_split) {
-        double best = p.r[0].g.cost * 0.97;          // a second launch has to pay for itself (e32 at a cost ratio of 0.963: -5.7 %)
-        for (int dir = 0; dir < 2; ++dir)
-            for (int s = 1; s < (dir ? ty : tx); ++s) {
-                WinoRegion a, b;
-                const bool oka = dir ? plan_region(d, s, tx, 0, 0, a) : plan_region(d, ty, s, 0, 0, a);
-                const bool okb = dir ? plan_region(d, ty - s, tx, s, 0, b) : plan_region(d, ty, tx - s, 0, s, b);
-                if (!oka || !okb) continue;
-                // fused skip: no block of the first region may straddle the split (SkipGrid), both regions within the candidate budget
-                if (d.skip_y && (s % (dir ? a.g.TY : a.g.TX) != 0 || !skip_region_ok(d, a.g) || !skip_region_ok(d, b.g))) continue;
-                if (a.g.cost + b.g.cost < best) { best = a.g.cost + b.g.cost; p.r[0] = a; p.r[1] = b; p.nreg = 2; }
+        // guillotine partition: a region is kept whole or cut by a column / row split whose two sides may be partitioned in turn,
+        // every cut only where the summed plan cost drops by more than 3 % (a launch has to pay for itself: e32 at a cost ratio of
+        // 0.963 measured -5.7 %). A fused skip allows one cut (SkipGrid describes two grids).
+        struct Part { std::vector<WinoRegion> regs; double cost; bool ok; };
+        // (a region's arrangement depends on its extent only: searched once per extent, the offsets filled in per use)
+        std::map<std::pair<int, int>, std::pair<bool, WinoRegion>> memo;
+        auto plan_region = [&](const ConvDesc &dd, int rty, int rtx, int oy, int ox, WinoRegion &out) -> bool {
+            auto it = memo.find({rty, rtx});
+            if (it == memo.end()) {
+                WinoRegion r;
+                const bool ok = evfly::plan_region(dd, rty, rtx, 0, 0, r);
+                it = memo.emplace(std::make_pair(rty, rtx), std::make_pair(ok, r)).first;
             }
+            out = it->second.second;
+            out.g.ty_off = oy; out.g.tx_off = ox;
+            return it->second.first;
+        };
+        std::function<Part(int, int, int, int, int)> part = [&](int rty, int rtx, int oy, int ox, int depth) -> Part {
+            Part whole;
+            whole.regs.resize(1);
+            whole.ok = plan_region(d, rty, rtx, oy, ox, whole.regs[0]);
+            whole.cost = whole.ok ? whole.regs[0].g.cost : 1e300;
+            if (!whole.ok || depth == 0) return whole;
+            Part best = whole;
+            double bar = whole.cost * 0.97;
+            for (int dir = 0; dir < 2; ++dir)
+                for (int sp = 1; sp < (dir ? rty : rtx); ++sp) {
+                    // (cheap bound first: the two sides as single regions)
+                    WinoRegion a1, b1;
+                    const bool oka = dir ? plan_region(d, sp, rtx, oy, ox, a1) : plan_region(d, rty, sp, oy, ox, a1);
+                    const bool okb = dir ? plan_region(d, rty - sp, rtx, oy + sp, ox, b1) : plan_region(d, rty, rtx - sp, oy, ox + sp, b1);
+                    if (!oka || !okb) continue;
+                    if (d.skip_y && (sp % (dir ? a1.g.TY : a1.g.TX) != 0 || !skip_region_ok(d, a1.g) || !skip_region_ok(d, b1.g))) continue;
+                    Part a, b;
+                    if (depth > 1 && !d.skip_y) {
+                        a = dir ? part(sp, rtx, oy, ox, depth - 1) : part(rty, sp, oy, ox, depth - 1);
+                        b = dir ? part(rty - sp, rtx, oy + sp, ox, depth - 1) : part(rty, rtx - sp, oy, ox + sp, depth - 1);
+                    } else {
+                        a.regs = {a1}; a.cost = a1.g.cost; a.ok = true;
+                        b.regs = {b1}; b.cost = b1.g.cost; b.ok = true;
+                    }
+                    if (a.cost + b.cost < bar && (int)(a.regs.size() + b.regs.size()) <= kMaxRegions) {
+                        bar = a.cost + b.cost;
+                        best.regs = a.regs;
+                        best.regs.insert(best.regs.end(), b.regs.begin(), b.regs.end());
+                        best.cost = bar;
+                    }
+                }
+            return best;
+        };
+        // (depth 2 -- up to four launches, 41 per C2 step -- measured as a wash: e31 / d11 -2..3 %, d21 / d31 / d22 / d42 +2..3 %)
+        const Part pt = part(ty, tx, 0, 0, 1);
+        p.nreg = (int)pt.regs.size();
+        for (int i = 0; i < p.nreg; ++i) p.r[i] = pt.regs[i];
     }
     p.c = p.r[0].c; p.g = p.r[0].g;
     p.exec_flops = p.efficiency = 0;
@@ -1093,6 +1138,7 @@ void wino_skip_grid(const ConvDesc &d, SkipGrid *sg) {
     for (int i = 0; i < p.nreg; ++i)
         if (!skip_region_ok(d, p.r[i].g)) return;
     sg->rh0 = 2 * p.r[0].g.TY; sg->rw0 = 2 * p.r[0].g.TX;
+    if (p.nreg > 2) { *sg = SkipGrid(); return; }          // (never planned with a fused skip)
     if (p.nreg == 2) {
         sg->dir = p.r[1].g.ty_off > 0 ? 1 : 0;
         sg->pos = 2 * (sg->dir ? p.r[1].g.ty_off : p.r[1].g.tx_off);
