@@ -782,7 +782,11 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px, int tiles_y, int t
                 const int np = IM * (2 * TY + 2) * (2 * TX + 2);
                 if (np > max_px) continue;
                 const int64_t blocks = (int64_t)cdiv(tiles_y, TY) * cdiv(tiles_x, TX) * cdiv(d.NI, IM);
-                const double cost = (double)blocks * (slots + 0.1 * np);
+                // fused first conv: the producer's items are (run of three pixel pairs of a patch row, 4-channel group); an
+                // arrangement whose item count just exceeds the block's threads runs a second, nearly empty pass (8 x 4 tiles:
+                // 288 items on 256 threads; 4 x 8 tiles: 240) -- one pass costs about what six tile slots do
+                const int pre_passes = d.pre_frames ? cdiv(IM * (2 * TY + 2) * cdiv(TX + 1, 3) * 8, 256 * MT) : 0;
+                const double cost = (double)blocks * (slots + 0.1 * np + 6.0 * pre_passes);
                 if (best < 0 || cost < best) { best = cost; g.IMGS = IM; g.TY = TY; g.TX = TX; }
             }
     if (best < 0) return false;
