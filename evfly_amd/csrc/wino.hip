@@ -342,8 +342,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs
     const int mt = MT == 2 ? (wv & 1) : 0, a = MT == 2 ? (wv >> 1) : wv;
-    const int fm = lane & 31, fh = lane >> 5;
-    const int per = g.TY * g.TX;
+    const int fm = lane & 31;
     // ---- prologue queue, hand-counted like the rest: [table entries, fragment table] -> block decode (scalar) -> [U0, U1]
     // -> vmcnt(2) -> patch offsets from the table -> [DMA pieces of chunk 0] -> chunk-0 barrier at vmcnt(0).
     // The lane tables do not depend on the block: they are requested before anything else, and their L2 round trip runs
