@@ -772,7 +772,7 @@ __global__ void k_wino_weights(const float *__restrict__ w, int cout, int cin, i
 bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px, int tiles_y, int tiles_x, int ty_off, int tx_off) {
     const int slots = 32 * MT;
     // cost of a plan ~ launched work: every block pays its tile slots (MFMA time, used or not) and its patch pixels
-    // (DMA + LDS traffic; ~5 px per tile for a square arrangement, far more for thin ones)
+    // (DMA + LDS traffic; ~5 px per tile for a square arrangement, far more for thin ones; weight 0.06 slot per pixel)
     double best = -1;
     for (int IM = 1; IM <= 4; ++IM)
         for (int TY = 1; TY <= std::min(tiles_y, 32); ++TY)
@@ -785,7 +785,8 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px, int tiles_y, int t
                 // arrangement whose item count just exceeds the block's threads runs a second, nearly empty pass (8 x 4 tiles:
                 // 288 items on 256 threads; 4 x 8 tiles: 240) -- one pass costs about what six tile slots do
                 const int pre_passes = d.pre_frames ? cdiv(IM * (2 * TY + 2) * cdiv(TX + 1, 3) * 8, 256 * MT) : 0;
-                const double cost = (double)blocks * (slots + 0.1 * np + 6.0 * pre_passes);
+                static const double npw = getenv("EVFLY_WINO_NPW") ? atof(getenv("EVFLY_WINO_NPW")) : 0.06;     // tuning switch (0.03 / 0.06 / 0.1 / 0.15 / 0.25: 17.05 / 16.98 / 17.12 / 17.22 / 17.36 ms per C2 step)
+                const double cost = (double)blocks * (slots + npw * np + 6.0 * pre_passes);
                 if (best < 0 || cost < best) { best = cost; g.IMGS = IM; g.TY = TY; g.TX = TX; }
             }
     if (best < 0) return false;
