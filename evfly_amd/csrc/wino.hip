@@ -920,7 +920,8 @@ WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
             whole.cost = whole.ok ? whole.regs[0].g.cost : 1e300;
             if (!whole.ok || depth == 0) return whole;
             Part best = whole;
-            double bar = whole.cost * 0.97;
+            static const double split_t = getenv("EVFLY_WINO_SPLIT_T") ? atof(getenv("EVFLY_WINO_SPLIT_T")) : 0.97;      // tuning switch
+            double bar = whole.cost * split_t;
             for (int dir = 0; dir < 2; ++dir)
                 for (int sp = 1; sp < (dir ? rty : rtx); ++sp) {
                     // (cheap bound first: the two sides as single regions)
