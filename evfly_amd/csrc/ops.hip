@@ -221,6 +221,32 @@ __global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, i
     }
 }
 
+// single-channel maps (the depth image: 68 x 148 -> 260 x 346, and the ViT's 60 x 90 input): one thread = two adjacent output pixels
+// of a row, one 8-B store (k_bilinear<1> spends a block per 346-pixel row and a 4-B store per thread: 1 TB/s on a pure write
+// stream). Same index / weight arithmetic and the same expression per pixel: the same bits.
+__global__ __launch_bounds__(256) void k_bilinear_c1(const float *__restrict__ x, int n, int Hi, int Wi, float *__restrict__ y, int Ho, int Wo,
+                                                     int align, int pre, float sh, float sw) {
+    const int W2 = Wo >> 1;
+    const int64_t total = (int64_t)n * Ho * W2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / W2), ox = 2 * (int)(i - (int64_t)row * W2);
+        const int img = row / Ho, oy = row - img * Ho;
+        int y0, y1, x0, x1;
+        float hy0, hy1, wx0, wx1;
+        bilinear_src_index(oy, Hi, Ho, sh, align, y0, y1, hy0, hy1);
+        const float *b0 = x + ((int64_t)img * Hi + y0) * Wi, *b1 = x + ((int64_t)img * Hi + y1) * Wi;
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            bilinear_src_index(ox + e, Wi, Wo, sw, align, x0, x1, wx0, wx1);
+            const float t0 = pre_op(b0[x0], pre) * wx0 + pre_op(b0[x1], pre) * wx1;
+            const float t1 = pre_op(b1[x0], pre) * wx0 + pre_op(b1[x1], pre) * wx1;
+            o[e] = t0 * hy0 + t1 * hy1;
+        }
+        *reinterpret_cast<float2 *>(y + (int64_t)row * Wo + ox) = make_float2(o[0], o[1]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_crop(const float4 *__restrict__ x, int n, int Hi, int Wi, int C4, int top, int left,
                                               float4 *__restrict__ y, int Ho, int Wo, int64_t ldy4) {
     const int64_t total = (int64_t)n * Ho * Wo * C4;
@@ -637,6 +663,12 @@ int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, f
     } else {
         sh = (float)Hi / (float)Ho;
         sw = (float)Wi / (float)Wo;
+    }
+    if (C == 1 && ldx == 1 && ldy == 1 && (Wo & 1) == 0 && excl.rh0 == 0 && (((uintptr_t)y) & 7) == 0 && (int64_t)n * Ho < ((int64_t)1 << 31)) {
+        const int64_t work = (int64_t)n * Ho * (Wo / 2);
+        hipLaunchKernelGGL(k_bilinear_c1, dim3(grid_for(work, 256)), dim3(256), 0, st, x, n, Hi, Wi, y, Ho, Wo, align_corners, pre, sh, sw);
+        EVFLY_LAUNCH_CHECK();
+        return 0;
     }
     const int CV = C % 4 == 0 ? C / 4 : C;
     EVFLY_REQUIRE((int64_t)n * Ho < ((int64_t)1 << 31) && (int64_t)Wo * CV * CV < ((int64_t)1 << 32), "bilinear: map too large");
