@@ -370,6 +370,47 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ a, 
 // ------------------------------------------------------------------------------------------ attention
 // One thread per (token, head), head dim 32. ViTsubmodules.py:74-80: keyVal rows are [2][heads][d].
 constexpr int kMaxKV = 16;
+// eight lanes per (token, head): lane c holds channels 4 c .. 4 c + 3 of the head's 32 -- one 16-B load of q and one 16-B store
+// per lane, a wave moves 8 x 128 contiguous bytes per instruction (the thread-per-head kernel below strides its lanes by 128 B:
+// every 16-B load instruction touches 64 cache lines). The q.k dot products are finished with three lane exchanges.
+__global__ __launch_bounds__(256) void k_attention_v8(const float *__restrict__ q, const float *__restrict__ kv, int frames, int N, int nkv,
+                                                      int C, int heads, float *__restrict__ out) {
+    const int64_t total = (int64_t)frames * N * heads * 8;
+    const float dim_head = sqrtf((float)(C / heads));
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    // (trip counts are wave-uniform up to the last partial wave: the exchanges run on all lanes, stores are guarded)
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 - (threadIdx.x & 63) < total; i0 += stride) {
+        const bool live = i0 < total;
+        const int64_t i = live ? i0 : total - 1;
+        const int c4 = (int)(i & 7);
+        const int64_t th = i >> 3;
+        const int hd = (int)(th % heads);
+        const int64_t tok = th / heads;
+        const int f = (int)(tok / N);
+        const float4 qv = *reinterpret_cast<const float4 *>(q + tok * C + hd * 32 + c4 * 4);
+        const float *kvf = kv + (int64_t)f * nkv * 2 * C + hd * 32 + c4 * 4;
+        float sc[kMaxKV];
+        float mx = -INFINITY;
+        for (int j = 0; j < nkv; ++j) {
+            const float4 kk = *reinterpret_cast<const float4 *>(kvf + (int64_t)j * 2 * C);
+            float s = fmaf(qv.w, kk.w, fmaf(qv.z, kk.z, fmaf(qv.y, kk.y, qv.x * kk.x)));
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s = s / dim_head;
+            sc[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float den = 0.f;
+        for (int j = 0; j < nkv; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < nkv; ++j) {
+            const float p = sc[j] / den;
+            const float4 vv = *reinterpret_cast<const float4 *>(kvf + (int64_t)j * 2 * C + C);
+            o.x = fmaf(p, vv.x, o.x); o.y = fmaf(p, vv.y, o.y); o.z = fmaf(p, vv.z, o.z); o.w = fmaf(p, vv.w, o.w);
+        }
+        if (live) *reinterpret_cast<float4 *>(out + tok * C + hd * 32 + c4 * 4) = o;   // (attn@v).transpose(1,2).reshape(B,N,C)
+    }
+}
+
 __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ q, const float *__restrict__ kv, int frames,
                                                    int N, int nkv, int C, int heads, float *__restrict__ out) {
     const int64_t total = (int64_t)frames * N * heads;
@@ -749,6 +790,11 @@ int launch_attention(const float *q, const float *kv, int frames, int N, int nkv
                      hipStream_t st) {
     EVFLY_REQUIRE(C / heads == 32 && C % heads == 0, "attention: head dim must be 32 (C=%d heads=%d)", C, heads);
     EVFLY_REQUIRE(nkv >= 1 && nkv <= kMaxKV, "attention: %d reduced keys (max %d)", nkv, kMaxKV);
+    if ((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(k_attention_v8, dim3(grid_for((int64_t)frames * N * heads * 8, 256)), dim3(256), 0, st, q, kv, frames, N, nkv, C, heads, out);
+        EVFLY_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_attention, dim3(grid_for((int64_t)frames * N * heads, 256)), dim3(256), 0, st, q, kv, frames, N, nkv,
                        C, heads, out);
     EVFLY_LAUNCH_CHECK();
