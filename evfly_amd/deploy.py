@@ -13,7 +13,11 @@ from . import voxelizer
 
 class EventDepthVelocityNode:
     def __init__(self, model, evcam_hw=(480, 640), model_hw=(260, 346), des_fwd_vel=1.0, dodge_scaler=2.0,
-                 des_z=0.8, desvel=4.0, device="cuda", aligner=None):
+                 des_z=0.8, desvel=4.0, device="cuda", aligner=None, use_graph=False):
+        """use_graph: after two eager frames (they create the recurrent states and every lazily allocated buffer of the library)
+        the per-frame work -- conditioning + stateful forward, ~100 kernel launches for one frame -- is captured ONCE into a HIP
+        graph (torch.cuda.CUDAGraph) and replayed per frame: same kernels, same order, same bits, without the per-launch host cost.
+        The frame is copied into a static input buffer, the new recurrent states back into the static state buffers."""
         self.model = model.to(device).float().eval()
         self.device = device
         self.evcam_height, self.evcam_width = evcam_hw                 # run.py:41
@@ -26,13 +30,66 @@ class EventDepthVelocityNode:
         self.origunet_hidden_state = None                              # run.py:173-174
         self.velpred_hidden_state = None
         self.pred_vel = self.pred_depth = self.evframe = None
+        self.use_graph = use_graph and aligner is None
+        self._graph = None
+        self._eager_frames = 0
 
     def image_callback(self, data):
         """run.py:325-328: UInt8MultiArray payload -> (480, 640) uint8 view."""
         self.proc_evs = np.frombuffer(data, dtype=np.uint8).reshape(self.evcam_height, self.evcam_width)
 
+    @staticmethod
+    def _tensors(tree):
+        """the tensors of a nested list / tuple, depth first"""
+        if torch.is_tensor(tree):
+            yield tree
+        elif isinstance(tree, (list, tuple)):
+            for t in tree:
+                yield from EventDepthVelocityNode._tensors(t)
+
+    def _capture(self, frame_u8):
+        dev = self.device
+        self._g_src = torch.from_numpy(np.ascontiguousarray(frame_u8))[None].to(dev)
+        self._g_desvel = torch.tensor([[self.desvel]], device=dev)
+        self._g_unet = [[t.clone() for t in pair] for pair in self.origunet_hidden_state]        # [[h, c]] (convlstm.py:166-174)
+        self._g_vp = tuple(t.clone() for t in self.velpred_hidden_state)                         # (h, c) of the velocity LSTM
+
+        def body():
+            x = voxelizer.condition_frames(self._g_src, out_hw=self.model_hw)
+            with torch.no_grad():
+                x_vel, (x_depth, _, ((hs, _), vps)) = self.model([x, self._g_desvel, [self._g_unet, None], self._g_vp])
+            return x, x_vel, x_depth, hs, vps
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()                                            # the capture stream's own scratch buffers exist before the capture
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self._g_out = body()
+        self._graph = g
+
+    def _run_graph(self, frame_u8):
+        if self._graph is None:
+            self._capture(frame_u8)
+        self._g_src.copy_(torch.from_numpy(np.ascontiguousarray(frame_u8))[None])
+        self._graph.replay()
+        x, x_vel, x_depth, hs, vps = self._g_out
+        for dst, src in zip(self._tensors(self._g_unet), self._tensors(hs)):
+            dst.copy_(src)
+        for dst, src in zip(self._tensors(self._g_vp), self._tensors(vps)):
+            dst.copy_(src)
+        self.origunet_hidden_state, self.velpred_hidden_state = self._g_unet, self._g_vp
+        self.evframe = x
+        self.pred_vel = x_vel.cpu().numpy().squeeze()
+        self.pred_depth = x_depth.cpu().numpy().squeeze() if x_depth is not None else None
+        return self.pred_vel, self.pred_depth
+
     def run_model(self, frame_u8):
         """run.py:334-350 + 245-268 for one accumulator image (decode, centre crop, q97, forward)."""
+        if self.use_graph and self._eager_frames >= 2:
+            return self._run_graph(frame_u8)
+        self._eager_frames += 1
         src = torch.from_numpy(np.ascontiguousarray(frame_u8))[None]
         if self.align_evframe:
             # run.py:338-340 then :345-350: rectify (decode fused into the gather), producing only the centre-crop
