@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x3 pass (C2 only)")
+    ap.add_argument("--no-other-configs", action="store_true", help="default C2 run: skip the compact C5 / C3 / C4 objects")
     ap.add_argument("--no-stage-rates", action="store_true", help="skip the V / D / P-only timings")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     a = ap.parse_args()
@@ -142,18 +143,38 @@ def cpu_baseline(sd, cfg, budget_s):
     what = "U-Net + ConvLSTM" if cfg["model"] == "unet" else f"composite ({cfg['vit']} ViT)"
     out = {"value": best["value"], "unit": "event-frames/s", "cores": best["cores"], "kind": "port"}
     out.update(res)
-    out["sample"] = (f"streams of {T} windows x {epw} events at {hs}x{ws}: C voxelizer port + torch-CPU fp32 oracle forward of the {what}, "
+    out["sample"] = (f"`value` = the FASTEST of {len(res)} thread counts ({', '.join(str(r['cores']) for r in res.values())}; oneDNN on a many-core "
+                     f"host is slower on a {T}-frame batch with every core than with a few); streams of {T} windows x {epw} events at {hs}x{ws}: C voxelizer port + torch-CPU fp32 oracle forward of the {what}, "
                      f"batch-as-time; " + ", ".join(f"{r['streams']} stream(s) at {r['cores']} thread(s) ({r['seconds']} s)" for r in res.values()) +
-                     "; `value` = the fastest")
+                     "")
     return out
+
+
+def visible_gpus():
+    """GPUs this process could use, WITHOUT initialising the runtime (torch.cuda.device_count() only enumerates on this image;
+    /sys/class/kfd is the cross-check when torch reports none)."""
+    n = torch.cuda.device_count()
+    if n:
+        return n
+    import glob
+    cnt = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            kv = dict(l.split() for l in open(prop) if len(l.split()) == 2)
+            cnt += int(kv.get("simd_count", "0")) > 0
+        except OSError:
+            pass
+    return cnt
 
 
 def main():
     a = parse()
-    cfg = a.cfg
     if a.gpus > 1 and "RANK" not in os.environ:
         # not under a launcher: start one rank per GPU as CHILD processes (nothing in this process has touched the
         # GPU yet) and leave with their exit code -- never silently measure one GPU when N were asked for
+        have = visible_gpus()
+        if have < a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but this node exposes {have} GPU(s); refusing to start {a.gpus} ranks")
         import socket
         import subprocess
         with socket.socket() as sk:
@@ -167,12 +188,60 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("EVFLY_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL over xGMI
 
+    out = run_config(a, a.config, a.cfg, rank, world, dist, detail=True)
+    # BASELINE.json's other GPU configs in the SAME (driver-run) invocation: compact objects under `other_configs`; the ONE JSON
+    # line and `value` stay the headline config's. Only for the plain default run (no shape overrides), on one GPU.
+    if a.config == "C2" and a.cfg == CONFIGS["C2"] and world == 1 and not a.no_other_configs:
+        others = {}
+        for name in ("C5", "C3", "C4"):
+            t0 = time.perf_counter()
+            try:
+                o = run_config(a, name, dict(CONFIGS[name]), rank, world, dist, detail=False)
+                others[name] = compact(o, time.perf_counter() - t0)
+            except Exception as e:                                       # never lose the headline line to a side config
+                others[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            out["other_configs"] = others
+    # The ONE JSON line goes last: RCCL writes a banner (host name, library path) into the C stdio buffer, which a pipe only
+    # flushes at exit -- behind everything Python printed, on every rank. Flush C stdio on all ranks, meet, then print.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def compact(o, wall_s):
+    """One BASELINE config as a compact object of the headline line's `other_configs`."""
+    r = o.get("roofline", {})
+    c = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "step_ms": o.get("step_ms"), "dtype": o["dtype"],
+         "steps": o["steps"], "warmup": o["warmup"], "workload": o["config"]["workload"],
+         "roofline": {k: r.get(k) for k in ("kernel", "bound", "frac", "frac_useful", "achieved", "peak", "unit", "launches", "avg_launch_ms")},
+         "step_mfma_util": o.get("step_mfma_util"),
+         "top_kernels": [{k: q[k] for k in ("name", "ms_per_step", "tflops")} for q in o.get("kernels", [])[:6]],
+         "stages": {k: o.get("stages", {}).get(k) for k in ("voxelize_ms", "condition_ms", "model_ms")},
+         "wall_s_incl_setup": round(wall_s, 1)}
+    if "hbm" in r:
+        c["roofline"]["hbm_frac_algorithmic"] = r["hbm"]["frac"]
+    if "convlstm" in o:
+        c["convlstm"] = {k: o["convlstm"][k] for k in ("serial_critical_path_ms_per_step", "steps_in_series")}
+    return c
+
+
+def run_config(a, cname, cfg, rank, world, dist, detail):
+    """Measure one BASELINE workload: W warm-up steps, exactly K timed steps between barrier + synchronize pairs (max over ranks).
+    detail: the full line (stage rates, alt precision, CPU baseline); otherwise what `compact` keeps."""
     from evfly_amd import synthetic as syn, voxelizer
     from evfly_amd.distributed import gather_velocities, shard_row_counts
     B, T, epw, (Hs, Ws), dtype = cfg["streams"], cfg["windows"], cfg["epw"], cfg["sensor"], cfg["dtype"]
@@ -227,18 +296,41 @@ def main():
         L.evfly_model_profile_reset(hip.h)
         L.evfly_model_set_profile_filter(hip.h, dom_name.encode())
         L.evfly_model_set_profiling(hip.h, 1)
+        # one event per step boundary on the launch stream (a record is ~1 us of host time, no synchronisation): the spread of
+        # the K steps inside the one timed region
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
         sync()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        marks[0].record()
+        for i in range(a.steps):
             out_dev = step()
+            marks[i + 1].record()
         sync()
         dt = time.perf_counter() - t0
         L.evfly_model_set_profiling(hip.h, 0)
         L.evfly_model_set_profile_filter(hip.h, None)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    step_ms = {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),
+               "note": "GPU time between per-step events on the launch stream inside the timed region"}
+    rank_ms, gather_us = None, None
     if dist is not None:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        mine = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        every = torch.empty(max(world, 1), device="cuda", dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        rank_ms = [round(1e3 * float(v) / a.steps, 3) for v in every.tolist()]   # where a scaling loss sits: per-rank ms/step
+        tmax = mine.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if composite:
+            # the one collective of the path, alone: 50 back-to-back all_gathers of this rank's velocity rows
+            vel_mine = out_dev[rank * B * T:(rank + 1) * B * T].contiguous()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            gather_velocities(vel_mine, dist, counts=counts); sync()
+            g0.record()
+            for _ in range(50):
+                gather_velocities(vel_mine, dist, counts=counts)
+            g1.record(); torch.cuda.synchronize()
+            gather_us = round(1e3 * g0.elapsed_time(g1) / 50, 2)
     if composite:
         assert out_dev.shape == (world * B * T, 3) and torch.isfinite(vel_host).all() and torch.equal(vel_host, out_dev.cpu())
     else:
@@ -257,7 +349,14 @@ def main():
     with torch.no_grad():
         vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi))
         cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W)))
-    vox_bytes = 13.0 * n_events + 4.0 * B * T * H * W          # read events once, write the (cropped) frames once
+        # the same stage for a batch whose pass-1 tables do not exist yet (fresh events every call, SURVEY.md §8d's definition):
+        # sortedness check + window ranges over the 8-B timestamps, then the accumulation
+        ev_raw = {k: v for k, v in ev.items() if k not in ("starts", "unsorted", "skip_kernels")}
+        vox1_ms = time_stage(lambda: voxelizer.voxelize_windows(ev_raw, Hs, Ws, out="f32", frames=frames, roi=roi))
+    # bytes the timed kernel moves: x, y, p of every event once (5 B; the timestamps were consumed by pass 1 at upload) + the
+    # (cropped) f32 frames once; with pass 1: + 8 B/event of timestamps = SURVEY.md §8d's 13 B/event
+    vox_bytes = 5.0 * n_events + 4.0 * B * T * H * W
+    vox1_bytes = 13.0 * n_events + 4.0 * B * T * H * W
 
     def families(recs):
         fam = {}
@@ -281,13 +380,18 @@ def main():
         "value": round(frames_per_step * a.steps / dt, 2), "unit": "event-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"{a.config}: {B} streams x {T} windows per GPU,{crop} 260x346, {epw} events/window, {what}, "
+        "config": {"workload": f"{cname}: {B} streams x {T} windows per GPU,{crop} 260x346, {epw} events/window, {what}, "
                                f"batch-as-time per stream; velocities end in pinned host memory" if composite else
-                               f"{a.config}: {B} streams x {T} windows per GPU (seq_len {T}), 260x346, {epw} events/window, {what}, "
+                               f"{cname}: {B} streams x {T} windows per GPU (seq_len {T}), 260x346, {epw} events/window, {what}, "
                                f"batch-as-time per stream; depth maps stay in HBM",
                    "streams_per_gpu": B, "windows": T, "events_per_step_per_gpu": n_events, "sensor": [Hs, Ws], "vit_trunk": cfg["vit"] if composite else None,
                    "parallelism": f"streams sharded x{world}, all_gather of velocities" if world > 1 else "single GPU"},
+        "step_ms": step_ms,
     }
+    if dist is not None:
+        out["ranks"] = {"ms_per_step_by_rank": rank_ms, "all_gather_us": gather_us,
+                        "note": "ms/step of every rank between its own barrier + synchronize pairs (`ms_per_step` = their max); all_gather_us = "
+                                "the velocity all_gather alone (RCCL, 50 back-to-back calls on this rank's rows)"}
     if rank == 0:
         peak = PEAK[dtype]
         sec = dom["ms"] * 1e-3
@@ -295,8 +399,8 @@ def main():
         # --pmc WRITE_SIZE, separate runs of this script at this config's default shape; FETCH doubled per the gfx950
         # calibration in profiles/README.md). PMC counters cannot be read inside this process, so the figure is null for other shapes.
         traffic, tnote = None, "no PMC summary for this shape/dtype"
-        pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in PMC_TRAFFIC.get(a.config, ())) if os.path.exists(q)), None)
-        if pmc and cfg == CONFIGS[a.config]:
+        pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in PMC_TRAFFIC.get(cname, ())) if os.path.exists(q)), None)
+        if pmc and cfg == CONFIGS[cname]:
             ks = json.load(open(pmc))["kernels"]
             # fp32: the 17 Winograd launches; bf16 pipeline: the 3x3 convs run on two kernels (direct conv for C_in <= 64, implicit
             # GEMM beyond; the GEMM family's count also holds the ViT / velpred convs, a rounding error in bytes)
@@ -351,13 +455,19 @@ def main():
         out["conv_layers"] = [{"name": p["name"], "ms_per_step": round(p["ms"], 3),
                                "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)}
                               for p in layers if p["name"].startswith(dom["name"] + "/")]
-        out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_GBs_algorithmic": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
+        out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_bytes_moved": vox_bytes,
+                         "voxelize_GBs": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
                          "voxelize_frac_of_hbm_peak": round(vox_bytes / (vox_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "voxelize_with_pass1_ms": round(vox1_ms, 4), "voxelize_with_pass1_bytes": vox1_bytes,
+                         "voxelize_with_pass1_GBs": round(vox1_bytes / (vox1_ms * 1e-3) / 1e9, 1),
+                         "voxelize_with_pass1_frac_of_hbm_peak": round(vox1_bytes / (vox1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms, 3),
-                         "voxelize_note": "the events are resident (uploaded before the timed region) together with the voxelizer's pass-1 "
-                                          "tables (evfly_voxel_prepare: per-stream sortedness, window -> event ranges; they depend on the "
-                                          "timestamps and edges only): a step accumulates and writes the frames"}
-        if not a.no_stage_rates:
+                         "voxelize_note": "voxelize_ms = what a timed step runs: the events are resident together with the voxelizer's pass-1 "
+                                          "tables (evfly_voxel_prepare at upload: per-stream sortedness, window -> event ranges), so the step's "
+                                          "kernel k_vox_band reads x, y, p (5 B/event) and writes the frames; voxelize_with_pass1 = the same "
+                                          "call on a batch without tables (k_check_sorted + k_window_ranges read the 8-B timestamps first: "
+                                          "13 B/event, SURVEY.md §8d's definition for fresh events); fractions = those bytes / ms / 8 TB/s"}
+        if detail and not a.no_stage_rates:
             # labelled per-stage rates ("publish both P-only and V+D+P"): each stage alone on the same batch,
             # inputs resident, torch events on the launch stream. V = voxelize + condition, D = OrigUNet + ConvLSTM,
             # P = ViT + LSTM on 260x346 depth images (resize to 60x90 inside, like the composite's hand-off).
@@ -385,7 +495,7 @@ def main():
             serial = sum(p["ms"] for p in prof if p["name"] in ("convlstm_h_gemm", "convlstm_gates"))
             xg = sum(p["ms"] for p in prof if p["name"] == "convlstm_x_gemm")
             one_ms = None
-            if not a.no_stage_rates:
+            if detail and not a.no_stage_rates:
                 with torch.no_grad():
                     x1 = voxelizer.condition_frames(frames.view(B * T, H, W)[:T], out_hw=(H, W))
                     one_ms = time_stage(lambda: model.forward_streams(x1, None, 1, T), reps=5)
@@ -397,7 +507,7 @@ def main():
                                        f"{T}-frame sequence through the U-Net alone (latency-bound: {T} frames do not fill the chip)"}
         mf = sum(p["flops"] for p in prof if p["flops"])
         out["mfma_flops_per_frame"] = mf / (B * T)
-        if world == 1 and a.config == "C2" and dtype == "f32" and not a.no_alt:
+        if detail and world == 1 and cname == "C2" and dtype == "f32" and not a.no_alt:
             # Informational second precision mode, NOT the headline `value`: the bf16 pipeline (bf16 activations in HBM, bf16
             # MFMA, fp32 accumulate). Same inputs, same weights; the velocity deviation from the exact-fp32 run is reported with it.
             vel_f32 = out_dev.clone()
@@ -416,18 +526,14 @@ def main():
                                     "max_rel_dev_velocity_vs_f32": float(((v3 - vel_f32).abs().max() / vel_f32.abs().max()).item()),
                                     "note": "bf16 pipeline (BASELINE configs C3 / C5 run in it); informational, not the headline"}
             model.set_compute_dtype("f32")
-        if not a.no_cpu_baseline and world == 1:
+        if detail and not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, a.cpu_seconds)
-    # The ONE JSON line goes last: RCCL writes a banner (host name, library path) into the C stdio buffer, which a pipe only
-    # flushes at exit -- behind everything Python printed, on every rank. Flush C stdio on all ranks, meet, then print.
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-    sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # release this config's device memory (events, frames, the model handle's arena) before the next one is built
+    del model, hip, ev, frames, out_dev, desvel
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from .._hipmodule import _inference_only
 
 
 class ConvLSTMCell(nn.Module):
@@ -51,8 +52,9 @@ class ConvLSTM(nn.Module):
     def forward(self, input_tensor, hidden_state=None):
         """convlstm.py:120-176. input_tensor (b, t, c, h, w) when batch_first else (t, b, c, h, w); hidden_state = one
         [h, c] pair per layer, each (b, hidden, h, w), or None for zeros. Returns (layer_output_list, last_state_list):
-        outputs (b, t, hidden, h, w) and [h, c] of every layer, or of the last one only unless return_all_layers."""
-        _lib.lib()
+        outputs (b, t, hidden, h, w) and [h, c] of every layer, or of the last one only unless return_all_layers.
+        Inference-only (no autograd graph; the cell has neither BatchNorm nor Dropout, so training mode computes the same)."""
+        _inference_only(self, "ConvLSTM", training_differs=False)
         if not self.batch_first:
             input_tensor = input_tensor.permute(1, 0, 2, 3, 4)                       # :137-139
         dev_in = input_tensor.device

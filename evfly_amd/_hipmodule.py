@@ -89,7 +89,10 @@ class HipModule(nn.Module):
         """(dict, key) of every parameter / buffer slot of the tree, collected once: the per-forward check then costs one
         dict lookup per tensor instead of a walk over `modules()` (0.35 ms for the composite's 149 tensors, in front of
         the first launch of a 1.9 ms single-frame forward). Looking the tensor up through its slot also catches a
-        re-assigned Parameter object. Sub-modules added after the first forward are not."""
+        re-assigned Parameter object. The list is dropped by `_invalidate` (load_state_dict, _apply, register_* / add_module /
+        module or Parameter assignment on a shell), so slots that were None at the first forward or sub-modules registered later
+        on a shell enter it; a child registered on a plain nn.Module INSIDE a shell after the first forward needs
+        `refresh_weights()`."""
         sl = self.__dict__.get("_slot_cache")
         if sl is None:
             sl, seen = [], set()
@@ -123,6 +126,61 @@ class HipModule(nn.Module):
         self.__dict__["_frozen"] = True
         return self
 
+    # ---- every structural or bulk weight change that goes through a module method thaws a frozen handle and drops the cached
+    # slot list (cheap, not on the forward path): .to() / .float() / .cuda() (_apply), load_state_dict on this module or on a
+    # parent (_load_from_state_dict is what the recursion calls), registering a parameter / buffer / sub-module later on.
+    def _invalidate(self):
+        d = self.__dict__
+        if "_slot_cache" in d:
+            d["_slot_cache"] = None
+            d["_frozen"] = False
+        for m in self.__dict__.get("_modules", {}).values():        # shells nested inside a shell (the composite)
+            if isinstance(m, HipModule):
+                m._invalidate()
+
+    def _invalidate_tree(self):
+        """thaw this shell and every HipModule above / below it that shares these tensors"""
+        self._invalidate()
+        for owner in self.__dict__.get("_hip_owners", ()):
+            o = owner()
+            if o is not None:
+                o._invalidate()
+
+    def _apply(self, fn, *a, **kw):
+        self._invalidate_tree()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._invalidate_tree()
+        return super().load_state_dict(*a, **kw)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self._invalidate_tree()
+        return super()._load_from_state_dict(*a, **kw)
+
+    def register_parameter(self, name, param):
+        self._invalidate_tree()
+        return super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        self._invalidate_tree()
+        return super().register_buffer(name, tensor, persistent=persistent)
+
+    def add_module(self, name, module):
+        self._invalidate_tree()
+        if isinstance(module, HipModule):
+            import weakref
+            module.__dict__.setdefault("_hip_owners", []).append(weakref.ref(self))
+        return super().add_module(name, module)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)):
+            self._invalidate_tree()
+            if isinstance(value, HipModule):
+                import weakref
+                value.__dict__.setdefault("_hip_owners", []).append(weakref.ref(self))
+        return super().__setattr__(name, value)
+
     def set_compute_dtype(self, name):
         self.compute_dtype = {"f32": 0, "fp32": 0, "bf16": 1, "bf16x3": 2}[name]
         self.__dict__["_frozen"] = False
@@ -145,6 +203,26 @@ class HipModule(nn.Module):
             self.__dict__["_hip"] = h
             self.__dict__["_hip_built_at"] = fp
         return h
+
+
+_WARNED_NO_GRAD = set()
+
+
+def _inference_only(mod, what, training_differs):
+    """The stand-alone native forwards are INFERENCE-ONLY: weights are read detached (no autograd graph comes back), BatchNorm uses
+    its running statistics and Dropout is the identity whatever `mod.training` says. Where that changes the numbers the reference
+    would produce (a module in training mode that holds BatchNorm / an active Dropout) this raises instead of returning them
+    silently; a call that merely expects gradients is warned about once per class."""
+    _lib.lib()                                                   # (no GPU / no library: that error first)
+    if mod.training and training_differs:
+        raise NotImplementedError(f"[{what}] the native forward is inference-only (BatchNorm running statistics, Dropout off): "
+                                  f"call .eval() first; training-mode semantics (batch statistics, dropout masks, running-stat "
+                                  f"updates) are not implemented")
+    if torch.is_grad_enabled() and what not in _WARNED_NO_GRAD and any(p.requires_grad for p in mod.parameters()):
+        _WARNED_NO_GRAD.add(what)
+        import warnings
+        warnings.warn(f"[{what}] the native forward is inference-only: the outputs carry no autograd graph (gradients of these "
+                      f"parameters will be None); wrap the call in torch.no_grad() to silence this", stacklevel=3)
 
 
 def to_gpu(t, dtype=torch.float32):

@@ -65,6 +65,7 @@ SIGNATURES = {
     "evfly_model_load_tensor": (c_i, [c_p, C.c_char_p, c_p, C.POINTER(c_i64), c_i]),
     "evfly_model_finalize": (c_i, [c_p]),
     "evfly_model_destroy": (None, [c_p]),
+    "evfly_model_arena_generation": (c_i, [c_p]),
     "evfly_unet_forward": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "evfly_vit_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "evfly_vit_stage_forward": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),

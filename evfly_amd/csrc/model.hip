@@ -62,6 +62,7 @@ struct evfly_model {
     // activation arena
     char *arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
+    int arena_generation = 0;      // bumped whenever the arena is reallocated (pointers captured earlier are stale)
     bool planning = false;
     size_t plan_peak = 0;
     std::map<std::string, Tap> taps;
@@ -1075,6 +1076,7 @@ int with_arena(evfly_model *m, Fn &&body) {
         m->arena = nullptr; m->arena_cap = 0;
         EVFLY_HIP(hipMalloc(reinterpret_cast<void **>(&m->arena), m->plan_peak));
         m->arena_cap = m->plan_peak;
+        ++m->arena_generation;
     }
     m->arena_off = 0;
     return body();
@@ -1269,6 +1271,7 @@ extern "C" int evfly_model_finalize(evfly_model *m) {
 }
 
 extern "C" void evfly_model_destroy(evfly_model *m) { delete m; }
+extern "C" int evfly_model_arena_generation(evfly_model *m) { return m ? m->arena_generation : -1; }
 
 extern "C" int64_t evfly_model_tap(evfly_model *m, const char *name, float *dst_host, int64_t max_elems, int64_t *shape_out,
                                    void *stream) {

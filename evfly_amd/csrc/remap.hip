@@ -4,8 +4,9 @@
 // algorithm of imgproc/src/imgwarp.cpp for CV_32FC1 maps, a CV_32FC1 image, INTER_CUBIC and BORDER_CONSTANT(0):
 //   sx = cvRound(mapx * 32), sy = cvRound(mapy * 32)          (INTER_BITS = 5: 1/32-pixel fractions)
 //   ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31
-//   dst = sum_{r=0..3} ( S[iy-1+r][ix-1]*w[r][0] + S[..][ix]*w[r][1] + S[..][ix+1]*w[r][2] + S[..][ix+2]*w[r][3] )
-//   w[r][c] = cubic(fy/32)[r] * cubic(fx/32)[c]  in float (interpolateCubic, A = -0.75), S = 0 outside the image.
+//   interior window:  dst = sum_{r=0..3} ( S[iy-1+r][ix-1]*w[r][0] + S[..][ix]*w[r][1] + S[..][ix+1]*w[r][2] + S[..][ix+2]*w[r][3] )
+//   window over an edge: dst = 0; dst += S[y][x]*w[r][c] tap by tap in (r, c) order over the taps inside the image
+//   w[r][c] = cubic(fy/32)[r] * cubic(fx/32)[c]  in float (interpolateCubic, A = -0.75).
 // Parity is UNPINNED (no cv2 in the build container, no calibration file in the reference tree): the CPU oracle
 // (oracle/rectify.py) restates the same published algorithm independently and the two are compared bit for bit.
 #include "common.h"
@@ -52,6 +53,11 @@ __global__ __launch_bounds__(256) void k_remap_cubic(RemapArgs a) {
         const int ix = max(-32768, min(32767, sx >> 5)), iy = max(-32768, min(32767, sy >> 5));
         const float *wy = tab[sy & 31], *wx = tab[sx & 31];
         float sum = 0.f;
+        // remapBicubic's two branches differ in the ASSOCIATION of the sixteen float products (same value set, not the same
+        // bits): a window that lies wholly inside the image sums each 4-tap row left to right and adds the rows one by one
+        // (`sum = S0*w0 + S1*w1 + S2*w2 + S3*w3; sum += <row 1>; ...`); a window that hangs over an edge starts from the border
+        // value and accumulates tap by tap, skipping the taps outside (`sum = cval; sum += (S[x] - cval) * w`, cval = 0).
+        const bool interior = (unsigned)(ix - 1) < (unsigned)max(a.sw - 3, 0) && (unsigned)(iy - 1) < (unsigned)max(a.sh - 3, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int y = iy - 1 + r;
@@ -59,15 +65,17 @@ __global__ __launch_bounds__(256) void k_remap_cubic(RemapArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int x = ix - 1 + c;
+                const bool in = (unsigned)y < (unsigned)a.sh && (unsigned)x < (unsigned)a.sw;
                 float s = 0.f;
-                if ((unsigned)y < (unsigned)a.sh && (unsigned)x < (unsigned)a.sw) {
+                if (in) {
                     const int64_t p = ((int64_t)img * a.sh + y) * a.sw + x;
                     s = a.u8 ? (float)((int)a.u8[p] - 128) * 0.2f : a.f32[p];   // run.py:334-336 decode fused in
                 }
                 const float t = s * (wy[r] * wx[c]);
                 row = c == 0 ? t : row + t;
+                if (!interior && in) sum += t;
             }
-            sum += row;
+            if (interior) sum += row;
         }
         a.dst[i] = sum;
     }

@@ -17,7 +17,10 @@ class EventDepthVelocityNode:
         """use_graph: after two eager frames (they create the recurrent states and every lazily allocated buffer of the library)
         the per-frame work -- conditioning + stateful forward, ~100 kernel launches for one frame -- is captured ONCE into a HIP
         graph (torch.cuda.CUDAGraph) and replayed per frame: same kernels, same order, same bits, without the per-launch host cost.
-        The frame is copied into a static input buffer, the new recurrent states back into the static state buffers."""
+        The frame is copied into a static input buffer, the new recurrent states back into the static state buffers. The graph
+        holds raw device pointers of the model's native handle (packed weights, arena): it is keyed by that handle's identity, and
+        a rebuilt handle (load_state_dict, refresh_weights, set_compute_dtype, .to()) drops the graph -- the node re-warms with two
+        eager frames and captures again. `desvel` is written into its static buffer every frame."""
         self.model = model.to(device).float().eval()
         self.device = device
         self.evcam_height, self.evcam_width = evcam_hw                 # run.py:41
@@ -31,7 +34,7 @@ class EventDepthVelocityNode:
         self.velpred_hidden_state = None
         self.pred_vel = self.pred_depth = self.evframe = None
         self.use_graph = use_graph and aligner is None
-        self._graph = None
+        self._graph = self._g_handle = self._g_out = None
         self._eager_frames = 0
 
     def image_callback(self, data):
@@ -68,11 +71,22 @@ class EventDepthVelocityNode:
         with torch.cuda.graph(g, stream=side):
             self._g_out = body()
         self._graph = g
+        self._g_handle = self.model.hip()          # the HipHandle whose pointers the graph holds (kept alive with the graph)
+        self._g_arena = self._g_handle._L.evfly_model_arena_generation(self._g_handle.h)
 
     def _run_graph(self, frame_u8):
+        h = self.model.hip()
+        if self._graph is not None and (h is not self._g_handle or h._L.evfly_model_arena_generation(h.h) != self._g_arena):
+            # the native handle was rebuilt since the capture (new weights / dtype / device) or an eager forward with a larger
+            # batch regrew its arena: the captured pointers are stale.
+            # Drop the graph and re-warm eagerly from the current recurrent state; capture again after two frames.
+            self._graph = self._g_handle = self._g_out = None
+            self._eager_frames = 0
+            return self.run_model(frame_u8)
         if self._graph is None:
             self._capture(frame_u8)
         self._g_src.copy_(torch.from_numpy(np.ascontiguousarray(frame_u8))[None])
+        self._g_desvel.fill_(float(self.desvel))
         self._graph.replay()
         x, x_vel, x_depth, hs, vps = self._g_out
         for dst, src in zip(self._tensors(self._g_unet), self._tensors(hs)):
@@ -80,7 +94,7 @@ class EventDepthVelocityNode:
         for dst, src in zip(self._tensors(self._g_vp), self._tensors(vps)):
             dst.copy_(src)
         self.origunet_hidden_state, self.velpred_hidden_state = self._g_unet, self._g_vp
-        self.evframe = x
+        self.evframe = x.clone()                   # (the static buffer is overwritten by the next replay)
         self.pred_vel = x_vel.cpu().numpy().squeeze()
         self.pred_depth = x_depth.cpu().numpy().squeeze() if x_depth is not None else None
         return self.pred_vel, self.pred_depth

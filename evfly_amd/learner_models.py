@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import vitfly_models
-from ._hipmodule import HipModule, to_gpu
+from ._hipmodule import HipModule, _inference_only, to_gpu
 from .ConvLSTM_pytorch.convlstm import ConvLSTM
 
 _SKIP = {"crop": 0, "interp": 1, "none": 2}
@@ -112,7 +112,9 @@ class DynamicConvNet(nn.Module):
     def forward(self, x):
         """learner_models.py:97-98 `self.layers(x)`: x (N, C, H, W) -> (N, C', H', W'), eval mode (BatchNorm2d running
         statistics folded into the bias-free conv: w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps),
-        what evfly_model_finalize does for the head inside OrigUNet). Native: evfly_op_conv2d_nhwc + evfly_op_pool2d_nhwc."""
+        what evfly_model_finalize does for the head inside OrigUNet). Native: evfly_op_conv2d_nhwc + evfly_op_pool2d_nhwc.
+        Inference-only: raises in training mode (the reference would use batch statistics there)."""
+        _inference_only(self, "DynamicConvNet", training_differs=True)
         L = _lib.lib()
         sp = self.spec
         dev = x.device
@@ -159,7 +161,9 @@ class DynamicFCNet(nn.Module):
 
     def forward(self, x):
         """learner_models.py:144-145 `self.layers(x)`: x (N, F) -> (N, layer_sizes[-1]); Dropout is the identity in eval.
-        Native: one evfly_op_conv2d_nhwc (1x1, H = W = 1) per Linear with the activation in its epilogue."""
+        Native: one evfly_op_conv2d_nhwc (1x1, H = W = 1) per Linear with the activation in its epilogue.
+        Inference-only: raises in training mode when a Dropout with p > 0 is present."""
+        _inference_only(self, "DynamicFCNet", training_differs=any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.layers))
         dev = x.device
         cur = to_gpu(x).reshape(x.shape[0], 1, 1, -1).contiguous()
         for i in range(self.spec['num_layers']):

@@ -50,12 +50,21 @@ def make_batch(B, T, H=260, W=346, events_per_window=60_000, polarity="pm1",
                clustered=False, seed_base=1234, first_stream=0):
     """B concatenated streams in SoA form + CSR-style offsets + (B, T+1) window edges."""
     xs, ys, ts, ps, offs, edges = [], [], [], [], [0], []
-    for b in range(B):
-        ev, e = make_stream(first_stream + b, T, H, W, events_per_window, polarity,
-                            clustered, seed_base)
+    gen = lambda b: make_stream(first_stream + b, T, H, W, events_per_window, polarity, clustered, seed_base)
+    if B * T * events_per_window >= 1 << 25:
+        # large batches (C3: 512 M events): one stream per worker thread -- every stream has its own RandomState and numpy
+        # releases the GIL in randint / sort, so the result is the serial one, ~10x sooner on a many-core host
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as pool:
+            streams = list(pool.map(gen, range(B)))
+    else:
+        streams = [gen(b) for b in range(B)]
+    for ev, e in streams:
         xs.append(ev["x"]); ys.append(ev["y"]); ts.append(ev["t"]); ps.append(ev["p"])
         offs.append(offs[-1] + len(ev["x"]))
         edges.append(e)
+    del streams
     return dict(x=np.concatenate(xs), y=np.concatenate(ys), t=np.concatenate(ts),
                 p=np.concatenate(ps), offsets=np.asarray(offs, dtype=np.int64),
                 edges=np.stack(edges).astype(np.int64))

@@ -33,6 +33,11 @@ def upload_events(batch, prepare=True):
     return prepare_events(ev) if prepare else ev
 
 
+def _prep_key(ev):
+    """identity of the arrays evfly_voxel_prepare read: (pointer, version counter, size) of t, offsets, edges"""
+    return tuple((ev[k].data_ptr(), ev[k]._version, ev[k].numel()) for k in ("t", "offsets", "edges"))
+
+
 def prepare_events(ev):
     """Attach evfly_voxel_prepare's tables to an uploaded batch: ev["unsorted"] (B,) int32, ev["starts"] (B, T+1) int64 and
     ev["skip_kernels"] (read back once: 2 when every stream is sorted and no window holds more than 65 535 events, 1 when no
@@ -46,6 +51,7 @@ def prepare_events(ev):
                                      _lib.ptr(uns), _lib.ptr(starts), _lib.cur_stream()))
     fast = (uns == 0)[:, None] & ((starts[:, 1:] - starts[:, :-1]) <= 65535)      # frames of the 16-bit kernel (voxel.hip kFastMax)
     ev["unsorted"], ev["starts"] = uns, starts
+    ev["_prep_key"] = _prep_key(ev)
     ev["skip_kernels"] = 2 if bool(fast.all()) else (1 if not bool(fast.any()) else 0)
     return ev
 
@@ -73,6 +79,11 @@ def voxelize_windows(ev, H, W, polarity="pm1", pos_thresh=0.2, neg_thresh=0.2, o
     T = ev["edges"].shape[-1] - 1
     dev = ev["x"].device
     bufs = {"f32": None, "f64": None, "counts": None}
+    if frames is not None and "f32" in outs:
+        # the kernel writes B*T*h*w contiguous floats: anything else is a silent wrong-stride fill or an out-of-bounds write
+        if not (frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and tuple(frames.shape) == (B, T, H, W)):
+            raise ValueError(f"voxelize_windows: `frames` must be a contiguous float32 CUDA tensor of shape {(B, T, H, W)} "
+                             f"(the region of interest when roi is given), got {frames.dtype} {tuple(frames.shape)} on {frames.device}")
     for o in outs:
         if o == "f32":
             bufs[o] = frames if frames is not None else torch.empty(B, T, H, W, device=dev, dtype=torch.float32)
@@ -83,6 +94,11 @@ def voxelize_windows(ev, H, W, polarity="pm1", pos_thresh=0.2, neg_thresh=0.2, o
         else:
             raise ValueError(o)
     prep = "starts" in ev
+    if prep:
+        # the pass-1 tables belong to ONE (t, offsets, edges) triple: re-prepare when any of them was replaced or written to
+        key = _prep_key(ev)
+        if ev.get("_prep_key") != key or tuple(ev["starts"].shape) != (B, T + 1) or ev["unsorted"].numel() != B:
+            prepare_events(ev)
     _lib.check(L.evfly_voxelize_windows_prepared(_lib.ptr(ev["x"]), _lib.ptr(ev["y"]), _lib.ptr(ev["t"]), _lib.ptr(ev["p"]),
                                                  ev["x"].numel(), _lib.ptr(ev["offsets"]), B, _lib.ptr(ev["edges"]), T, Hf, Wf,
                                                  top, left, rh, rw, POL[polarity], float(pos_thresh), float(neg_thresh),

@@ -255,6 +255,10 @@ int evfly_model_load_tensor(evfly_model *m, const char *key, const float *data_h
                             const int64_t *shape, int ndim);
 int evfly_model_finalize(evfly_model *m);
 void evfly_model_destroy(evfly_model *m);
+/* Number of times the handle's activation arena was (re)allocated. A caller that captured launches of this handle into a
+ * hipGraph (evfly_amd/deploy.py, the run.py:245-268 per-frame work) compares it before a replay: a forward with a larger batch
+ * regrows the arena and leaves the captured pointers stale. No reference counterpart (the reference has no native state). */
+int evfly_model_arena_generation(evfly_model *m);
 
 /* Replaces OrigUNet.forward learner/learner_models.py:521-616 (velpred = 0, decoder always run).
  * frames: (n_streams * T, input_h, input_w) conditioned event frames laid out [stream][t]; the T

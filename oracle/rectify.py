@@ -63,13 +63,24 @@ def remap_cubic(img, mapx, mapy):
     wx = tab[sx & 31]; wy = tab[sy & 31]                                         # (h, w, 4)
     pad = np.zeros((H + 8, W + 8), np.float32)                                   # zero border, 4 px is enough after clipping
     pad[4:H + 4, 4:W + 4] = img
-    out = np.zeros(mapx.shape, np.float32)
+    # remapBicubic has two branches with different float association (same products):
+    #  * the 4x4 window lies inside the image ((unsigned)(ix-1) < W-3 and (unsigned)(iy-1) < H-3): every row is summed left to
+    #    right, the rows are added one after the other      sum = S0*w0 + S1*w1 + S2*w2 + S3*w3;  sum += <row 1>; ...
+    #  * the window hangs over an edge (BORDER_CONSTANT): start from the border value and accumulate tap by tap over the taps
+    #    that lie inside      sum = cval;  sum += (S[y][x] - cval) * w[r][c]      (cval = 0: (S - 0) * w = S * w exactly)
+    interior = ((ix - 1 >= 0) & (ix - 1 < max(W - 3, 0)) & (iy - 1 >= 0) & (iy - 1 < max(H - 3, 0)))
+    out_in = np.zeros(mapx.shape, np.float32)
+    out_bd = np.zeros(mapx.shape, np.float32)
     for r in range(4):
-        yy = np.clip(iy - 1 + r, -4, H + 3) + 4
+        y = iy - 1 + r
+        yy = np.clip(y, -4, H + 3) + 4
         row = None
         for c in range(4):
-            xx = np.clip(ix - 1 + c, -4, W + 3) + 4
+            x = ix - 1 + c
+            xx = np.clip(x, -4, W + 3) + 4
             t = pad[yy, xx] * (wy[..., r] * wx[..., c])
             row = t if row is None else row + t
-        out = out + row
-    return out
+            valid = (y >= 0) & (y < H) & (x >= 0) & (x < W)
+            out_bd = np.where(valid, out_bd + t, out_bd)
+        out_in = row if r == 0 else out_in + row
+    return np.where(interior, out_in, out_bd).astype(np.float32)

@@ -49,8 +49,19 @@ def test_bench_source_keeps_the_contract_keys():
     for k in ('"metric"', '"value"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"',
               '"data"', '"config"', '"roofline"', '"cpu_baseline"', "--gpus", "--steps", "--warmup", "dist.barrier()",
               '"frac_useful"', '"frac_algorithmic"', '"step_mfma_util"', '"stage_rates"', '"threads_1"', '"threads_nproc"', "--config",
-              "pin_memory()"):
+              "pin_memory()", '"other_configs"', '"voxelize_bytes_moved"', '"voxelize_with_pass1_ms"', '"step_ms"',
+              '"ms_per_step_by_rank"', '"all_gather_us"'):
         assert k in src, k
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` outside a launcher counts the node's GPUs in the PARENT (no runtime initialisation) and refuses to spawn N
+    ranks when fewer are visible -- never a silent smaller run."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode != 0 and "--gpus 64 but this node exposes" in r.stderr
 
 
 def test_bench_configs_are_the_baseline_configs():

@@ -84,6 +84,48 @@ def test_gather_twice_even_then_ragged_same_group():
         assert outs[r][4] == "ValueError"
 
 
+def _worker_c4(rank, world, port, q):
+    """BASELINE config C4's shape on 4 ranks: 2048 streams x 5 windows sharded over 8 GPUs -- here ranks 0..3 of a 4-rank group
+    each hold the rows two of those GPUs would (512 streams = 2560 velocity rows per rank), counts from `shard_row_counts`
+    (no exchange), ONE all_gather_into_tensor per call, three calls in a row like the benchmark's steps."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_streams, T = 2048, 5
+    counts = shard_row_counts(n_streams, world, T)
+    s0, s1 = shard_streams(n_streams, rank, world)
+    ok = counts == [512 * T] * world and (s0, s1) == (512 * rank, 512 * (rank + 1))
+    base = torch.arange(s0 * T, s1 * T, dtype=torch.float32)[:, None]
+    for step in range(3):
+        vel = torch.cat([base, base * 0.5 + step, -base], 1)
+        out = gather_velocities(vel, dist, counts=counts)
+        want = torch.arange(n_streams * T, dtype=torch.float32)[:, None]
+        ok = ok and out.shape == (n_streams * T, 3) and torch.equal(out, torch.cat([want, want * 0.5 + step, -want], 1))
+    # max-over-ranks timing reduction of the benchmark (gloo has MAX)
+    tm = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    every = torch.empty(world, dtype=torch.float64)
+    dist.all_gather_into_tensor(every, torch.tensor([float(rank + 1)], dtype=torch.float64))
+    ok = ok and tm.item() == world and every.tolist() == [float(r + 1) for r in range(world)]
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_shape_world_size_4():
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_c4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs == {r: True for r in range(world)}
+
+
 def test_shard_row_counts():
     assert shard_row_counts(65, 2, 5) == [165, 160] and shard_row_counts(2048, 8, 5) == [1280] * 8
 

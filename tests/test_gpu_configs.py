@@ -11,7 +11,7 @@ from oracle import conditioning as ocond
 from oracle import models as om
 from oracle import voxel as ovox
 
-from _util import cond_frames, rel_err
+from _util import ELEM_TOL, cond_frames, rel_err, rel_err_elem
 
 pytestmark = pytest.mark.gpu
 
@@ -106,6 +106,7 @@ def test_c4_shard_256_streams_vit_base(gpu_device, base_trunk):
         rows = slice(s * T, (s + 1) * T)
         v_ref, d_ref = om.composite_streams(sd, xc[rows], desvel[rows], 1, T)
         assert rel_err(v[rows].cpu(), v_ref) < 1e-4 and rel_err(d[rows].cpu(), d_ref) < 1e-4, s
+        assert rel_err_elem(v[rows].cpu(), v_ref) < ELEM_TOL and rel_err_elem(d[rows].cpu(), d_ref) < ELEM_TOL, s
     v2, (d2, _, _) = net.forward_streams([x, desvel.to(gpu_device), [None, None], None], S, T)
     assert torch.equal(v, v2) and torch.equal(d, d2)
 

@@ -51,6 +51,20 @@ def test_remap_edge_maps(gpu_device):
         assert np.array_equal(got[i], orect.remap_cubic(img[i], mx, my))
 
 
+def test_remap_border_windows_per_tap_association(gpu_device):
+    """The 6x6 known answer of tests/test_rectify.py on the device: windows over an edge accumulate tap by tap (remapBicubic's
+    border branch), interior windows row by row; checked against the scalar third derivation, not only the oracle."""
+    from evfly_amd.calibration_tools.rectify_bag import remap_img
+    from test_rectify import _scalar_remap
+    rs = np.random.RandomState(3)
+    img = (rs.rand(6, 6).astype(np.float32) * 10 - 5).astype(np.float32)
+    gx, gy = np.meshgrid(np.arange(-1, 7, dtype=np.float32), np.arange(-1, 7, dtype=np.float32))
+    mx, my = (gx + np.float32(0.40625)).astype(np.float32), (gy + np.float32(0.28125)).astype(np.float32)
+    got = remap_img(torch.from_numpy(img[None]), (torch.from_numpy(mx).cuda(), torch.from_numpy(my).cuda())).cpu().numpy()[0]
+    assert np.array_equal(got, _scalar_remap(img, mx, my, True))
+    assert not np.array_equal(got, _scalar_remap(img, mx, my, False))
+
+
 def test_deploy_node_with_alignment(gpu_device, tmp_path):
     import evfly_amd.learner_models as lm
     from evfly_amd.calibration_tools.rectify_bag import Aligner

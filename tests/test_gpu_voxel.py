@@ -71,6 +71,57 @@ def test_full_c2_batch_size_independent_properties(gpu_device):
     assert np.array_equal(counts[:6], c6)
 
 
+def test_full_c3_batch_size_independent_properties(gpu_device):
+    """BASELINE.json C3 at FULL size: 256 streams x 10 windows x 200 000 events at 480x640 = 512 M events (the timestamp array
+    alone is 4.1 GB: element and byte offsets past 2^31 / 2^32), accumulated over the centre-crop region of interest of
+    run.py:345-350 by the 32-bit-counter kernel (every window holds > 65 535 events). Size-independent properties: per stream the
+    counts total the stream's events inside the region (computed from x, y on the host); per-window totals from searchsorted on
+    three streams incl. the LAST; the polarity split; frames = 0.2 * (P - N); and streams 0, 1 and 255 are bit-identical to the
+    same streams voxelized alone, of which the first two are checked against the oracle."""
+    from evfly_amd import voxelizer
+    B, T, Hs, Ws, EPW = 256, 10, 480, 640, 200_000
+    batch = syn.make_batch(B, T, Hs, Ws, events_per_window=EPW)
+    n = len(batch["x"])
+    assert n == B * T * EPW and batch["t"].nbytes > 1 << 32
+    top, left, rh, rw = roi = voxelizer.centre_crop_roi(Hs, Ws, (H, W))
+    ev = voxelizer.upload_events(batch)
+    assert ev["skip_kernels"] == 1                                        # no window fits the 16-bit kernel
+    f32, counts = voxelizer.voxelize_windows(ev, Hs, Ws, out=("f32", "counts"), roi=roi)
+    torch.cuda.synchronize()
+    assert counts.shape == (B, T, 2, H, W) and f32.shape == (B, T, H, W)
+    per_win = counts.sum(dim=(3, 4)).cpu().numpy().astype(np.int64)      # (B, T, 2), reduced on the device
+    # frames from the counts, on the device in float64 like the kernel's arithmetic (to_events.py:409)
+    want32 = (0.2 * counts[:, :, 0].double() - 0.2 * counts[:, :, 1].double()).float()
+    assert torch.equal(f32, want32)
+    del want32, f32
+    off = batch["offsets"]
+    tot_pos = tot_neg = 0
+    for b in range(B):
+        sl = slice(int(off[b]), int(off[b + 1]))
+        cx = np.minimum(batch["x"][sl].astype(np.int32), Ws - 1) - left    # np.histogram2d: x == W counts in the last column
+        cy = np.minimum(batch["y"][sl].astype(np.int32), Hs - 1) - top
+        inside = (cx >= 0) & (cx < rw) & (cy >= 0) & (cy < rh)
+        pos = inside & (batch["p"][sl] > 0)
+        assert per_win[b].sum() == int(inside.sum()), b                   # every in-region event of the stream in exactly one window
+        tot_pos += int(pos.sum()); tot_neg += int(inside.sum()) - int(pos.sum())
+        if b in (0, 131, B - 1):                                          # per-window, per-polarity totals from the timestamps alone
+            idx = np.searchsorted(batch["t"][sl], batch["edges"][b], side="left")
+            for w in range(T):
+                assert per_win[b, w, 0] == int(pos[idx[w]:idx[w + 1]].sum()), (b, w)
+                assert per_win[b, w, 1] == int((inside & ~pos)[idx[w]:idx[w + 1]].sum()), (b, w)
+    assert per_win[:, :, 0].sum() == tot_pos and per_win[:, :, 1].sum() == tot_neg
+    # the same streams alone (small batches: 32-bit-safe indices everywhere) -- and those against the oracle
+    for lo, hi in ((0, 2), (B - 1, B)):
+        sl = slice(int(off[lo]), int(off[hi]))
+        sub = dict(x=batch["x"][sl], y=batch["y"][sl], t=batch["t"][sl], p=batch["p"][sl],
+                   offsets=(off[lo:hi + 1] - off[lo]).astype(np.int64), edges=batch["edges"][lo:hi])
+        c_sub = voxelizer.voxelize_windows(voxelizer.upload_events(sub), Hs, Ws, out="counts", roi=roi)
+        assert torch.equal(counts[lo:hi], c_sub), (lo, hi)
+        if lo == 0:
+            want = ovox.batch_window_counts(sub, Hs, Ws)[:, :, :, top:top + rh, left:left + rw]
+            assert np.array_equal(c_sub.cpu().numpy(), want)
+
+
 def test_sensor_size_thresholds_and_01(gpu_device):
     """C3-shaped: 480x640, T=10, {0,1} polarity convention, unequal thresholds."""
     from evfly_amd import voxelizer

@@ -25,6 +25,60 @@ def test_cubic_table_and_remap_known_answers():
     assert np.array_equal(orect.remap_cubic(img, mx + 0.51, my), out)
 
 
+def _scalar_remap(img, mx, my, per_tap_on_border=True):
+    """Third derivation, scalar np.float32 loops: OpenCV's remapBicubic for a float image, BORDER_CONSTANT 0."""
+    f = np.float32
+    H, W = img.shape
+    tab = orect.cubic_table()
+    out = np.zeros(mx.shape, np.float32)
+    for i in range(mx.shape[0]):
+        for j in range(mx.shape[1]):
+            sx, sy = int(np.rint(f(mx[i, j]) * f(32))), int(np.rint(f(my[i, j]) * f(32)))
+            ix, iy, wx, wy = sx >> 5, sy >> 5, tab[sx & 31], tab[sy & 31]
+            inside = 0 <= ix - 1 < max(W - 3, 0) and 0 <= iy - 1 < max(H - 3, 0)
+            if inside or not per_tap_on_border:
+                acc = None
+                for r in range(4):
+                    row = None
+                    for c in range(4):
+                        y, x = iy - 1 + r, ix - 1 + c
+                        s = img[y, x] if (0 <= y < H and 0 <= x < W) else f(0)
+                        t = f(s * f(wy[r] * wx[c]))
+                        row = t if row is None else f(row + t)
+                    acc = row if acc is None else f(acc + row)
+            else:
+                acc = f(0)
+                for r in range(4):
+                    for c in range(4):
+                        y, x = iy - 1 + r, ix - 1 + c
+                        if 0 <= y < H and 0 <= x < W:
+                            acc = f(acc + f(img[y, x] * f(wy[r] * wx[c])))
+            out[i, j] = acc
+    return out
+
+
+def test_border_windows_accumulate_tap_by_tap():
+    """Known answer for the branch of remapBicubic that handles a 4x4 window hanging over the image edge: `sum = cval;
+    sum += (S - cval) * w` per tap, against the interior branch's row sums. On a 6x6 image with a fractional map every window
+    except the centre ones crosses an edge; the two associations give different float32 bits there, and the oracle must follow
+    the per-tap one on those pixels and the row-wise one inside."""
+    rs = np.random.RandomState(3)
+    img = (rs.rand(6, 6).astype(np.float32) * 10 - 5).astype(np.float32)
+    gx, gy = np.meshgrid(np.arange(-1, 7, dtype=np.float32), np.arange(-1, 7, dtype=np.float32))
+    mx, my = (gx + np.float32(0.40625)).astype(np.float32), (gy + np.float32(0.28125)).astype(np.float32)
+    per_tap, row_wise = _scalar_remap(img, mx, my, True), _scalar_remap(img, mx, my, False)
+    got = orect.remap_cubic(img, mx, my)
+    assert np.array_equal(got, per_tap)
+    ix, iy = np.floor(mx + 0.0).astype(int), np.floor(my + 0.0).astype(int)
+    interior = (ix - 1 >= 0) & (ix - 1 < 3) & (iy - 1 >= 0) & (iy - 1 < 3)
+    assert interior.sum() == 9 and np.array_equal(per_tap[interior], row_wise[interior])
+    assert (per_tap[~interior] != row_wise[~interior]).any()          # the test can tell the two associations apart
+    assert np.abs(per_tap - row_wise).max() < 1e-5                    # ... and they differ by rounding only
+    assert got[0, 0] != 0                                             # a corner window keeps its inside taps
+    far = orect.remap_cubic(img, mx + 20, my)                         # windows wholly outside: the border value
+    assert not far.any()
+
+
 def test_maps_match_oracle(tmp_path):
     import yaml
     from evfly_amd.calibration_tools import rectify_bag as rb
