@@ -73,7 +73,7 @@ def test_full_c2_batch_size_independent_properties(gpu_device):
 
 def test_full_c3_batch_size_independent_properties(gpu_device):
     """BASELINE.json C3 at FULL size: 256 streams x 10 windows x 200 000 events at 480x640 = 512 M events (the timestamp array
-    alone is 4.1 GB: element and byte offsets past 2^31 / 2^32), accumulated over the centre-crop region of interest of
+    alone is 4.1 GB: byte offsets past 2^31, the whole batch past 2^32), accumulated over the centre-crop region of interest of
     run.py:345-350 by the 32-bit-counter kernel (every window holds > 65 535 events). Size-independent properties: per stream the
     counts total the stream's events inside the region (computed from x, y on the host); per-window totals from searchsorted on
     three streams incl. the LAST; the polarity split; frames = 0.2 * (P - N); and streams 0, 1 and 255 are bit-identical to the
@@ -82,7 +82,7 @@ def test_full_c3_batch_size_independent_properties(gpu_device):
     B, T, Hs, Ws, EPW = 256, 10, 480, 640, 200_000
     batch = syn.make_batch(B, T, Hs, Ws, events_per_window=EPW)
     n = len(batch["x"])
-    assert n == B * T * EPW and batch["t"].nbytes > 1 << 32
+    assert n == B * T * EPW and batch["t"].nbytes > 1 << 31 and 13 * n > 1 << 32       # t: 4.1 GB; the SoA batch: 6.7 GB
     top, left, rh, rw = roi = voxelizer.centre_crop_roi(Hs, Ws, (H, W))
     ev = voxelizer.upload_events(batch)
     assert ev["skip_kernels"] == 1                                        # no window fits the 16-bit kernel
