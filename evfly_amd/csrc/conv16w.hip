@@ -1,0 +1,298 @@
+// Implicit-GEMM 3x3 convolution of the bf16 pipeline for the DEEP U-Net layers (C_in a multiple of 64, C_out a multiple of
+// 128; learner_models.py:373-390, 553-583), gfx950. igemm16.hip runs these layers on 128 x 128 tiles with four waves, a 512-cycle
+// K-step per wave and `__syncthreads()` (= vmcnt(0)) behind it: every K-step pays the tail of its own LDS-DMA, the matrix pipe
+// sits at 26 % (profiles/r3_C5_pmc_mfma.json). This kernel is the wide-tile form of the same contraction:
+//
+//   * block tile 256 pixels x BC output channels (BC = 256 or 128), 512 threads = 8 waves, two per SIMD; a K-tile is 64 input
+//     channels of ONE tap (K order: 64-channel chunk major, tap minor), i.e. 2 x 256 x BC x 64 flops = 2048 (1024) matrix-pipe
+//     cycles per SIMD between two barriers -- long enough that the NEXT tile's LDS-DMA, issued in the first half of the tile,
+//     has landed when the tile ends: the closing `s_waitcnt vmcnt(0)` finds an empty queue;
+//   * the DMA is `buffer_load_dwordx4 ... lds` from inline asm (hipcc orders a DMA it knows of against every later ds_read with
+//     vmcnt(0)); the tap / chunk advance is the instruction's SCALAR offset, the per-lane part (pixel row, swizzled 16-B chunk)
+//     is computed once per block; one raw `s_barrier` per K-tile, two LDS stages;
+//   * MFMA roles swapped like conv16.hip (A = weights, B = pixels): D[channel][pixel] leaves a lane with one pixel's channel
+//     quads, `v_permlane32_swap` makes them 8 adjacent channels -- bias, ReLU, one RNE rounding and 16-B NHWC stores straight
+//     from the accumulators, no LDS transpose, no epilogue barrier;
+//   * a wave's tile is 64 channels x 128 (64) pixels; per 16-deep sub-step it reads 2 weight + 4 (2) pixel fragments for 8 (4)
+//     MFMAs on 8 (4) different accumulators, the fragments of sub-step s + 1 requested under the MFMAs of s: 24 (16) ds_read_b128
+//     for 32 (16) MFMAs per K-tile.
+//
+// Weights are the bf16 GEMM weights the model already holds ([C_out][K], K = (c / 32, tap, c % 32), igemm.h conv_k_index): the
+// two 32-channel halves of a 64-channel K-tile lie 9 * 64 B apart, a constant of the lane (its chunk is in one half).
+// LDS tile rows are 128 B (64 k-values), 16-B chunks XOR-swizzled with (row >> 1) & 7 on the DMA source and on the fragment
+// read (igemm16.hip's layout: conflict-free ds_read_b128 groups). MFMA sub-step s consumes chunks 2s (lanes 0-31) and 2s + 1
+// (lanes 32-63) of both operands -- a K permutation that a dot product does not see.
+#include "igemm.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+
+#include "bf16.h"
+
+// Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 pixel DMA for tap 0 of a chunk only
+// (the traffic of a direct convolution that stages each input pixel once), 2 no pixel DMA, 4 no weight DMA, 8 no LDS fragment
+// reads behind the first K-tile. The shipped library is built with 0.
+#ifndef EVFLY_C16W_ABL
+#define EVFLY_C16W_ABL 0
+#endif
+
+namespace evfly {
+namespace {
+
+constexpr int kAblW = EVFLY_C16W_ABL;
+#ifndef EVFLY_C16W_ISSUE
+#define EVFLY_C16W_ISSUE 0
+#endif
+constexpr int kIssue = EVFLY_C16W_ISSUE;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int BP = 256;            // pixels per block tile
+constexpr int NW = 8;              // waves per block
+
+// one 1-KiB LDS-DMA piece: lane l's 16 B land at lds_addr + 16 l (M0 = LDS base; nothing else in this file uses M0)
+__device__ __forceinline__ void dma_piece(unsigned voff, i32x4 srd, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+}
+
+template <int BC, int WP, int WC>
+__global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt, int cpx) {
+    static_assert(WP * WC == NW, "8 waves");
+    constexpr int TP = BP / WP / 32, TC = BC / WC / 32;       // 32-wide pixel / channel MFMA tiles per wave
+    constexpr int XPW = BP / 64, WPW = BC / 64;               // 1-KiB DMA pieces per wave and K-tile (8 rows each)
+    constexpr int NREQ = XPW + WPW, NMFMA = 4 * TP * TC;
+    constexpr int STAGE = (BP + BC) * 128;                    // bytes: [pixels: BP rows x 128 B][weights: BC rows x 128 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
+
+    const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
+    const int mt = xcd * cpx + slot / n_nt, nt = slot % n_nt;
+    if (mt >= n_mt) return;
+    const int m0 = mt * BP, n0 = nt * BC;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wv / WC, wc = wv % WC;
+    const int lr = lane >> 3, ls = lane & 7;
+    const int Mi = (int)d.M;
+
+    // ---- buffer descriptors: the input tensor, the weight matrix
+    i32x4 srdx, srdw;
+    {
+        const uint64_t xb = (uint64_t)(uintptr_t)d.x, wb = (uint64_t)(uintptr_t)d.w;
+        const unsigned xbytes = (unsigned)((int64_t)d.NI * d.H * d.W * d.ldx * 2), wbytes = (unsigned)((int64_t)d.Nc * d.ldw * 2);
+        srdx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        srdx[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffff));
+        srdx[2] = __builtin_amdgcn_readfirstlane((int)xbytes);
+        srdx[3] = 0x00020000;
+        srdw[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wb);
+        srdw[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(wb >> 32) & 0xffff));
+        srdw[2] = __builtin_amdgcn_readfirstlane((int)wbytes);
+        srdw[3] = 0x00020000;
+    }
+    // ---- per-lane byte offsets of this wave's DMA pieces (fixed over the K loop). Piece q covers tile rows 8q .. 8q + 7; lane l
+    // fills slot l & 7 of row 8q + (l >> 3), i.e. logical chunk (l & 7) ^ ((row >> 1) & 7). Rows past M re-read the last pixel:
+    // their columns of D are computed and never stored.
+    unsigned xoff[XPW], woff[WPW];
+    {
+        const int ohw = d.OH * d.OW;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const int r = (wv * XPW + i) * 8 + lr;
+            const int c = ls ^ ((r >> 1) & 7);
+            const int m = min(m0 + r, Mi - 1);
+            const int img = m / ohw, rem = m - img * ohw, oy = rem / d.OW, ox = rem - oy * d.OW;
+            xoff[i] = (unsigned)((((int64_t)img * d.H + oy) * d.W + ox) * d.ldx * 2) + (unsigned)c * 16u;
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int r = (wv * WPW + i) * 8 + lr;
+            const int c = ls ^ ((r >> 1) & 7);
+            woff[i] = (unsigned)(n0 + r) * (unsigned)d.ldw * 2u + (unsigned)(c >> 2) * (9u * 64u) + (unsigned)(c & 3) * 16u;
+        }
+    }
+    // ---- K walk: tile kt = (64-channel chunk j, tap t); scalar offsets of the tile the next DMA fetches
+    const int nk = (d.C >> 6) * 9;
+    int kj = 0, kty = 0, ktx = 0;
+    auto soff_x = [&]() { return (unsigned)(((kty * d.W + ktx) * (int)d.ldx + 64 * kj) * 2); };
+    auto soff_w = [&]() { return (unsigned)((2 * kj * 9 + kty * 3 + ktx) * 64); };
+    auto advance = [&]() {
+        if (++ktx == 3) { ktx = 0; if (++kty == 3) { kty = 0; ++kj; } }
+    };
+    auto issue = [&](int q, unsigned sx, unsigned sw, int stage, i32x4 sdx, i32x4 sdw) {       // request q of the next tile
+        const unsigned base = lds0 + (unsigned)stage * STAGE;
+        if ((kAblW & 2) && q < XPW) return;
+        if ((kAblW & 4) && q >= XPW) return;
+        if ((kAblW & 1) && q < XPW && !(kty == 0 && ktx == 0)) return;
+        if (q < XPW) dma_piece(xoff[q], sdx, sx, __builtin_amdgcn_readfirstlane(base + (unsigned)(wv * XPW + q) * 1024u));
+        else dma_piece(woff[q - XPW], sdw, sw, __builtin_amdgcn_readfirstlane(base + BP * 128u + (unsigned)(wv * WPW + (q - XPW)) * 1024u));
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    int swz[4];                                                 // byte offset of sub-step s's chunk inside this lane's tile row
+#pragma unroll
+    for (int s = 0; s < 4; ++s) swz[s] = frow * 128 + (((2 * s + fh) ^ ((frow >> 1) & 7)) << 4);
+
+    {   // tile 0 -> stage 0
+        const unsigned sx = soff_x(), sw = soff_w();
+#pragma unroll
+        for (int q = 0; q < NREQ; ++q) issue(q, sx, sw, 0, srdx, srdw);
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // behind the last tile the requests go through empty descriptors (zeros into the idle stage): no branch in the MFMA stream
+        const bool more = kt + 1 < nk;
+        i32x4 sdx = srdx, sdw = srdw;
+        sdx[2] = more ? srdx[2] : 0;
+        sdw[2] = more ? srdw[2] : 0;
+        const unsigned sx = soff_x(), sw = soff_w();
+        const unsigned char *xs = smem + cur * STAGE + (wp * TP * 32) * 128;
+        const unsigned char *ws = smem + cur * STAGE + BP * 128 + (wc * TC * 32) * 128;
+        // sub-step s (chunks 2s / 2s + 1 of every row): TC weight + TP pixel fragments, those of s + 1 requested under the MFMAs of s
+        bf16x8 wq[2][TC], xq[2][TP];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) wq[0][i] = *reinterpret_cast<const bf16x8 *>(ws + i * 32 * 128 + swz[0]);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) xq[0][j] = *reinterpret_cast<const bf16x8 *>(xs + j * 32 * 128 + swz[0]);
+        int issued = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) wq[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(ws + i * 32 * 128 + swz[s + 1]);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) xq[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(xs + j * 32 * 128 + swz[s + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // (left alone, hipcc sinks the requests of the last sub-steps to their first use)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s & 1][i], xq[s & 1][j], acc[i][j], 0, 0, 0);
+                    const int idx = (s * TP + j) * TC + i;
+                    if constexpr (kIssue == 0) {
+                        // the next tile's requests, one behind every second MFMA of the first half of the tile
+                        const int due = std::min(NREQ, (idx + 2) / 2 * ((2 * NREQ + NMFMA - 1) / NMFMA));
+                        if (issued < due) {
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int q = 0; q < NREQ; ++q)
+                                if (q >= issued && q < due) issue(q, sx, sw, cur ^ 1, sdx, sdw);
+                            __builtin_amdgcn_sched_barrier(0);
+                            issued = due;
+                        }
+                    } else {
+                        // all of a wave's requests in ONE burst, wave w behind its MFMA w * STEP: the eight waves run in lock step
+                        // behind the tile barrier, and eight simultaneous vector-memory issues queue up in front of the CU's one
+                        // address path while both waves of every SIMD wait
+                        constexpr int STEP = NMFMA / 16;
+                        if (idx < 8 * STEP && idx % STEP == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (wv == idx / STEP) {
+#pragma unroll
+                                for (int q = 0; q < NREQ; ++q) issue(q, sx, sw, cur ^ 1, sdx, sdw);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+        }
+        advance();
+        // the next tile has landed (this wave's pieces), every wave is done reading this one
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue: bias, activation, one RNE rounding, 16-B stores straight from the accumulators.
+    // C/D layout of the 32x32 MFMA: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
+    const bool relu = d.act == ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int nb = n0 + (wc * TC + i) * 32;
+        float4 b4[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) b4[rg] = d.bias ? *reinterpret_cast<const float4 *>(d.bias + nb + 8 * rg + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int m = m0 + (wp * TP + j) * 32 + frow;
+            const bool ok = m < Mi;
+            unsigned pk[8];
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float b0 = (e & 2) ? b4[e >> 2].z : b4[e >> 2].x, b1 = (e & 2) ? b4[e >> 2].w : b4[e >> 2].y;
+                float v0 = acc[i][j][e] + b0, v1 = acc[i][j][e + 1] + b1;
+                v0 = (relu && v0 < 0.f) ? 0.f : v0; v1 = (relu && v1 < 0.f) ? 0.f : v1;
+                pk[e >> 1] = pack_bf2(v0, v1);
+            }
+            // lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: after the swaps lane l owns
+            // channels 0-7 and 16-23, lane l + 32 channels 8-15 and 24-31 (16 B each)
+            bf16_t *dst = y16 + (int64_t)(ok ? m : 0) * d.ldy + nb + fh * 8;
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                unsigned o[4];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const auto sw2 = __builtin_amdgcn_permlane32_swap(pk[(2 * grp) * 2 + w], pk[(2 * grp + 1) * 2 + w], false, false);
+                    o[w] = sw2[0]; o[2 + w] = sw2[1];
+                }
+                if (ok) *reinterpret_cast<uint4 *>(dst + grp * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+template <int BC, int WP, int WC>
+int launch16w(const ConvDesc &d, hipStream_t st) {
+    const int n_mt = cdiv((int)d.M, BP), n_nt = d.Nc / BC, cpx = cdiv(n_mt, kNumXCD);
+    const int lds = 2 * (BP + BC) * 128;
+    auto kern = k_conv16w<BC, WP, WC>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt), dim3(512), lds, st, d, n_mt, n_nt, cpx);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+bool conv16w_applicable(const ConvDesc &d) {
+    static const bool off = getenv("EVFLY_NO_CONV16W") != nullptr;
+    return !off && d.in_bf16 && d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 &&
+           d.C % 64 == 0 && d.C >= 128 && d.Nc % 128 == 0 && !d.res && d.out_mode == OUT_ROWS && (d.act == ACT_RELU || d.act == ACT_NONE) &&
+           d.ldx % 8 == 0 && d.ldy % 8 == 0 && ((uintptr_t)d.x) % 16 == 0 && ((uintptr_t)d.y) % 16 == 0 && ((uintptr_t)d.w) % 16 == 0 &&
+           d.ldw % 64 == 0 && d.ldw >= d.K && d.M >= 64 * BP && d.M < ((int64_t)1 << 31) &&
+           (int64_t)d.NI * d.H * d.W * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.Nc * d.ldw * 2 < ((int64_t)1 << 32) &&
+           (!d.bias || ((uintptr_t)d.bias) % 16 == 0);
+}
+
+int conv16w_launch(const ConvDesc &d, hipStream_t st) {
+    EVFLY_REQUIRE(conv16w_applicable(d), "conv16w: layer not eligible");
+    // 256-channel tiles halve the pixel re-reads per flop: taken whenever the channel count allows (measured on the U-Net shapes at
+    // 320 frames: d11 0.310 -> 0.246 ms, e51 0.143 -> 0.132, d12 0.133 -> 0.126 against 128-channel tiles, although the grid shrinks
+    // to 1.6 blocks per CU)
+    static const int force = getenv("EVFLY_CONV16W_BC") ? atoi(getenv("EVFLY_CONV16W_BC")) : 0;
+    bool wide = d.Nc % 256 == 0;
+    if (force == 128) wide = false;
+    return wide ? launch16w<256, 2, 4>(d, st) : launch16w<128, 4, 2>(d, st);
+}
+
+}  // namespace evfly

@@ -108,6 +108,11 @@ void conv16_pack_host(const float *w_oihw, int cout, int cin, unsigned short *ou
 int conv16_pack_device(const float *w_otc, int cout, int cin, void *out, hipStream_t st);
 int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t st);
 
+// Wide-tile implicit GEMM of the bf16 pipeline for the deep 3x3 layers (conv16w.hip): C % 64 == 0, C >= 128, Nc % 128 == 0, stride 1,
+// no padding, bf16 in / out, bias + ReLU / none; reads the [Nc][ldw] bf16 GEMM weights of igemm16_launch.
+bool conv16w_applicable(const ConvDesc &d);
+int conv16w_launch(const ConvDesc &d, hipStream_t st);
+
 // >= 256 B of zeros in global memory on the current device (source of masked LDS-DMA rows)
 int igemm_zero_page(const float **out);
 

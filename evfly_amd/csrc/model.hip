@@ -613,6 +613,10 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     }
     EVFLY_REQUIRE(!d.pre_frames, "the fused first conv needs the Winograd / direct-convolution kernels");
     if (pool_fused) *pool_fused = false;
+    if (f16 == IO16 && !m->planning && conv16w_applicable(d)) {    // bf16 pipeline, deep 3x3 layers: 256-pixel tiles, 8 waves
+        RUN(m, pn.c_str(), igemm_flops(d), bytes, conv16w_launch(d, m->st));
+        return 0;
+    }
     RUN(m, pn.c_str(), igemm_flops(d), bytes, igemm_launch(d, m->st));
     return 0;
 }
@@ -1395,6 +1399,7 @@ extern "C" int evfly_op_conv2d_nhwc_bf16(const uint16_t *x, int n, int h, int w,
         if (int rc = conv16_pack_device(w_packed, cout, cin, wdp, as_stream(stream))) return rc;
         return conv16_launch(d, wdp, nullptr, as_stream(stream));
     }
+    if (conv16w_applicable(d)) return conv16w_launch(d, as_stream(stream));      // the deep 3x3 layers
     return igemm_launch(d, as_stream(stream));
 }
 

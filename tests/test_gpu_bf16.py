@@ -90,6 +90,10 @@ def _assert_bf16_close(got, ref):
     (200, 27, 37, 128, 256, 3, 1, 1, 0, True),   # padding + residual
     (300, 29, 39, 128, 256, 3, 1, 0, 1, False),  # e41's geometry
     (100, 45, 45, 512, 128, 1, 1, 0, 2, True),   # Linear K = 512 + residual
+    # wide-tile kernel of the deep layers (conv16w.hip; the two e32 / e41 cases above run on it too: 128- and 256-channel tiles)
+    (48, 22, 20, 256, 128, 3, 1, 0, 1, False),   # four 64-channel K chunks, 128-channel tiles, ragged last pixel tile
+    (20, 32, 30, 512, 256, 3, 1, 0, 0, False),   # too few pixel tiles for the 256-channel tile: two 128-channel tiles per pixel tile
+    (130, 34, 34, 256, 512, 3, 1, 0, 1, False),  # 256-channel tiles, two per pixel tile
 ])
 def test_conv_bf16_pipeline_kernel(gpu_device, case):
     n, h, w, cin, cout, k, stride, pad, act, with_res = case
