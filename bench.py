@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x3 pass (C2 only)")
     ap.add_argument("--no-other-configs", action="store_true", help="default C2 run: skip the compact C5 / C3 / C4 objects")
+    ap.add_argument("--no-overlap", action="store_true", help="run the velocity model back to back behind the depth model on one "
+                    "stream (the composite call) instead of on a second stream under the next step's depth model")
     ap.add_argument("--no-stage-rates", action="store_true", help="skip the V / D / P-only timings")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     a = ap.parse_args()
@@ -257,8 +259,22 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
     frames = torch.empty(B, T, H, W, device="cuda")
     counts = shard_row_counts(world * B, world, T)                                  # every rank: B streams (weak scaling)
     vel_host = torch.empty(world * B * T, 3).pin_memory() if composite else None    # §8d: "velocity rows on host-visible memory"
-    hip = model.hip()
+    # Two-stream pipeline (evfly_amd/pipeline.py): the velocity model of step i (ViT + LSTM, ~55 small launches) runs on a second HIP
+    # stream behind the depth model's completion event while the first stream goes on with voxelize + condition + depth model of
+    # step i + 1 -- the same kernels and bits as the back-to-back composite call, the small launches filling the large ones' gaps.
+    # The timed region still closes with a device-wide synchronize: all K steps' velocities are in pinned host memory inside it.
+    pipe = None
+    if composite and not a.no_overlap:
+        from evfly_amd.pipeline import StreamPipeline
+        pipe = StreamPipeline(model)
+    hips = [pipe.unet.hip(), pipe.vit.hip()] if pipe else [model.hip()]
+    hip = hips[0]
     L = hip._L
+
+    def publish(vel):
+        vel_all = gather_velocities(vel, dist, counts=counts if dist is not None else None)
+        vel_host.copy_(vel_all, non_blocking=True)                                    # lands before the closing synchronize
+        return vel_all
 
     def step():
         voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi)
@@ -266,10 +282,10 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         if not composite:                                                             # C5: depth maps stay in HBM
             depth, _, _ = model.forward_streams(x, None, B, T)
             return depth
+        if pipe:
+            return pipe.step(x, desvel, B, T, after=publish)[2]
         vel, _ = model.forward_streams([x, desvel, [None, None], None], B, T)
-        vel_all = gather_velocities(vel, dist, counts=counts if dist is not None else None)
-        vel_host.copy_(vel_all, non_blocking=True)                                    # lands before the closing synchronize
-        return vel_all
+        return publish(vel)
 
     def sync():
         torch.cuda.synchronize()
@@ -283,12 +299,15 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         # An untimed, fully bracketed step first: the per-kernel breakdown (`kernels`, `conv_layers`, `stages`) and the
         # name of the dominant family. Bracketing EVERY launch with HIP events costs ~1 ms per step (two
         # hipEventRecord serialise each of the ~150 launches), so the timed region brackets only that family.
-        L.evfly_model_set_profile_filter(hip.h, None)
-        L.evfly_model_profile_reset(hip.h)
-        L.evfly_model_set_profiling(hip.h, 1)
+        for hh in hips:
+            L.evfly_model_set_profile_filter(hh.h, None)
+            L.evfly_model_profile_reset(hh.h)
+            L.evfly_model_set_profiling(hh.h, 1)
         step(); sync()
-        L.evfly_model_set_profiling(hip.h, 0)
-        layers_all = hip.profile()
+        layers_all = []
+        for hh in hips:
+            L.evfly_model_set_profiling(hh.h, 0)
+            layers_all += hh.profile()
         fam_ms = {}
         for p in layers_all:
             fam_ms[p["name"].split("/")[0]] = fam_ms.get(p["name"].split("/")[0], 0.0) + p["ms"]
@@ -387,6 +406,8 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                    "streams_per_gpu": B, "windows": T, "events_per_step_per_gpu": n_events, "sensor": [Hs, Ws], "vit_trunk": cfg["vit"] if composite else None,
                    "parallelism": f"streams sharded x{world}, all_gather of velocities" if world > 1 else "single GPU"},
         "step_ms": step_ms,
+        "pipeline": ("two HIP streams: velocity model (ViT + LSTM) of step i under voxelize + depth model of step i + 1 "
+                     "(evfly_amd/pipeline.py; --no-overlap = one stream)" if pipe else "one HIP stream"),
     }
     if dist is not None:
         out["ranks"] = {"ms_per_step_by_rank": rank_ms, "all_gather_us": gather_us,
@@ -511,7 +532,8 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             # Informational second precision mode, NOT the headline `value`: the bf16 pipeline (bf16 activations in HBM, bf16
             # MFMA, fp32 accumulate). Same inputs, same weights; the velocity deviation from the exact-fp32 run is reported with it.
             vel_f32 = out_dev.clone()
-            model.set_compute_dtype("bf16")
+            for mm in (model, model.origunet, model.vitfly_vitlstm):
+                mm.set_compute_dtype("bf16")
             with torch.no_grad():
                 for _ in range(max(1, a.warmup)):
                     v3 = step()
@@ -525,11 +547,12 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                                     "ms_per_step": round(1e3 * dt3 / a.steps, 3),
                                     "max_rel_dev_velocity_vs_f32": float(((v3 - vel_f32).abs().max() / vel_f32.abs().max()).item()),
                                     "note": "bf16 pipeline (BASELINE configs C3 / C5 run in it); informational, not the headline"}
-            model.set_compute_dtype("f32")
+            for mm in (model, model.origunet, model.vitfly_vitlstm):
+                mm.set_compute_dtype("f32")
         if detail and not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, a.cpu_seconds)
     # release this config's device memory (events, frames, the model handle's arena) before the next one is built
-    del model, hip, ev, frames, out_dev, desvel
+    del model, hip, hips, pipe, ev, frames, out_dev, desvel
     import gc
     gc.collect()
     torch.cuda.empty_cache()

@@ -332,6 +332,33 @@ def test_handle_invalidation_parent_load_and_inplace_updates(gpu_device):
     assert not torch.equal(d0, d4), ".data re-assignment was not picked up"
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_stream_pipeline_equals_composite(gpu_device, dtype):
+    """evfly_amd.pipeline.StreamPipeline (velocity model of batch i on a second HIP stream under the depth model of batch i + 1)
+    against the composite's back-to-back call: three consecutive stateful batches of 3 streams x 2 windows -- velocities, depth,
+    ConvLSTM and LSTM states bit-identical (same kernels, same order inside each model)."""
+    from evfly_amd.pipeline import StreamPipeline
+    net, sd = _composite(gpu_device, dtype)
+    net2, _ = _composite(gpu_device, dtype)
+    pipe = StreamPipeline(net2)
+    S, T = 3, 2
+    desvel = torch.full((S * T, 1), 4.0, device=gpu_device)
+    hu = hv = hu2 = hv2 = None
+    outs = []
+    for i in range(3):
+        x = cond_frames(300 + i, S * T).to(gpu_device)
+        v, (d, up, ((hu, _), hv)) = net.forward_streams([x, desvel, [hu, None], hv], S, T)
+        v2, (d2, up2, ((hu2, _), hv2)), tag = pipe.step(x, desvel, S, T, unet_state=hu2, vit_state=hv2, after=lambda vel: vel.shape[0])
+        outs.append((v, d, up, v2, d2, up2))
+        assert tag == S * T
+    pipe.wait()
+    torch.cuda.synchronize()
+    for v, d, up, v2, d2, up2 in outs:
+        assert torch.equal(v, v2) and torch.equal(d, d2) and torch.equal(up, up2)
+    assert torch.equal(hu[0][0], hu2[0][0]) and torch.equal(hu[0][1], hu2[0][1])
+    assert torch.equal(hv[0], hv2[0]) and torch.equal(hv[1], hv2[1])
+
+
 def test_multi_stream_matches_per_stream_oracle(gpu_device):
     """The throughput entry (streams batched, batch-as-time inside each) == every stream run alone."""
     net, sd = _composite(gpu_device)
