@@ -33,6 +33,10 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+#ifndef EVFLY_C16_ABL
+#define EVFLY_C16_ABL 0        // tools/scripts timing experiments only (garbage results): 1 = contiguous 1-KiB store runs
+#endif
+constexpr int kAbl16 = EVFLY_C16_ABL;
 constexpr int TW = 32;             // output pixels per tile row = one MFMA pixel tile
 constexpr int PWD = TW + 2;        // patch width
 constexpr int NWAVE = 8;
@@ -269,6 +273,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
             const int ch = grp * 16 + fh * 8;     // first of this lane's 8 channels inside the 32-channel tile
+            if constexpr (kAbl16 & 1) {           // timing experiment: the same bytes as one contiguous 1-KiB run per instruction
+                bf16_t *rowp = dst_px - (int64_t)fj * (ncount);
+                *reinterpret_cast<uint4 *>(rowp + ((nbase >> 5) * 2 + grp) * 512 + (threadIdx.x & 63) * 8) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
+                continue;
+            }
             if (nbase + ch < ncount)
                 *reinterpret_cast<uint4 *>(dst_px + nbase + ch) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
         }

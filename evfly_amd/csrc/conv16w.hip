@@ -32,7 +32,7 @@
 
 // Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 pixel DMA for tap 0 of a chunk only
 // (the traffic of a direct convolution that stages each input pixel once), 2 no pixel DMA, 4 no weight DMA, 8 no LDS fragment
-// reads behind the first K-tile. The shipped library is built with 0.
+// reads behind the first K-tile, 32 / 64 every weight / pixel K-tile re-reads tile 0 (cache-resident source). The shipped library is built with 0.
 #ifndef EVFLY_C16W_ABL
 #define EVFLY_C16W_ABL 0
 #endif
@@ -51,7 +51,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int BP = 256;            // pixels per block tile
 constexpr int NW = 8;              // waves per block
 
 // one 1-KiB LDS-DMA piece: lane l's 16 B land at lds_addr + 16 l (M0 = LDS base; nothing else in this file uses M0)
@@ -59,7 +58,7 @@ __device__ __forceinline__ void dma_piece(unsigned voff, i32x4 srd, unsigned sof
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
 
-template <int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC>
 __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt, int cpx) {
     static_assert(WP * WC == NW, "8 waves");
     constexpr int TP = BP / WP / 32, TC = BC / WC / 32;       // 32-wide pixel / channel MFMA tiles per wave
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
         i32x4 sdx = srdx, sdw = srdw;
         sdx[2] = more ? srdx[2] : 0;
         sdw[2] = more ? srdw[2] : 0;
-        const unsigned sx = soff_x(), sw = soff_w();
+        const unsigned sx = (kAblW & 64) ? 0u : soff_x(), sw = (kAblW & 32) ? 0u : soff_w();     // (ablations: the same tile again)
         const unsigned char *xs = smem + cur * STAGE + (wp * TP * 32) * 128;
         const unsigned char *ws = smem + cur * STAGE + BP * 128 + (wc * TC * 32) * 128;
         // sub-step s (chunks 2s / 2s + 1 of every row): TC weight + TP pixel fragments, those of s + 1 requested under the MFMAs of s
@@ -254,11 +253,11 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
     }
 }
 
-template <int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC>
 int launch16w(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv((int)d.M, BP), n_nt = d.Nc / BC, cpx = cdiv(n_mt, kNumXCD);
     const int lds = 2 * (BP + BC) * 128;
-    auto kern = k_conv16w<BC, WP, WC>;
+    auto kern = k_conv16w<BP, BC, WP, WC>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
@@ -279,7 +278,7 @@ bool conv16w_applicable(const ConvDesc &d) {
     return !off && d.in_bf16 && d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 &&
            d.C % 64 == 0 && d.C >= 128 && d.Nc % 128 == 0 && !d.res && d.out_mode == OUT_ROWS && (d.act == ACT_RELU || d.act == ACT_NONE) &&
            d.ldx % 8 == 0 && d.ldy % 8 == 0 && ((uintptr_t)d.x) % 16 == 0 && ((uintptr_t)d.y) % 16 == 0 && ((uintptr_t)d.w) % 16 == 0 &&
-           d.ldw % 64 == 0 && d.ldw >= d.K && d.M >= 64 * BP && d.M < ((int64_t)1 << 31) &&
+           d.ldw % 64 == 0 && d.ldw >= d.K && d.M >= 64 * 256 && d.M < ((int64_t)1 << 31) &&
            (int64_t)d.NI * d.H * d.W * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.Nc * d.ldw * 2 < ((int64_t)1 << 32) &&
            (!d.bias || ((uintptr_t)d.bias) % 16 == 0);
 }
@@ -292,7 +291,9 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st) {
     static const int force = getenv("EVFLY_CONV16W_BC") ? atoi(getenv("EVFLY_CONV16W_BC")) : 0;
     bool wide = d.Nc % 256 == 0;
     if (force == 128) wide = false;
-    return wide ? launch16w<256, 2, 4>(d, st) : launch16w<128, 4, 2>(d, st);
+    // (128-pixel tiles for grids of 1..2 rounds -- e52 at 320 frames is 260 tiles on 256 CUs -- were measured: they stream the
+    // weights twice as often per flop and lose on every layer, e52 0.229 -> 0.260 ms, d11 0.247 -> 0.353)
+    return wide ? launch16w<256, 256, 2, 4>(d, st) : launch16w<256, 128, 4, 2>(d, st);
 }
 
 }  // namespace evfly
