@@ -34,7 +34,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 #ifndef EVFLY_C16_ABL
-#define EVFLY_C16_ABL 0        // tools/scripts timing experiments only (garbage results): 1 = contiguous 1-KiB store runs
+#define EVFLY_C16_ABL 0        // tools/scripts timing experiments only (garbage results): 1 = contiguous 1-KiB store runs, 2 = no fused
+                               // first-conv producer, 4 = no frame staging, 8 = no output stores
 #endif
 constexpr int kAbl16 = EVFLY_C16_ABL;
 constexpr int TW = 32;             // output pixels per tile row = one MFMA pixel tile
@@ -148,17 +149,28 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     // full memory round trip every step.
     constexpr int FPT = (FPIX + 511) / 512;                            // frame-patch values per thread
     float fval[PRE ? FPT : 1];
-    auto frame_load = [&](int t) {
-        int img, ty, tx;
-        tile_decode(t, img, ty, tx);
-        const int fy0 = ty * TH, fx0 = tx * TW;                        // the frame is (H + 2) x (W + 2): frame pixel = e11 pixel + tap
+    // (per-thread frame-patch coordinates are tile-invariant: computed once, not per step -- the shallow layers are bound by their
+    // VALU instruction count, not by the matrix pipe)
+    int f_yx[PRE ? FPT : 1], f_off[PRE ? FPT : 1];
+    if constexpr (PRE) {
 #pragma unroll
         for (int u = 0; u < FPT; ++u) {
             const int i = tid + u * 512;
             const int fy = i / FW, fx = i - fy * FW;
-            const int gy = fy0 + fy, gx = fx0 + fx;
-            fval[u] = (i < FPIX && gy < d.H + 2 && gx < d.W + 2) ? d.pre_frames[((int64_t)img * (d.H + 2) + gy) * (d.W + 2) + gx] : 0.f;
+            f_yx[u] = i < FPIX ? (fy | (fx << 16)) : (0x7fff | (0x7fff << 16));
+            f_off[u] = fy * (d.W + 2) + fx;
         }
+    }
+    auto frame_load = [&](int t) {
+        if constexpr (kAbl16 & 4) return;          // timing experiment: no frame staging
+        int img, ty, tx;
+        tile_decode(t, img, ty, tx);
+        const int fy0 = ty * TH, fx0 = tx * TW;                        // the frame is (H + 2) x (W + 2): frame pixel = e11 pixel + tap
+        const float *fsrc = d.pre_frames + ((int64_t)img * (d.H + 2) + fy0) * (d.W + 2) + fx0;
+        const int hrem = d.H + 2 - fy0, wrem = d.W + 2 - fx0;
+#pragma unroll
+        for (int u = 0; u < FPT; ++u)
+            fval[u] = ((f_yx[u] & 0xffff) < hrem && (f_yx[u] >> 16) < wrem) ? fsrc[f_off[u]] : 0.f;
     };
     auto frame_store = [&](int fb) {
         float *f = fbuf + fb * FPIX;
@@ -195,34 +207,51 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) pbias16[r] = d.pre_b[(r & 3) + 8 * (r >> 2) + 4 * kh];
     }
+    // producer geometry of this lane's patch pixels (m-tile slots wv, wv + 8, wv + 16): tile-invariant, computed once
+    constexpr int NMT = (NPIX + 31) / 32, NSLOT = (NMT + NWAVE - 1) / NWAVE;
+    int pp_f[PRE ? NSLOT : 1], pp_rc[PRE ? NSLOT : 1], pp_d0[PRE ? NSLOT : 1], pp_d1[PRE ? NSLOT : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int q = (wv + i * NWAVE) * 32 + (lane & 31), qc = q < NPIX ? q : NPIX - 1;
+            const int pr = qc / PWD, pcx = qc - pr * PWD;
+            pp_f[i] = pr * FW + pcx;
+            pp_rc[i] = pr | (pcx << 16);
+            pp_d0[i] = q < NPIX ? patch_off(q, lane >> 5) : -1;
+            pp_d1[i] = q < NPIX ? patch_off(q, 2 + (lane >> 5)) : -1;
+        }
+    }
     auto produce_patch = [&](int t, int fb, int buf) {
+        if constexpr (kAbl16 & 2) return;          // timing experiment: no producer
         int img, ty, tx;
         tile_decode(t, img, ty, tx);
         const int iy0 = ty * TH, ix0 = tx * TW;
         const float *f = fbuf + fb * FPIX;
         unsigned char *dstb = smem + buf * PATCH_BYTES;
-        const int pn = lane & 31, kh = lane >> 5;
-        constexpr int NMT = (NPIX + 31) / 32;
-        for (int mt = wv; mt < NMT; mt += NWAVE) {
-            const int q = mt * 32 + pn, qc = q < NPIX ? q : NPIX - 1;
-            const int pr = qc / PWD, pcx = qc - pr * PWD;
-            const float *fp = f + pr * FW + pcx;
-            float v[8];
-            if (kh == 0) {
-                v[0] = fp[0]; v[1] = fp[1]; v[2] = fp[2]; v[3] = fp[FW]; v[4] = fp[FW + 1]; v[5] = fp[FW + 2]; v[6] = fp[2 * FW]; v[7] = fp[2 * FW + 1];
-            } else {
-                v[0] = fp[2 * FW + 2];
+        const int kh = lane >> 5;
+        const int hrem = d.H - iy0, wrem = d.W - ix0;
 #pragma unroll
-                for (int e = 1; e < 8; ++e) v[e] = 0.f;
-            }
+        for (int i = 0; i < NSLOT; ++i) {
+            if (wv + i * NWAVE >= NMT) break;
+            const float *fp = f + pp_f[i];
+            // taps 0-7 in lanes 0-31, tap 8 + seven zeros in lanes 32-63: every lane issues the same eight loads (the upper half reads
+            // valid neighbours and discards them) -- a divergent if / else runs the two halves one after the other
+            float v[8];
+            v[0] = fp[kh ? 2 * FW + 2 : 0];
+            v[1] = fp[1]; v[2] = fp[2]; v[3] = fp[FW]; v[4] = fp[FW + 1]; v[5] = fp[FW + 2]; v[6] = fp[2 * FW]; v[7] = fp[2 * FW + 1];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) v[e] = kh ? 0.f : v[e];
             const uint4 b4 = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
             const f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pwa, *reinterpret_cast<const bf16x8 *>(&b4), pbias16, 0, 0, 0);
-            const bool in = iy0 + pr < d.H && ix0 + pcx < d.W;           // beyond the (virtual) e11 map: zeros
+            const bool in = (pp_rc[i] & 0xffff) < hrem && (pp_rc[i] >> 16) < wrem;           // beyond the (virtual) e11 map: zeros
             unsigned pkd[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float x0 = in ? (a[2 * k] < 0.f ? 0.f : a[2 * k]) : 0.f, x1 = in ? (a[2 * k + 1] < 0.f ? 0.f : a[2 * k + 1]) : 0.f;
-                pkd[k] = pack_bf2(x0, x1);
+                // (ReLU as a plain select, the edge mask on the packed pair: nested `in ? (a < 0 ? 0 : a) : 0` made hipcc emit an
+                // exec-mask branch region per value -- 150 of them in this kernel)
+                const float x0 = a[2 * k] < 0.f ? 0.f : a[2 * k], x1 = a[2 * k + 1] < 0.f ? 0.f : a[2 * k + 1];
+                const unsigned pp = pack_bf2(x0, x1);
+                pkd[k] = in ? pp : 0u;
             }
             // pkd[2 g], pkd[2 g + 1] = channel quad g of this half (channels 8 g + 4 kh .. + 3): the swaps hand every lane 8
             // adjacent channels twice -- lanes < 32: chunks 0 and 2 of the pixel, lanes >= 32: chunks 1 and 3
@@ -234,7 +263,8 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                     const auto sw = __builtin_amdgcn_permlane32_swap(pkd[(2 * grp) * 2 + w], pkd[(2 * grp + 1) * 2 + w], false, false);
                     o[w] = sw[0]; o[2 + w] = sw[1];
                 }
-                if (q < NPIX) *reinterpret_cast<uint4 *>(dstb + patch_off(q, grp * 2 + kh)) = make_uint4(o[0], o[1], o[2], o[3]);
+                const int doff = grp == 0 ? pp_d0[i] : pp_d1[i];
+                if (doff >= 0) *reinterpret_cast<uint4 *>(dstb + doff) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
     };
@@ -273,6 +303,10 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
             const int ch = grp * 16 + fh * 8;     // first of this lane's 8 channels inside the 32-channel tile
+            if constexpr (kAbl16 & 8) {           // timing experiment: no output stores (values kept alive)
+                asm volatile("" ::"v"(o[grp * 4]), "v"(o[grp * 4 + 1]), "v"(o[grp * 4 + 2]), "v"(o[grp * 4 + 3]));
+                continue;
+            }
             if constexpr (kAbl16 & 1) {           // timing experiment: the same bytes as one contiguous 1-KiB run per instruction
                 bf16_t *rowp = dst_px - (int64_t)fj * (ncount);
                 *reinterpret_cast<uint4 *>(rowp + ((nbase >> 5) * 2 + grp) * 512 + (threadIdx.x & 63) * 8) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
@@ -315,6 +349,14 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     };
 
     f32x16 acc[ROWS][NTB];
+    // bias of this lane's channels n = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): the accumulators START from it (one
+    // v_mov per value instead of a v_mov 0 and an add behind the MFMAs)
+    // (kept in registers for one 32-channel tile per block; with two, re-read from LDS per output tile: 32 more live registers spill)
+    f32x16 bias16[NTB == 1 ? 1 : 1];
+    if constexpr (NTB == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias16[0][e] = bl[(e & 3) + 8 * (e >> 2) + 4 * fh];
+    }
     int t_cur = bis, cc = 0;
     for (int s = 0; s < n_steps; ++s) {
         // the next step's patch flies (DMA) or is computed (PRE) under this step's MFMAs.
@@ -341,30 +383,40 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
                 for (int j = 0; j < NTB; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[r][j][e] = NTB == 1 ? bias16[0][e] : bl[j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
         }
+        // (kx, k-half) outer: the ROWS + 2 pixel fragments of the wave's input rows at this column shift and the 3 NTB weight
+        // fragments of the tap column feed 3 ROWS NTB MFMAs (an input row serves up to three output rows: 24 pixel reads per
+        // step instead of 36), and the fragments of iteration it + 1 are requested before the MFMAs of it. (Round 3's loop read
+        // three fragments, waited for all of them and issued two MFMAs, 18 times per step: the matrix pipe idled through an LDS
+        // round trip per MFMA pair -- 35 % busy with stores and producer ablated.)
+        bf16x8 pxq[2][ROWS + 2], wfq[2][3][NTB];
+        auto load_it = [&](int it, bf16x8 (&pxd)[ROWS + 2], bf16x8 (&wfd)[3][NTB]) {
+            const int kx = it >> 1, kb = it & 1;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ky = t / 3, kx = t % 3;
+            for (int y = 0; y < ROWS + 2; ++y) {
+                const int q = (wv * ROWS + y) * PWD + fj + kx;
+                pxd[y] = *reinterpret_cast<const bf16x8 *>(pb + patch_off(q, kb * 2 + fh));
+            }
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                bf16x8 px[ROWS], wf[NTB];
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const int q = (wv * ROWS + r + ky) * PWD + fj + kx;
-                    px[r] = *reinterpret_cast<const bf16x8 *>(pb + patch_off(q, kb * 2 + fh));
-                }
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int j = 0; j < NTB; ++j)
-                    wf[j] = *reinterpret_cast<const bf16x8 *>(wc + ((t * 2 + kb) * NTB + j) * 1024 + lane * 16);
+                    wfd[ky][j] = *reinterpret_cast<const bf16x8 *>(wc + (((ky * 3 + kx) * 2 + kb) * NTB + j) * 1024 + lane * 16);
+        };
+        load_it(0, pxq[0], wfq[0]);
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            if (it + 1 < 6) load_it(it + 1, pxq[(it + 1) & 1], wfq[(it + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], px[r], acc[r][j], 0, 0, 0);
-            }
-            // (fragment reads stay within two taps of their MFMAs: unbounded, the scheduler front-loads all 18 x (ROWS + NTB) reads
-            // of a step and the <2, 2> variants run out of registers)
-            if (t & 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < NTB; ++j)
+                        acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[it & 1][ky][j], pxq[it & 1][r + ky], acc[r][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (PRE) {
             if ((wv & 1) == 1 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
@@ -374,38 +426,36 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             // ---- the tile's results, packed straight from the accumulators (stored by flush_tile)
             const bool relu = d.act == ACT_RELU;        // (conv16_applicable admits ACT_RELU / ACT_NONE only)
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) {
-                // bias of this lane's channels n = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): four adjacent floats per r-group
-                float4 b4[4];
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) b4[rg] = *reinterpret_cast<const float4 *>(bl + j * 32 + 8 * rg + 4 * fh);
+            for (int j = 0; j < NTB; ++j)
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
-                        const float b0 = (e & 2) ? b4[e >> 2].z : b4[e >> 2].x, b1 = (e & 2) ? b4[e >> 2].w : b4[e >> 2].y;
-                        float v0 = acc[r][j][e] + b0, v1 = acc[r][j][e + 1] + b1;
-                        v0 = (relu && v0 < 0.f) ? 0.f : v0; v1 = (relu && v1 < 0.f) ? 0.f : v1;
+                        float v0 = acc[r][j][e], v1 = acc[r][j][e + 1];
+                        // ReLU as !(v <= 0) ? v : +0: NaN passes like torch.relu, and -0 becomes +0 so that every activated value is
+                        // +0, positive, +inf or NaN -- the domain the pooling below relies on
+                        if constexpr (!(kAbl16 & 32)) { v0 = (relu && v0 <= 0.f) ? 0.f : v0; v1 = (relu && v1 <= 0.f) ? 0.f : v1; }
                         pk[r][j][e >> 1] = pack_bf2(v0, v1);
                     }
-            }
             if constexpr (POOL && ROWS == 2) {
-                // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes.
-                // The max of bf16-rounded values is the rounded max (rounding is monotonic): pool the packed results. NaN wins like
-                // in torch (fmaxf alone would drop it).
+                // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes (one DPP
+                // quad permute per packed pair: no LDS round trip). The max of bf16-rounded values is the rounded max (rounding is
+                // monotonic): pool the packed results, and do it as UNSIGNED 16-bit integers -- on {+0, positive, +inf, NaN} the bit
+                // patterns order like the values, with every NaN (0x7f81.. / 0xff81..) above +inf: one v_pk_max_u16 per pair is the
+                // NaN-propagating max of torch's max_pool2d (the launcher fuses the pool only behind a ReLU). (Round 3 spelled the
+                // NaN cases as nested float selects around ds_bpermute shuffles: sixteen divergent branch regions with an LDS wait
+                // each, ~2.5 k cycles per tile.)
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                auto pmax = [](unsigned x, unsigned y) {
+                    const u16x2 r = __builtin_elementwise_max(*reinterpret_cast<const u16x2 *>(&x), *reinterpret_cast<const u16x2 *>(&y));
+                    return *reinterpret_cast<const unsigned *>(&r);
+                };
 #pragma unroll
                 for (int j = 0; j < NTB; ++j)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const unsigned a = pk[0][j][e], b = pk[1][j][e];
-                        float lo = fmaxf(bf_lo(a), bf_lo(b)), hi = fmaxf(bf_hi(a), bf_hi(b));
-                        lo = (bf_lo(a) != bf_lo(a)) ? bf_lo(a) : (bf_lo(b) != bf_lo(b)) ? bf_lo(b) : lo;
-                        hi = (bf_hi(a) != bf_hi(a)) ? bf_hi(a) : (bf_hi(b) != bf_hi(b)) ? bf_hi(b) : hi;
-                        const float lo2 = __shfl_xor(lo, 1), hi2 = __shfl_xor(hi, 1);
-                        float ml = fmaxf(lo, lo2), mh = fmaxf(hi, hi2);
-                        ml = (lo != lo) ? lo : (lo2 != lo2) ? lo2 : ml;
-                        mh = (hi != hi) ? hi : (hi2 != hi2) ? hi2 : mh;
-                        pm[j][e] = pack_bf2(ml, mh);
+                        const unsigned v = pmax(pk[0][j][e], pk[1][j][e]);
+                        pm[j][e] = pmax(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));       // lane ^ 1: quad_perm [1, 0, 3, 2]
                     }
             }
             st_tile = t_cur;
@@ -502,7 +552,7 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
     const bool pool = y_pool != nullptr;
     const int waste16 = cdiv(d.OH, 16) * 16 - d.OH, waste8 = cdiv(d.OH, 8) * 8 - d.OH;
     const int rows = (pool || d.pre_frames || waste16 <= waste8 + 2) ? 2 : 1;
-    EVFLY_REQUIRE(!pool || (d.OH % 2 == 0 || true), "conv16: pool");
+    EVFLY_REQUIRE(!pool || d.act == ACT_RELU, "conv16: the fused 2x2 max pool needs the ReLU epilogue (its integer max relies on non-negative values)");
     Conv16Geom g{};
     const int TH = 8 * rows;
     g.tiles_x = cdiv(d.OW, TW); g.tiles_y = cdiv(d.OH, TH);
