@@ -276,7 +276,7 @@ int launch16w(const ConvDesc &d, hipStream_t st) {
 bool conv16w_applicable(const ConvDesc &d) {
     static const bool off = getenv("EVFLY_NO_CONV16W") != nullptr;
     return !off && d.in_bf16 && d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 0 &&
-           d.C % 64 == 0 && d.C >= 128 && d.Nc % 128 == 0 && !d.res && d.out_mode == OUT_ROWS && (d.act == ACT_RELU || d.act == ACT_NONE) &&
+           d.C % 64 == 0 && d.C >= 128 && d.Nc % 64 == 0 && !d.res && d.out_mode == OUT_ROWS && (d.act == ACT_RELU || d.act == ACT_NONE) &&
            d.ldx % 8 == 0 && d.ldy % 8 == 0 && ((uintptr_t)d.x) % 16 == 0 && ((uintptr_t)d.y) % 16 == 0 && ((uintptr_t)d.w) % 16 == 0 &&
            d.ldw % 64 == 0 && d.ldw >= d.K && d.M >= 64 * 256 && d.M < ((int64_t)1 << 31) &&
            (int64_t)d.NI * d.H * d.W * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.Nc * d.ldw * 2 < ((int64_t)1 << 32) &&
@@ -291,6 +291,8 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st) {
     static const int force = getenv("EVFLY_CONV16W_BC") ? atoi(getenv("EVFLY_CONV16W_BC")) : 0;
     bool wide = d.Nc % 256 == 0;
     if (force == 128) wide = false;
+    // 64 output channels (d31): 512 pixels x 64 channels per block, the 256 x 128 tile's operand traffic per flop with half the weights
+    if (d.Nc % 128 != 0) return launch16w<512, 64, 8, 1>(d, st);
     // (128-pixel tiles for grids of 1..2 rounds -- e52 at 320 frames is 260 tiles on 256 CUs -- were measured: they stream the
     // weights twice as often per flop and lose on every layer, e52 0.229 -> 0.260 ms, d11 0.247 -> 0.353)
     return wide ? launch16w<256, 256, 2, 4>(d, st) : launch16w<256, 128, 4, 2>(d, st);

@@ -94,6 +94,7 @@ def _assert_bf16_close(got, ref):
     (48, 22, 20, 256, 128, 3, 1, 0, 1, False),   # four 64-channel K chunks, 128-channel tiles, ragged last pixel tile
     (20, 32, 30, 512, 256, 3, 1, 0, 0, False),   # too few pixel tiles for the 256-channel tile: two 128-channel tiles per pixel tile
     (130, 34, 34, 256, 512, 3, 1, 0, 1, False),  # 256-channel tiles, two per pixel tile
+    (60, 40, 40, 128, 64, 3, 1, 0, 1, False),    # d31's channel counts: 512-pixel x 64-channel tiles, ragged last tile
 ])
 def test_conv_bf16_pipeline_kernel(gpu_device, case):
     n, h, w, cin, cout, k, stride, pad, act, with_res = case
