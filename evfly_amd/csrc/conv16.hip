@@ -289,7 +289,14 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
     // lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: after the swaps lane l owns
     // channels 0-7 and 16-23, lane l + 32 channels 8-15 and 24-31 (16 B each)
-    auto store_rows = [&](const unsigned (&p)[8], bf16_t *dst_px, bool ok, int nbase, int ncount) {
+    // Outputs leave through buffer descriptors over the two output tensors: a store is ONE unconditional instruction (lanes without
+    // an output carry an out-of-range offset and are dropped) -- no exec-mask branch per store.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y16, 0, (int)(unsigned)((int64_t)d.NI * d.OH * d.OW * d.ldy * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+        POOL ? reinterpret_cast<bf16_t *>(g.y_pool) : y16, 0, POOL ? (int)(unsigned)((int64_t)d.NI * (d.OH / 2) * (d.OW / 2) * d.Nc * 2) : 0, 0x00020000);
+    auto store_rows = [&](const unsigned (&p)[8], __amdgpu_buffer_rsrc_t rs, unsigned px_off, int nbase, int ncount) {
         unsigned o[8];
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp)          // quads (0, 1) and (2, 3)
@@ -299,7 +306,6 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                 o[grp * 4 + w] = sw[0];          // lanes < 32: own quad 2 grp       | lanes >= 32: partner's quad 2 grp + 1
                 o[grp * 4 + 2 + w] = sw[1];      // lanes < 32: partner's quad 2 grp | lanes >= 32: own quad 2 grp + 1
             }
-        if (!ok) return;
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
             const int ch = grp * 16 + fh * 8;     // first of this lane's 8 channels inside the 32-channel tile
@@ -307,23 +313,19 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                 asm volatile("" ::"v"(o[grp * 4]), "v"(o[grp * 4 + 1]), "v"(o[grp * 4 + 2]), "v"(o[grp * 4 + 3]));
                 continue;
             }
-            if constexpr (kAbl16 & 1) {           // timing experiment: the same bytes as one contiguous 1-KiB run per instruction
-                bf16_t *rowp = dst_px - (int64_t)fj * (ncount);
-                *reinterpret_cast<uint4 *>(rowp + ((nbase >> 5) * 2 + grp) * 512 + (threadIdx.x & 63) * 8) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
-                continue;
-            }
-            if (nbase + ch < ncount)
-                *reinterpret_cast<uint4 *>(dst_px + nbase + ch) = make_uint4(o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]);
+            const unsigned vo = (px_off != OOB && nbase + ch < ncount) ? px_off + (unsigned)(nbase + ch) * 2u : OOB;
+            const u32x4 v = {o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)vo, 0, 0);
         }
     };
-    // The finished tile is packed (bias, activation, bf16, pool) behind its MFMAs but STORED at the top of the next step, ahead
-    // of that step's DMA requests: with one block per CU nothing else hides the stores' acknowledgement, and the step-closing
-    // vmcnt(0) (which the DMA needs) would wait for it every step (measured: 12 k cycles per step for 2.3 k cycles of MFMAs).
+    // The finished tile is packed (bias, activation, bf16, pool) behind its MFMAs but STORED at the top of the next step: with one
+    // block per CU nothing else hides the stores' acknowledgement (measured in round 3: 12 k cycles per step for 2.3 k cycles of
+    // MFMAs when the step-closing wait covered them).
     unsigned pk[ROWS][NTB][8];           // packed bf16 pairs of the tile waiting to be stored: [row][n-tile][r-group 0..3][dword 0..1]
     unsigned pm[POOL ? NTB : 1][8];
     int st_tile = -1;
-    auto flush_tile = [&]() {
-        if (st_tile < 0) return;
+    auto flush_tile = [&]() -> bool {
+        if (st_tile < 0) return false;
         int img, ty, tx;
         tile_decode(st_tile, img, ty, tx);
         const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
@@ -332,20 +334,20 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         for (int r = 0; r < ROWS; ++r) {
             const int oy = oy0 + r;
             const bool ok = col_ok && oy < d.OH;
-            bf16_t *dst_px = y16 + (((int64_t)img * d.OH + (ok ? oy : 0)) * d.OW + (ok ? ox : 0)) * d.ldy;
+            const unsigned po = ok ? (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2) : OOB;
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) store_rows(pk[r][j], dst_px, ok, n0 + j * 32, d.Nc);
+            for (int j = 0; j < NTB; ++j) store_rows(pk[r][j], yr, po, n0 + j * 32, d.Nc);
         }
         if constexpr (POOL && ROWS == 2) {
-            bf16_t *yp = reinterpret_cast<bf16_t *>(g.y_pool);
             const int PHo = d.OH / 2, PWo = d.OW / 2;
             const int py = oy0 >> 1, pxo = ox >> 1;
             const bool pok = (fj & 1) == 0 && py < PHo && pxo < PWo;
-            bf16_t *dst_px = yp + (((int64_t)img * PHo + (pok ? py : 0)) * PWo + (pok ? pxo : 0)) * d.Nc;
+            const unsigned po = pok ? (unsigned)((((int64_t)img * PHo + py) * PWo + pxo) * d.Nc * 2) : OOB;
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) store_rows(pm[j], dst_px, pok, n0 + j * 32, d.Nc);
+            for (int j = 0; j < NTB; ++j) store_rows(pm[j], pr, po, n0 + j * 32, d.Nc);
         }
         st_tile = -1;
+        return true;
     };
 
     f32x16 acc[ROWS][NTB];
@@ -367,10 +369,17 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         if constexpr (PRE) {
             if ((wv & 1) == 0 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
         }
-        flush_tile();                          // the previous tile's stores: acknowledged under this step's MFMAs
+        // PRE: the frame loads go first -- vmcnt retires in order, so the wait in front of their use (frame_store, at the end of
+        // the step) then leaves the younger stores in flight; nothing else in a PRE step waits for vector memory, the stores of tile
+        // t drain under the steps of tiles t + 1, t + 2
         if constexpr (PRE) {
             if (s + 2 < n_steps) frame_load(t_cur + 2 * g.blocks_per_slice);
-        } else {
+        }
+        // the previous tile's stores, then the next patch's DMA. (The other order with a counted step-closing wait -- `vmcnt(stores)`,
+        // the stores left in flight across the barrier -- was measured in round 4: e21 0.376 -> 0.397 ms, e22 / e31 unchanged; these
+        // layers are paced by the bytes through the CU's memory pipe, not by the wait.)
+        flush_tile();
+        if constexpr (!PRE) {
             int t_nx = t_cur, c_nx = cc + 1;
             if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
             if (s + 1 < n_steps) issue_patch(t_nx, c_nx, (s + 1) & 1);
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             st_tile = t_cur;
         }
         // the next patch has landed (this wave's pieces) and every wave is done reading this one
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (++cc == nchunks) { cc = 0; t_cur += g.blocks_per_slice; }
     }
@@ -499,7 +508,8 @@ bool conv16_applicable(const ConvDesc &d) {
            (d.C == 32 || d.C == 64) && d.Nc % 32 == 0 && !d.res && d.out_mode == OUT_ROWS && d.ldx % 8 == 0 && d.ldy % 8 == 0 &&
            (d.act == ACT_RELU || d.act == ACT_NONE) &&
            (d.pre_frames || ((uintptr_t)d.x) % 16 == 0) && ((uintptr_t)d.y) % 16 == 0 && d.OW >= 1 && d.OH >= 1 &&
-           (int64_t)(d.H) * d.W * d.ldx * 2 < ((int64_t)1 << 31);
+           (int64_t)(d.H) * d.W * d.ldx * 2 < ((int64_t)1 << 31) &&
+           (int64_t)d.NI * d.OH * d.OW * d.ldy * 2 < ((int64_t)1 << 32) - 16;      // outputs addressed through a 32-bit buffer offset
 }
 void conv16_pack_host(const float *w_oihw, int cout, int cin, bf16_t *out) {
     const int ntb = conv16_ntb(cout), nsl = (cout + ntb * 32 - 1) / (ntb * 32), ncc = cin / 32;
