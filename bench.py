@@ -44,11 +44,15 @@ H, W = 260, 346
 PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, summarised per kernel family (first existing file wins)
-PMC_TRAFFIC = {"C2": ("r3_C2_pmc_traffic.json", "r2_pmc_traffic.json"), "C5": ("r3_C5_pmc_traffic.json",)}
+PMC_TRAFFIC = {"C2": ("r4_C2_pmc_traffic.json", "r3_C2_pmc_traffic.json", "r2_pmc_traffic.json"), "C5": ("r4_C5_pmc_traffic.json", "r3_C5_pmc_traffic.json")}
 
 CONFIGS = {
     "C2": dict(streams=64, windows=5, epw=60_000, sensor=(260, 346), vit="tiny", dtype="f32", model="composite"),
-    "C3": dict(streams=256, windows=10, epw=200_000, sensor=(480, 640), vit="base", dtype="bf16", model="composite"),
+    # C3 runs the velocity model on a second HIP stream (evfly_amd/pipeline.py): with the ViT-base trunk in bf16 it is a third of the
+    # step and made of launches that leave most of the chip idle (90.7 -> 79.2 ms per step). C2 / C4 do not: the fp32 Winograd
+    # kernels hold every CU's LDS, the gain is 1-2 % (21.4 -> 21.0 / 115.0 -> 113.3 ms) and kernels of two streams sharing the chip
+    # stretch the HIP-event durations the roofline is computed from (--overlap / --no-overlap override)
+    "C3": dict(streams=256, windows=10, epw=200_000, sensor=(480, 640), vit="base", dtype="bf16", model="composite", overlap=True),
     "C4": dict(streams=256, windows=5, epw=60_000, sensor=(260, 346), vit="base", dtype="f32", model="composite"),
     "C5": dict(streams=20, windows=16, epw=60_000, sensor=(260, 346), vit="tiny", dtype="bf16", model="unet"),
 }
@@ -69,7 +73,9 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x3 pass (C2 only)")
     ap.add_argument("--no-other-configs", action="store_true", help="default C2 run: skip the compact C5 / C3 / C4 objects")
     ap.add_argument("--no-overlap", action="store_true", help="run the velocity model back to back behind the depth model on one "
-                    "stream (the composite call) instead of on a second stream under the next step's depth model")
+                    "stream (the composite call) even where the config's default is the two-stream pipeline (C3)")
+    ap.add_argument("--overlap", action="store_true", help="velocity model of step i on a second HIP stream under the depth model "
+                    "of step i + 1 (evfly_amd/pipeline.py) for every composite config")
     ap.add_argument("--no-stage-rates", action="store_true", help="skip the V / D / P-only timings")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     a = ap.parse_args()
@@ -229,7 +235,8 @@ def compact(o, wall_s):
     r = o.get("roofline", {})
     c = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "step_ms": o.get("step_ms"), "dtype": o["dtype"],
          "steps": o["steps"], "warmup": o["warmup"], "workload": o["config"]["workload"],
-         "roofline": {k: r.get(k) for k in ("kernel", "bound", "frac", "frac_useful", "achieved", "peak", "unit", "launches", "avg_launch_ms")},
+         "roofline": {k: r.get(k) for k in ("kernel", "bound", "frac", "frac_useful", "achieved", "peak", "unit", "launches", "avg_launch_ms", "one_stream")},
+         "pipeline": o.get("pipeline"),
          "step_mfma_util": o.get("step_mfma_util"),
          "top_kernels": [{k: q[k] for k in ("name", "ms_per_step", "tflops")} for q in o.get("kernels", [])[:6]],
          "stages": {k: o.get("stages", {}).get(k) for k in ("voxelize_ms", "condition_ms", "model_ms")},
@@ -264,7 +271,7 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
     # step i + 1 -- the same kernels and bits as the back-to-back composite call, the small launches filling the large ones' gaps.
     # The timed region still closes with a device-wide synchronize: all K steps' velocities are in pinned host memory inside it.
     pipe = None
-    if composite and not a.no_overlap:
+    if composite and not a.no_overlap and (a.overlap or cfg.get("overlap")):
         from evfly_amd.pipeline import StreamPipeline
         pipe = StreamPipeline(model)
     hips = [pipe.unet.hip(), pipe.vit.hip()] if pipe else [model.hip()]
@@ -328,6 +335,28 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         dt = time.perf_counter() - t0
         L.evfly_model_set_profiling(hip.h, 0)
         L.evfly_model_set_profile_filter(hip.h, None)
+    one_stream = None
+    if pipe:
+        # the same steps on ONE stream, outside the timed region: in the timed region kernels of the two streams share the chip, which
+        # stretches the HIP-event durations of the dominant family; this pass times the family alone (3 steps)
+        def step_serial():
+            voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi)
+            x = voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W))
+            depth, _, _ = pipe.unet.forward_streams(x, None, B, T)
+            vel, _ = pipe.vit._run([depth, desvel, None], B, T, clip2x=1)
+            return publish(vel)
+        timed_rec = hip.profile()
+        with torch.no_grad():
+            step_serial(); sync()
+            L.evfly_model_profile_reset(hip.h)
+            L.evfly_model_set_profile_filter(hip.h, dom_name.encode())
+            L.evfly_model_set_profiling(hip.h, 1)
+            for _ in range(3):
+                step_serial()
+            sync()
+            L.evfly_model_set_profiling(hip.h, 0)
+            L.evfly_model_set_profile_filter(hip.h, None)
+        one_stream = hip.profile()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     step_ms = {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),
                "note": "GPU time between per-step events on the launch stream inside the timed region"}
@@ -385,7 +414,7 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             for k in ("ms", "flops", "bytes", "launches", "exec_flops", "useful_flops"):
                 f[k] += p[k]
         return list(fam.values())
-    timed = hip.profile()                          # dominant family only, bracketed inside the timed region
+    timed = timed_rec if pipe else hip.profile()   # dominant family only, bracketed inside the timed region
     dom = max(families(timed), key=lambda p: p["ms"])
     layers = layers_all                            # every launch site ("family/layer"), from the untimed step
     prof = families(layers)
@@ -423,9 +452,10 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in PMC_TRAFFIC.get(cname, ())) if os.path.exists(q)), None)
         if pmc and cfg == CONFIGS[cname]:
             ks = json.load(open(pmc))["kernels"]
-            # fp32: the 17 Winograd launches; bf16 pipeline: the 3x3 convs run on two kernels (direct conv for C_in <= 64, implicit
-            # GEMM beyond; the GEMM family's count also holds the ViT / velpred convs, a rounding error in bytes)
-            fams = ["wino_conv3x3"] if dtype == "f32" else ["conv16_direct", "igemm16_conv"]
+            # fp32: the 17 Winograd launches; bf16 pipeline: the 3x3 convs run on three kernels (direct conv for C_in <= 64, the
+            # wide-tile implicit GEMM for the deep layers, igemm16 for what is left; that family's count also holds the ViT / velpred
+            # convs, a rounding error in bytes)
+            fams = ["wino_conv3x3"] if dtype == "f32" else ["conv16_direct", "conv16w_deep", "igemm16_conv"]
             gs = [ks[f] for f in fams if f in ks]
             g = None
             if gs:
@@ -462,6 +492,14 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4)}
+        if one_stream and dom["flops"]:
+            od = max(families(one_stream), key=lambda p: p["ms"])
+            osec = od["ms"] * 1e-3
+            oex = (od["exec_flops"] or od["flops"]) / osec / 1e12
+            out["roofline"]["one_stream"] = {"achieved": round(oex, 2), "frac": round(oex / peak, 4), "launches": od["launches"],
+                                             "avg_launch_ms": round(od["ms"] / od["launches"], 4),
+                                             "note": "the same family over 3 one-stream steps outside the timed region (no kernels of "
+                                                     "the velocity model beside it)"}
         model_ms = sum(p["ms"] for p in prof)
         # matrix-core utilisation of the WHOLE step: every MFMA kernel's issued flops (one bracketed step) over the timed ms/step
         step_exec = sum((p["exec_flops"] or p["flops"]) for p in prof if p["flops"] and not p["name"].startswith(("vit_attention", "vit_grouped", "lstm_rec", "e11_direct", "unet_out")))

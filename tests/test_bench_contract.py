@@ -1,4 +1,4 @@
-"""The committed bench lines (profiles/r3_C*_bench.json, produced by `python bench.py [--config ..]` on the MI355X box) carry
+"""The committed bench lines (profiles/r4_C*_bench.json, produced by `python bench.py [--config ..]` on the MI355X box) carry
 every field of the bench contract; guards against a refactor of bench.py dropping one."""
 import json
 import os
@@ -11,7 +11,7 @@ def _line(name):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    b = _line("r3_C2_bench.json")
+    b = _line("r4_C2_bench.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "step_mfma_util", "stage_rates"):
         assert k in b, k
@@ -31,11 +31,30 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample", "threads_1", "threads_nproc"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["threads_1"]["cores"] == 1
+    # round 4: the V-stage bytes are the bytes the timed kernel moves (5 B/event + the frames), pass 1 reported beside it
+    st = b["stages"]
+    assert abs(st["voxelize_bytes_moved"] - (5.0 * b["config"]["events_per_step_per_gpu"] + 4.0 * 320 * 260 * 346)) < 1
+    assert abs(st["voxelize_frac_of_hbm_peak"] - st["voxelize_bytes_moved"] / (st["voxelize_ms"] * 1e-3) / 8e12) < 2e-3
+    assert st["voxelize_with_pass1_ms"] > st["voxelize_ms"] and st["voxelize_with_pass1_bytes"] > st["voxelize_bytes_moved"]
+    assert b["step_ms"]["min"] <= b["step_ms"]["median"] <= b["step_ms"]["max"]
+
+
+def test_default_line_carries_the_other_baseline_configs():
+    """The driver runs `python bench.py` (C2): BASELINE.json's C5 / C3 / C4 ride on the same line as compact objects."""
+    oc = _line("r4_C2_bench.json")["other_configs"]
+    assert set(oc) == {"C5", "C3", "C4"}
+    for name, dtype, frames in (("C5", "bf16", 320), ("C3", "bf16", 2560), ("C4", "f32", 1280)):
+        o = oc[name]
+        assert "error" not in o and o["dtype"] == dtype and o["workload"].startswith(name + ":")
+        assert abs(o["value"] - frames * 1e3 / o["ms_per_step"]) < 1e-2 * o["value"]
+        r = o["roofline"]
+        assert r["kernel"] == "conv3x3" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["avg_launch_ms"] > 0
+    assert oc["C3"]["pipeline"].startswith("two HIP streams") and oc["C3"]["roofline"]["one_stream"]["frac"] > oc["C3"]["roofline"]["frac"]
 
 
 def test_committed_lines_of_the_other_baseline_configs():
     """BASELINE.json configs[2..4] have a driver-form line each (C3 bf16 ViT-base at 480x640, C4 shard, C5 ConvLSTM seq-16)."""
-    c3, c4, c5 = _line("r3_C3_bench.json"), _line("r3_C4_bench.json"), _line("r3_C5_bench.json")
+    c3, c4, c5 = _line("r4_C3_bench.json"), _line("r4_C4_bench.json"), _line("r4_C5_bench.json")
     assert c3["dtype"] == "bf16" and c3["config"]["sensor"] == [480, 640] and c3["config"]["vit_trunk"] == "base" and c3["config"]["streams_per_gpu"] == 256
     assert abs(c3["value"] - 2560 * 1e3 / c3["ms_per_step"]) < 1e-2 * c3["value"]
     assert c4["config"]["streams_per_gpu"] == 256 and c4["config"]["windows"] == 5 and c4["config"]["vit_trunk"] == "base"
