@@ -236,22 +236,27 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             const float *fp = f + pp_f[i];
             // taps 0-7 in lanes 0-31, tap 8 + seven zeros in lanes 32-63: every lane issues the same eight loads (the upper half reads
             // valid neighbours and discards them) -- a divergent if / else runs the two halves one after the other
+            // (the upper half's seven spare k-slots meet zero WEIGHTS in the A operand: whatever finite frame values sit in them
+            // contribute exactly 0, so they are not cleared)
             float v[8];
             v[0] = fp[kh ? 2 * FW + 2 : 0];
             v[1] = fp[1]; v[2] = fp[2]; v[3] = fp[FW]; v[4] = fp[FW + 1]; v[5] = fp[FW + 2]; v[6] = fp[2 * FW]; v[7] = fp[2 * FW + 1];
-#pragma unroll
-            for (int e = 1; e < 8; ++e) v[e] = kh ? 0.f : v[e];
             const uint4 b4 = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
             const f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pwa, *reinterpret_cast<const bf16x8 *>(&b4), pbias16, 0, 0, 0);
-            const bool in = (pp_rc[i] & 0xffff) < hrem && (pp_rc[i] >> 16) < wrem;           // beyond the (virtual) e11 map: zeros
+            // ReLU as a plain select per value; the edge mask (pixels beyond the virtual e11 map are zeros) on the packed pair and only
+            // in tiles that touch the right / bottom edge. (Round 3's nested `in ? (a < 0 ? 0 : a) : 0` made hipcc emit an exec-mask
+            // branch region per value, 150 of them in this kernel. A packed signed-16-bit max on the rounded pair -- 8 instructions
+            // instead of 32 -- was measured too: no faster, and it turns a NaN with the sign bit set into 0.)
             unsigned pkd[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                // (ReLU as a plain select, the edge mask on the packed pair: nested `in ? (a < 0 ? 0 : a) : 0` made hipcc emit an
-                // exec-mask branch region per value -- 150 of them in this kernel)
                 const float x0 = a[2 * k] < 0.f ? 0.f : a[2 * k], x1 = a[2 * k + 1] < 0.f ? 0.f : a[2 * k + 1];
-                const unsigned pp = pack_bf2(x0, x1);
-                pkd[k] = in ? pp : 0u;
+                pkd[k] = pack_bf2(x0, x1);
+            }
+            if (hrem < PH || wrem < PWD) {                                   // wave-uniform: an edge tile
+                const bool in = (pp_rc[i] & 0xffff) < hrem && (pp_rc[i] >> 16) < wrem;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pkd[k] = in ? pkd[k] : 0u;
             }
             // pkd[2 g], pkd[2 g + 1] = channel quad g of this half (channels 8 g + 4 kh .. + 3): the swaps hand every lane 8
             // adjacent channels twice -- lanes < 32: chunks 0 and 2 of the pixel, lanes >= 32: chunks 1 and 3
