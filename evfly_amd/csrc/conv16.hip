@@ -38,6 +38,14 @@ typedef __attribute__((address_space(3))) void lds_void;
                                // first-conv producer, 4 = no frame staging, 8 = no output stores
 #endif
 constexpr int kAbl16 = EVFLY_C16_ABL;
+// ---- phase timeline (developer build: -DEVFLY_C16_TS; tools/conv16_ts.py): every wave of a PRE kernel sums the s_memtime ticks it
+// spends in six phases of its steps; read back with evfly_debug_conv16_ts
+#ifdef EVFLY_C16_TS
+__device__ unsigned long long g_c16_ts[256 * 8 * 8];
+#define C16_TS(i) do { if constexpr (PRE) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_acc[i] += t_ - ts_last; ts_last = t_; } } while (0)
+#else
+#define C16_TS(i) do { } while (0)
+#endif
 constexpr int TW = 32;             // output pixels per tile row = one MFMA pixel tile
 constexpr int PWD = TW + 2;        // patch width
 constexpr int NWAVE = 8;
@@ -301,36 +309,20 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y16, 0, (int)(unsigned)((int64_t)d.NI * d.OH * d.OW * d.ldy * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
         POOL ? reinterpret_cast<bf16_t *>(g.y_pool) : y16, 0, POOL ? (int)(unsigned)((int64_t)d.NI * (d.OH / 2) * (d.OW / 2) * d.Nc * 2) : 0, 0x00020000);
-    auto store_rows = [&](const unsigned (&p)[8], __amdgpu_buffer_rsrc_t rs, unsigned px_off, int nbase, int ncount) {
-        unsigned o[8];
-#pragma unroll
-        for (int grp = 0; grp < 2; ++grp)          // quads (0, 1) and (2, 3)
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(p[(2 * grp) * 2 + w], p[(2 * grp + 1) * 2 + w], false, false);
-                o[grp * 4 + w] = sw[0];          // lanes < 32: own quad 2 grp       | lanes >= 32: partner's quad 2 grp + 1
-                o[grp * 4 + 2 + w] = sw[1];      // lanes < 32: partner's quad 2 grp | lanes >= 32: own quad 2 grp + 1
-            }
-#pragma unroll
-        for (int grp = 0; grp < 2; ++grp) {
-            const int ch = grp * 16 + fh * 8;     // first of this lane's 8 channels inside the 32-channel tile
-            if constexpr (kAbl16 & 8) {           // timing experiment: no output stores (values kept alive)
-                asm volatile("" ::"v"(o[grp * 4]), "v"(o[grp * 4 + 1]), "v"(o[grp * 4 + 2]), "v"(o[grp * 4 + 3]));
-                continue;
-            }
-            const unsigned vo = (px_off != OOB && nbase + ch < ncount) ? px_off + (unsigned)(nbase + ch) * 2u : OOB;
-            const u32x4 v = {o[grp * 4], o[grp * 4 + 1], o[grp * 4 + 2], o[grp * 4 + 3]};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)vo, 0, 0);
-        }
-    };
-    // The finished tile is packed (bias, activation, bf16, pool) behind its MFMAs but STORED at the top of the next step: with one
-    // block per CU nothing else hides the stores' acknowledgement (measured in round 3: 12 k cycles per step for 2.3 k cycles of
-    // MFMAs when the step-closing wait covered them).
-    unsigned pk[ROWS][NTB][8];           // packed bf16 pairs of the tile waiting to be stored: [row][n-tile][r-group 0..3][dword 0..1]
+    // The finished tile is packed (bias, activation, bf16, pool) behind its MFMAs, STAGED (lane swaps, byte offsets) at the top of
+    // the next step and stored during that step: with one block per CU nothing else hides the stores' acknowledgement (round 3:
+    // 12 k cycles per step for 2.3 k cycles of MFMAs when the step-closing wait covered them), and -- PRE, round 4 -- issuing a
+    // tile's six stores back to back held every wave ~2 k of its 9 k cycles per step in the store issue (tools/conv16_ts.py): they
+    // now go one per fragment-loop iteration, between the MFMAs.
+    unsigned pk[ROWS][NTB][8];           // packed bf16 pairs of the finished tile: [row][n-tile][r-group 0..3][dword 0..1]
     unsigned pm[POOL ? NTB : 1][8];
     int st_tile = -1;
-    auto flush_tile = [&]() -> bool {
-        if (st_tile < 0) return false;
+    constexpr int NST_Y = ROWS * NTB * 2, NST = NST_Y + (POOL ? NTB * 2 : 0);     // 16-B stores per lane and tile
+    unsigned st_off[ROWS + 1];           // staged byte offsets of this lane's pixel in the output rows / the pooled map (OOB: none)
+    bool st_pending = false;
+    auto stage_tile = [&]() {
+        st_pending = st_tile >= 0;
+        if (!st_pending) return;
         int img, ty, tx;
         tile_decode(st_tile, img, ty, tx);
         const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
@@ -338,23 +330,48 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int oy = oy0 + r;
-            const bool ok = col_ok && oy < d.OH;
-            const unsigned po = ok ? (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2) : OOB;
-#pragma unroll
-            for (int j = 0; j < NTB; ++j) store_rows(pk[r][j], yr, po, n0 + j * 32, d.Nc);
+            st_off[r] = (col_ok && oy < d.OH) ? (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2) : OOB;
         }
+        st_off[ROWS] = OOB;
         if constexpr (POOL && ROWS == 2) {
             const int PHo = d.OH / 2, PWo = d.OW / 2;
             const int py = oy0 >> 1, pxo = ox >> 1;
             const bool pok = (fj & 1) == 0 && py < PHo && pxo < PWo;
-            const unsigned po = pok ? (unsigned)((((int64_t)img * PHo + py) * PWo + pxo) * d.Nc * 2) : OOB;
-#pragma unroll
-            for (int j = 0; j < NTB; ++j) store_rows(pm[j], pr, po, n0 + j * 32, d.Nc);
+            st_off[ROWS] = pok ? (unsigned)((((int64_t)img * PHo + py) * PWo + pxo) * d.Nc * 2) : OOB;
         }
         st_tile = -1;
-        return true;
+    };
+    // store k of the staged tile: k = (row * NTB + n-tile) * 2 + group for the output map, NST_Y + n-tile * 2 + group for the pool.
+    // Lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: the swaps of group g hand lane l channels
+    // 16 g .. 16 g + 7 and lane l + 32 channels 16 g + 8 .. 16 g + 15 (16 B each)
+    auto issue_stores = [&](int k0, int k1) {          // (compile-time range after unrolling)
+        if (!st_pending) return;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            if (k < k0 || k >= k1) continue;
+            const bool pool = k >= NST_Y;
+            const int kk = pool ? k - NST_Y : k, grp = kk & 1, j = (kk >> 1) % NTB, r = (kk >> 1) / NTB;
+            const unsigned(&p)[8] = pool ? pm[POOL ? j : 0] : pk[r][j];
+            unsigned o[4];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(p[(2 * grp) * 2 + w], p[(2 * grp + 1) * 2 + w], false, false);
+                o[w] = sw[0]; o[2 + w] = sw[1];
+            }
+            if constexpr (kAbl16 & 8) { asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }      // timing experiment: no stores
+            const unsigned px_off = st_off[pool ? ROWS : r];
+            const int nb = n0 + j * 32 + grp * 16 + fh * 8;
+            const unsigned vo = (px_off != OOB && nb < d.Nc) ? px_off + (unsigned)nb * 2u : OOB;
+            const u32x4 v = {o[0], o[1], o[2], o[3]};
+            if (pool) __builtin_amdgcn_raw_buffer_store_b128(v, pr, (int)vo, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)vo, 0, 0);
+        }
     };
 
+#ifdef EVFLY_C16_TS
+    unsigned long long ts_acc[8] = {}, ts_last = 0;
+    if constexpr (PRE) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_last) :: "memory");
+#endif
     f32x16 acc[ROWS][NTB];
     // bias of this lane's channels n = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): the accumulators START from it (one
     // v_mov per value instead of a v_mov 0 and an add behind the MFMAs)
@@ -374,6 +391,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         if constexpr (PRE) {
             if ((wv & 1) == 0 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
         }
+        C16_TS(0);                             // 0: even waves' producer
         // PRE: the frame loads go first -- vmcnt retires in order, so the wait in front of their use (frame_store, at the end of
         // the step) then leaves the younger stores in flight; nothing else in a PRE step waits for vector memory, the stores of tile
         // t drain under the steps of tiles t + 1, t + 2
@@ -383,12 +401,14 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         // the previous tile's stores, then the next patch's DMA. (The other order with a counted step-closing wait -- `vmcnt(stores)`,
         // the stores left in flight across the barrier -- was measured in round 4: e21 0.376 -> 0.397 ms, e22 / e31 unchanged; these
         // layers are paced by the bytes through the CU's memory pipe, not by the wait.)
-        flush_tile();
+        stage_tile();
         if constexpr (!PRE) {
+            issue_stores(0, NST);
             int t_nx = t_cur, c_nx = cc + 1;
             if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
             if (s + 1 < n_steps) issue_patch(t_nx, c_nx, (s + 1) & 1);
         }
+        C16_TS(1);                             // 1: frame loads issued, previous tile's stores issued
         const unsigned char *pb = smem + (s & 1) * PATCH_BYTES;
         const unsigned char *wc = wl + (size_t)cc * 18 * NTB * 1024;
         if (cc == 0) {
@@ -431,13 +451,21 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                     for (int j = 0; j < NTB; ++j)
                         acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[it & 1][ky][j], pxq[it & 1][r + ky], acc[r][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PRE) {                   // this iteration's share of the previous tile's stores
+                constexpr int PER = (NST + 5) / 6;
+                issue_stores(it * PER, (it + 1) * PER < NST ? (it + 1) * PER : NST);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        C16_TS(2);                             // 2: fragment loop (36 MFMAs issued)
         if constexpr (PRE) {
             if ((wv & 1) == 1 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
+            C16_TS(3);                         // 3: odd waves' producer
             if (s + 2 < n_steps) frame_store(s & 1);
+            C16_TS(4);                         // 4: frame store (waits for the frame loads)
         }
         if (cc == nchunks - 1) {
-            // ---- the tile's results, packed straight from the accumulators (stored by flush_tile)
+            // ---- the tile's results, packed straight from the accumulators (staged and stored during the next step)
             const bool relu = d.act == ACT_RELU;        // (conv16_applicable admits ACT_RELU / ACT_NONE only)
 #pragma unroll
             for (int j = 0; j < NTB; ++j)
@@ -475,12 +503,34 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             st_tile = t_cur;
         }
         // the next patch has landed (this wave's pieces) and every wave is done reading this one
+        C16_TS(5);                             // 5: pack / pool
         if constexpr (!PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        C16_TS(6);                             // 6: step barrier
         if (++cc == nchunks) { cc = 0; t_cur += g.blocks_per_slice; }
     }
-    flush_tile();
+    stage_tile();
+    issue_stores(0, NST);
+#ifdef EVFLY_C16_TS
+    if constexpr (PRE) {
+        if (lane == 0 && blockIdx.x < 256) {
+            ts_acc[7] = (unsigned long long)n_steps;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g_c16_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_acc[i];
+        }
+    }
+#endif
 }
+
+#ifdef EVFLY_C16_TS
+}  // namespace
+}  // namespace evfly
+extern "C" int evfly_debug_conv16_ts(unsigned long long *out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evfly::g_c16_ts), n * sizeof(unsigned long long));
+}
+namespace evfly {
+namespace {
+#endif
 
 template <int ROWS, int NTB, bool POOL, bool PRE>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
