@@ -42,7 +42,7 @@ constexpr int kAbl16 = EVFLY_C16_ABL;
 // spends in six phases of its steps; read back with evfly_debug_conv16_ts
 #ifdef EVFLY_C16_TS
 __device__ unsigned long long g_c16_ts[256 * 8 * 8];
-#define C16_TS(i) do { if constexpr (PRE) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_acc[i] += t_ - ts_last; ts_last = t_; } } while (0)
+#define C16_TS(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_acc[i] += t_ - ts_last; ts_last = t_; } while (0)
 #else
 #define C16_TS(i) do { } while (0)
 #endif
@@ -318,6 +318,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     unsigned pm[POOL ? NTB : 1][8];
     int st_tile = -1;
     constexpr int NST_Y = ROWS * NTB * 2, NST = NST_Y + (POOL ? NTB * 2 : 0);     // 16-B stores per lane and tile
+    // SPREAD: the previous tile's stores are issued one or two per fragment-loop iteration instead of in one burst at the top of the
+    // step (a burst held every wave ~2 k (e12) .. 4.4 k (e21) cycles in the store issue, tools/conv16_ts*.py). Measured per variant in the
+    // C5 step: e12 0.91 -> 0.86 ms, e21 0.379 -> 0.348, e31 0.265 -> 0.259 -- but e22 (two chunks, pool: 12 stores) 0.575 -> 0.68 and the
+    // one-tile variants unchanged, so only the fused-first-conv variant and the two-tile variants without pool spread
+    constexpr bool SPREAD = PRE || (NTB == 2 && !POOL);
     unsigned st_off[ROWS + 1];           // staged byte offsets of this lane's pixel in the output rows / the pooled map (OOB: none)
     bool st_pending = false;
     auto stage_tile = [&]() {
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 
 #ifdef EVFLY_C16_TS
     unsigned long long ts_acc[8] = {}, ts_last = 0;
-    if constexpr (PRE) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_last) :: "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_last) :: "memory");
 #endif
     f32x16 acc[ROWS][NTB];
     // bias of this lane's channels n = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): the accumulators START from it (one
@@ -398,12 +403,9 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         if constexpr (PRE) {
             if (s + 2 < n_steps) frame_load(t_cur + 2 * g.blocks_per_slice);
         }
-        // the previous tile's stores, then the next patch's DMA. (The other order with a counted step-closing wait -- `vmcnt(stores)`,
-        // the stores left in flight across the barrier -- was measured in round 4: e21 0.376 -> 0.397 ms, e22 / e31 unchanged; these
-        // layers are paced by the bytes through the CU's memory pipe, not by the wait.)
         stage_tile();
-        if constexpr (!PRE) {
-            issue_stores(0, NST);
+        if constexpr (!SPREAD) issue_stores(0, NST);
+        if constexpr (!PRE) {                  // (SPREAD: the DMA first -- the step-closing wait is for it, the stores behind it are counted)
             int t_nx = t_cur, c_nx = cc + 1;
             if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
             if (s + 1 < n_steps) issue_patch(t_nx, c_nx, (s + 1) & 1);
@@ -451,9 +453,9 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                     for (int j = 0; j < NTB; ++j)
                         acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[it & 1][ky][j], pxq[it & 1][r + ky], acc[r][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PRE) {                   // this iteration's share of the previous tile's stores
+            if constexpr (SPREAD) {                // this iteration's share of the previous tile's stores
                 constexpr int PER = (NST + 5) / 6;
-                issue_stores(it * PER, (it + 1) * PER < NST ? (it + 1) * PER : NST);
+                issue_stores(it * PER < NST ? it * PER : NST, (it + 1) * PER < NST ? (it + 1) * PER : NST);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -504,7 +506,12 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         }
         // the next patch has landed (this wave's pieces) and every wave is done reading this one
         C16_TS(5);                             // 5: pack / pool
-        if constexpr (!PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!PRE) {
+            // the next patch has landed: its DMA pieces are older than the NST stores issued behind them in this step (vmcnt retires
+            // in order), which stay in flight across the barrier and drain under the next step
+            if (SPREAD && st_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         C16_TS(6);                             // 6: step barrier
         if (++cc == nchunks) { cc = 0; t_cur += g.blocks_per_slice; }
@@ -512,12 +519,10 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     stage_tile();
     issue_stores(0, NST);
 #ifdef EVFLY_C16_TS
-    if constexpr (PRE) {
-        if (lane == 0 && blockIdx.x < 256) {
-            ts_acc[7] = (unsigned long long)n_steps;
+    if (lane == 0 && blockIdx.x < 256) {
+        ts_acc[7] = (unsigned long long)n_steps;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) g_c16_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_acc[i];
-        }
+        for (int i = 0; i < 8; ++i) g_c16_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_acc[i];
     }
 #endif
 }
