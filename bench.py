@@ -504,6 +504,9 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         # matrix-core utilisation of the WHOLE step: every MFMA kernel's issued flops (one bracketed step) over the timed ms/step
         step_exec = sum((p["exec_flops"] or p["flops"]) for p in prof if p["flops"] and not p["name"].startswith(("vit_attention", "vit_grouped", "lstm_rec", "e11_direct", "unet_out")))
         out["step_mfma_util"] = round(step_exec / (ms_per_step * 1e-3) / 1e12 / peak, 4)      # (this rank's kernels over the step time)
+        # the same on USEFUL flops (Winograd tile padding not counted): what the north star's ">= 60 % MFMA utilisation" reads on
+        step_useful = sum((p["useful_flops"] or p["exec_flops"] or p["flops"]) for p in prof if p["flops"] and not p["name"].startswith(("vit_attention", "vit_grouped", "lstm_rec", "e11_direct", "unet_out")))
+        out["step_mfma_util_useful"] = round(step_useful / (ms_per_step * 1e-3) / 1e12 / peak, 4)
         out["breakdown_note"] = ("kernels / conv_layers / stages.model_ms: one untimed step with every launch bracketed by HIP "
                                  "events; roofline: the dominant family bracketed inside the timed region")
         out["kernels"] = [{"name": p["name"], "ms_per_step": round(p["ms"], 3), "launches_per_step": p["launches"],
