@@ -133,6 +133,14 @@ void wino_skip_grid(const ConvDesc &d, SkipGrid *g);
 // kernel launches wino_launch(d) issues: 1, or 2 with a split plan
 int wino_launch_count(const ConvDesc &d);
 
+// Winograd F(4x4,3x3) prototype (wino4.hip; EVFLY_WINO4=1 routes evfly_op_conv2d_nhwc to it): plain layers only (no fused pool /
+// skip / 1x1 consumer / first conv), C % 8 == 0, Nc % 32 == 0; U = G g G^T in its own layout (wino4_u_floats floats)
+size_t wino4_u_floats(int cout, int cin);
+void wino4_pack_host(const float *w_oihw, int cout, int cin, float *U);
+int wino4_pack_device(const float *w, int cout, int cin, int64_t sn, int64_t sc, int64_t st, float *U, hipStream_t stream);
+bool wino4_applicable(const ConvDesc &d);
+int wino4_launch(const ConvDesc &d, const float *U, hipStream_t st);
+
 // algorithmic work of one launch (for the profile / roofline accounting)
 inline double igemm_flops(const ConvDesc &d) { return 2.0 * (double)d.M * d.Nc * d.K; }
 

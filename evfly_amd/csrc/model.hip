@@ -1365,6 +1365,13 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
         d.w = static_cast<const float *>(scr);
     }
     d.ldw = ld; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
+    static const bool use_w4 = getenv("EVFLY_WINO4") && atoi(getenv("EVFLY_WINO4")) == 1;
+    if (use_w4 && wino4_applicable(d)) {      // F(4x4,3x3) prototype (tools / tests)
+        void *u = nullptr;
+        if (int rc = scratch_get(wino4_u_floats(cout, cin) * 4, &u, as_stream(stream), 2)) return rc;
+        if (int rc = wino4_pack_device(w_packed, cout, cin, (int64_t)9 * cin, 1, cin, static_cast<float *>(u), as_stream(stream))) return rc;
+        return wino4_launch(d, static_cast<const float *>(u), as_stream(stream));
+    }
     if (wino_applicable(d) && !(getenv("EVFLY_WINO_OP") && atoi(getenv("EVFLY_WINO_OP")) == 0)) {
         void *u = nullptr;
         if (int rc = scratch_get(wino_u_floats(cout, cin) * 4, &u, as_stream(stream), 2)) return rc;

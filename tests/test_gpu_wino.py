@@ -60,6 +60,30 @@ def test_wino_forced_block_variant(gpu_device, mt):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
+SHAPES4 = [  # n, h, w, cin, cout -- the F(4x4,3x3) prototype (EVFLY_WINO4=1): plain layers, C_in % 8 == 0, C_out % 32 == 0
+    (2, 18, 34, 8, 32),       # exactly one 4 x 8-tile block per image, one chunk
+    (3, 22, 38, 16, 32),      # ragged right / bottom tiles, two chunks
+    (5, 10, 15, 64, 64),      # e52-like: 2 x 4 tiles per image, several images per block, two channel slices
+    (2, 27, 37, 128, 64),     # e41-like geometry
+    (7, 6, 6, 32, 32),        # one tile per image: eight images per block (one block ragged in images)
+    (1, 40, 60, 32, 96),      # three channel slices
+    (4, 14, 24, 256, 32),     # d12-like: long K
+]
+
+
+def test_wino4_prototype(gpu_device):
+    """k_wino4 (wino4.hip) through evfly_op_conv2d_nhwc with EVFLY_WINO4=1 (read once per process: subprocess) against F.conv2d:
+    F(4x4,3x3) in fp32 carries ~16x the rounding of F(2x2) (tools/wino_f4_error.py: 4-6e-6 per layer), bar 2e-5."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_wino as t\n"
+            "for s in t.SHAPES4: t._check(s)\n"
+            "for s in t.SHAPES[:1] + t.SHAPES[3:]: t._check(s)\n"
+            "print('ok')\n") % (REPO, os.path.join(REPO, "tests"))
+    env = dict(os.environ, EVFLY_WINO4="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-3000:])
+
+
 def test_wino_nan_and_inf_propagate(gpu_device):
     """A NaN / Inf input pixel reaches exactly the outputs whose 3x3 window (or whose Winograd tile) contains it and
     never leaks further than one tile; finite regions stay exact."""
