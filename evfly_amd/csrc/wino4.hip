@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace evfly {
@@ -52,7 +53,67 @@ __device__ __forceinline__ int key4(const W4Geom &g, int s, int y, int x) {
     return (((x >> 2) & (g.TX - 1)) + (((y >> 2) & (g.TY - 1)) << g.lgTX) + (s << (g.lgTX + g.lgTY))) & 15;
 }
 
+// One 8-channel chunk of position row A: t[c] = row A of B^T d for this lane's tile and four channels (the LAST source row has
+// coefficient 1: it seeds the accumulation), then the six column combinations with their common sub-expressions, each feeding the
+// four channel-pair MFMAs of its position.
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+template <int PP, int A>
+__device__ __forceinline__ void w4_chunk(const unsigned char *pbuf, const int (&fb)[6], int ykx, const float *uc, f32x16 (&acc)[6]) {
+    constexpr int RS = PP * 32;                               // bytes per patch row
+    constexpr int NR = (A == 0 || A == 5) ? 3 : 4;
+    constexpr int R0 = A == 0 ? 0 : 1, R1 = A == 0 ? 2 : (A == 5 ? 3 : 2), R2 = A == 0 ? 4 : (A == 5 ? 5 : 3), R3 = 4;
+    constexpr float C0 = A == 0 ? 4.f : A == 1 ? -4.f : A == 2 ? 4.f : A == 3 ? -2.f : A == 4 ? 2.f : 4.f;
+    constexpr float C1 = A == 0 ? -5.f : A == 1 ? -4.f : A == 2 ? -4.f : A == 3 ? -1.f : A == 4 ? -1.f : -5.f;
+    constexpr float C2 = A == 1 ? 1.f : A == 2 ? -1.f : A == 3 ? 2.f : A == 4 ? -2.f : 1.f;      // (A = 0, 5: the seeding row)
+    auto ld = [&](int c, int r) -> f32x4 {                    // patch pixel (4 ty + r, 4 tx + c), this lane's four channels
+        const int off = (r >> 2) ? (fb[c] ^ ykx) : fb[c];
+        return *reinterpret_cast<const f32x4 *>(pbuf + off + r * RS);
+    };
+    f32x4 t[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        if constexpr (NR == 3) {
+            const f32x4 a0 = ld(c, R0), a1 = ld(c, R1);
+            f32x4 tt = ld(c, R2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = fmaf(C1, a1[k], fmaf(C0, a0[k], tt[k]));
+            t[c] = tt;
+        } else {
+            const f32x4 a0 = ld(c, R0), a1 = ld(c, R1), a2 = ld(c, R2);
+            f32x4 tt = ld(c, R3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = fmaf(C2, a2[k], fmaf(C1, a1[k], fmaf(C0, a0[k], tt[k])));
+            t[c] = tt;
+        }
+        // (bounds the fragment loads in flight to two columns' worth: left alone hipcc requests all 24 up front -- 96 registers on
+        // top of 96 accumulators -- and spills inside the loop)
+        if (c & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // the six column combinations, one position at a time (its four values live only until its four MFMAs)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const f32x4 u = *reinterpret_cast<const f32x4 *>(uc + b * 256);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t0 = t[0][k], t1 = t[1][k], t2 = t[2][k], t3 = t[3][k], t4 = t[4][k], t5 = t[5][k];
+            float r;
+            if (b == 0) r = fmaf(4.f, t0, fmaf(-5.f, t2, t4));
+            else if (b == 1) r = fmaf(-4.f, t1, fmaf(-4.f, t2, t3 + t4));
+            else if (b == 2) r = fmaf(4.f, t1, fmaf(-4.f, t2, t4 - t3));
+            else if (b == 3) r = fmaf(-2.f, t1, fmaf(2.f, t3, t4 - t2));
+            else if (b == 4) r = fmaf(2.f, t1, fmaf(-2.f, t3, t4 - t2));
+            else r = fmaf(4.f, t1, fmaf(-5.f, t3, t5));
+            v[k] = r;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[b], 0, 0, 0);
+    }
+}
+
+template <int LGTX>
 __global__ __launch_bounds__(384) void k_wino4(ConvDesc d, const float *__restrict__ U, W4Geom g) {
+    constexpr int PP = ((4 << LGTX) + 2 + 7) / 8 * 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,24 +177,8 @@ __global__ __launch_bounds__(384) void k_wino4(ConvDesc d, const float *__restri
     int ykey[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) ykey[e] = (((((lty + e) & (g.TY - 1)) << g.lgTX) + (ls << (g.lgTX + g.lgTY))) & 15) << 4;
-
-    // ---- row a of B^T: up to four source rows with their coefficients (wave-uniform)
-    //  a = 0: 4 d0 - 5 d2 + d4      a = 1: -4 d1 - 4 d2 + d3 + d4      a = 2: 4 d1 - 4 d2 - d3 + d4
-    //  a = 3: -2 d1 - d2 + 2 d3 + d4   a = 4: 2 d1 - d2 - 2 d3 + d4    a = 5: 4 d1 - 5 d3 + d5
-    int rrow[4];
-    float rco[4];
-    {
-        static const int R[6][4] = {{0, 2, 4, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 5}};
-        static const float Cf[6][4] = {{4, -5, 1, 0}, {-4, -4, 1, 1}, {4, -4, -1, 1}, {-2, -1, 2, 1}, {2, -1, -2, 1}, {4, -5, 1, 0}};
-        // (tables indexed by the wave id: scalar selects)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int rr = 0; float cc = 0.f;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) { rr = wv == a ? R[a][e] : rr; cc = wv == a ? Cf[a][e] : cc; }
-            rrow[e] = rr; rco[e] = cc;
-        }
-    }
+    for (int c = 0; c < 6; ++c) fbase[c] ^= ykey[0];           // rows 0..3; rows 4, 5 XOR ykey[0] ^ ykey[1] on top
 
     // ---- U stream of this wave: 16 B per lane and (chunk, b)
     const float *ub = U + ((size_t)slice * g.nchunk * 36 + (size_t)wv * 6) * 256 + (size_t)(h * 32 + ti) * 4;     // + chunk * 36 * 256 + b * 256
@@ -147,61 +192,35 @@ __global__ __launch_bounds__(384) void k_wino4(ConvDesc d, const float *__restri
     issue_patch(0, 0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    for (int chunk = 0; chunk < g.nchunk; ++chunk) {
-        const int buf = chunk & 1;
-        if (chunk + 1 < g.nchunk) issue_patch(chunk + 1, buf ^ 1);
-        const unsigned char *pbuf = smem + buf * g.buf_bytes;
-        // t[c] = sum_e rco[e] * d[rrow[e]][c]     (4 channels per lane)
-        f32x4 t[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) t[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = rrow[e];
-            const int roff = r * g.PP * 32, yk = ykey[r >> 2];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(pbuf + roff + (fbase[c] ^ yk));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[c][k] = fmaf(rco[e], v[k], t[c][k]);
-            }
+    // the K loop, one copy per position row (the rows and coefficients of B^T row a are compile-time; every copy executes the same
+    // barriers)
+    auto k_loop = [&](auto role) {
+        constexpr int A = decltype(role)::value;
+        for (int chunk = 0; chunk < g.nchunk; ++chunk) {
+            const int buf = chunk & 1;
+            if (chunk + 1 < g.nchunk) issue_patch(chunk + 1, buf ^ 1);
+            w4_chunk<PP, A>(smem + buf * g.buf_bytes, fbase, ykey[0] ^ ykey[1], ub + (size_t)chunk * 36 * 256, acc);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        // V[b] = sum_c t[c] * B[c][b], one b at a time, each feeding the four channel pairs' MFMAs
-        const float *uc = ub + (size_t)chunk * 36 * 256;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const f32x4 u = *reinterpret_cast<const f32x4 *>(uc + b * 256);
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float t0 = t[0][k], t1 = t[1][k], t2 = t[2][k], t3 = t[3][k], t4 = t[4][k], t5 = t[5][k];
-                float r;
-                if (b == 0) r = fmaf(4.f, t0, fmaf(-5.f, t2, t4));
-                else if (b == 1) r = fmaf(-4.f, t1, fmaf(-4.f, t2, t3 + t4));
-                else if (b == 2) r = fmaf(4.f, t1, fmaf(-4.f, t2, t4 - t3));
-                else if (b == 3) r = fmaf(-2.f, t1, fmaf(2.f, t3, t4 - t2));
-                else if (b == 4) r = fmaf(2.f, t1, fmaf(-2.f, t3, t4 - t2));
-                else r = fmaf(4.f, t1, fmaf(-5.f, t3, t5));
-                v[k] = r;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[b], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    switch (wv) {
+        case 0: k_loop(std::integral_constant<int, 0>{}); break;
+        case 1: k_loop(std::integral_constant<int, 1>{}); break;
+        case 2: k_loop(std::integral_constant<int, 2>{}); break;
+        case 3: k_loop(std::integral_constant<int, 3>{}); break;
+        case 4: k_loop(std::integral_constant<int, 4>{}); break;
+        default: k_loop(std::integral_constant<int, 5>{}); break;
     }
 
-    // ---- output transform along b (in registers): Z[j] = sum_b M[b] * A[b][j]
+    // ---- output transform along b (in registers, one column j per exchange round below): Z[j] = sum_b M[b] * A[b][j]
     //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-    f32x16 z[4];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-        z[0][r] = m0 + s12 + s34;
-        z[1][r] = fmaf(2.f, d34, d12);
-        z[2][r] = fmaf(4.f, s34, s12);
-        z[3][r] = fmaf(8.f, d34, d12) + m5;
-    }
+    auto zcol = [&](int j, int r) -> float {
+        const float m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r];
+        if (j == 0) return acc[0][r] + (m1 + m2) + (m3 + m4);
+        if (j == 1) return fmaf(2.f, m3 - m4, m1 - m2);
+        if (j == 2) return fmaf(4.f, m3 + m4, m1 + m2);
+        return fmaf(8.f, m3 - m4, m1 - m2) + acc[5][r];
+    };
     // ---- along a through LDS, one output column j per round: plane[a][r][lane]; waves 0..3 finish output row i = wave
     float *xch = reinterpret_cast<float *>(smem);                         // 6 * 16 * 64 floats = 24 KB (every wave passed the loop's last barrier)
     const float bias = (d.bias && n0 + ti < d.Nc) ? d.bias[n0 + ti] : 0.f;
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(384) void k_wino4(ConvDesc d, const float *__restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(wv * 16 + r) * 64 + lane] = z[j][r];
+        for (int r = 0; r < 16; ++r) xch[(wv * 16 + r) * 64 + lane] = zcol(j, r);
         __syncthreads();
         if (wv < 4) {
 #pragma unroll
@@ -345,12 +364,24 @@ int wino4_launch(const ConvDesc &d, const float *U, hipStream_t st) {
     EVFLY_HIP(hipGetDevice(&dev));
     EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
     if (attr_set[dev].load(std::memory_order_acquire) < lds) {
-        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino4), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino4<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino4<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino4<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino4<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         attr_set[dev].store(kMaxLds, std::memory_order_release);
     }
     const int64_t blocks = (int64_t)g.n_slices * g.bx * g.by * g.bi;
     EVFLY_REQUIRE(blocks < ((int64_t)1 << 31), "wino4: grid too large");
-    hipLaunchKernelGGL(k_wino4, dim3((unsigned)blocks), dim3(384), lds, st, d, U, g);
+    switch (g.lgTX) {
+        case 0: hipLaunchKernelGGL(k_wino4<0>, dim3((unsigned)blocks), dim3(384), lds, st, d, U, g); break;
+        case 1: hipLaunchKernelGGL(k_wino4<1>, dim3((unsigned)blocks), dim3(384), lds, st, d, U, g); break;
+        case 2: hipLaunchKernelGGL(k_wino4<2>, dim3((unsigned)blocks), dim3(384), lds, st, d, U, g); break;
+        case 3: hipLaunchKernelGGL(k_wino4<3>, dim3((unsigned)blocks), dim3(384), lds, st, d, U, g); break;
+        case 4: hipLaunchKernelGGL(k_wino4<4>, dim3((unsigned)blocks), dim3(384), lds, st, d, U, g); break;
+        default: hipLaunchKernelGGL(k_wino4<5>, dim3((unsigned)blocks), dim3(384), lds, st, d, U, g); break;
+    }
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
