@@ -295,7 +295,25 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st) {
     if (d.Nc % 128 != 0) return launch16w<512, 64, 8, 1>(d, st);
     // (128-pixel tiles for grids of 1..2 rounds -- e52 at 320 frames is 260 tiles on 256 CUs -- were measured: they stream the
     // weights twice as often per flop and lose on every layer, e52 0.229 -> 0.260 ms, d11 0.247 -> 0.353)
-    return wide ? launch16w<256, 256, 2, 4>(d, st) : launch16w<256, 128, 4, 2>(d, st);
+    if (!wide) return launch16w<256, 128, 4, 2>(d, st);
+    // One block per CU: a grid of n blocks costs ceil(n / 256) rounds, and the deep layers' grids are 1..5 rounds (e52 at 320 frames:
+    // 260 tiles of 256 pixels = two rounds for 1.02 rounds of work). The pixel tile is therefore chosen among 192 / 256 / 320 (3 / 4 / 5
+    // MFMA tiles per wave; 158 / 202 / 242 registers) to minimise rounds x tile pixels x a per-pixel cost factor measured on the U-Net
+    // shapes (a larger tile streams the weights less often per flop): e52 0.225 -> 0.153 ms (320), e42 0.338 -> 0.318 (320), e41
+    // 0.207 -> 0.195 (320), e51 / d12 0.132 / 0.125 -> 0.129 / 0.119 (192), d11 stays at 256.
+    static const int force_bp = getenv("EVFLY_CONV16W_BP") ? atoi(getenv("EVFLY_CONV16W_BP")) : 0;
+    const int nt = d.Nc / 256;
+    auto cost = [&](int bp) {
+        const double per_pixel = bp == 192 ? 1.12 : bp == 320 ? 0.94 : 1.0;
+        return (double)cdiv(cdiv((int)d.M, bp) * nt, kNumCU) * bp * per_pixel;
+    };
+    int bp = 256;
+    if (cost(192) < cost(bp)) bp = 192;
+    if (cost(320) < cost(bp)) bp = 320;
+    if (force_bp == 192 || force_bp == 256 || force_bp == 320) bp = force_bp;
+    if (bp == 192) return launch16w<192, 256, 2, 4>(d, st);
+    if (bp == 320) return launch16w<320, 256, 2, 4>(d, st);
+    return launch16w<256, 256, 2, 4>(d, st);
 }
 
 }  // namespace evfly

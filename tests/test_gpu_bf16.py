@@ -95,6 +95,8 @@ def _assert_bf16_close(got, ref):
     (20, 32, 30, 512, 256, 3, 1, 0, 0, False),   # too few pixel tiles for the 256-channel tile: two 128-channel tiles per pixel tile
     (130, 34, 34, 256, 512, 3, 1, 0, 1, False),  # 256-channel tiles, two per pixel tile
     (60, 40, 40, 128, 64, 3, 1, 0, 1, False),    # d31's channel counts: 512-pixel x 64-channel tiles, ragged last tile
+    (80, 26, 24, 128, 256, 3, 1, 0, 1, False),   # 42 240 pixels: one round either way, the 192-pixel tile is chosen (the e41 / 256 -> 512 cases
+                                                  # above run the 320-pixel one)
 ])
 def test_conv_bf16_pipeline_kernel(gpu_device, case):
     n, h, w, cin, cout, k, stride, pad, act, with_res = case
