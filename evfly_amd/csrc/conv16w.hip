@@ -289,13 +289,19 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st) {
     // 320 frames: d11 0.310 -> 0.246 ms, e51 0.143 -> 0.132, d12 0.133 -> 0.126 against 128-channel tiles, although the grid shrinks
     // to 1.6 blocks per CU)
     static const int force = getenv("EVFLY_CONV16W_BC") ? atoi(getenv("EVFLY_CONV16W_BC")) : 0;
+    static const int alt128 = getenv("EVFLY_CONV16W_ALT128") ? atoi(getenv("EVFLY_CONV16W_ALT128")) : 0;
     bool wide = d.Nc % 256 == 0;
     if (force == 128) wide = false;
-    // 64 output channels (d31): 512 pixels x 64 channels per block, the 256 x 128 tile's operand traffic per flop with half the weights
-    if (d.Nc % 128 != 0) return launch16w<512, 64, 8, 1>(d, st);
+    // 64 output channels (d31)
+    if (d.Nc % 128 != 0 && alt128 == 2) return launch16w<512, 64, 8, 1>(d, st);
+    if (d.Nc % 128 != 0) return launch16w<256, 64, 4, 2>(d, st);      // 80 KB of LDS: two blocks per CU (d31 0.243 -> 0.229 ms against 512 x 64)
     // (128-pixel tiles for grids of 1..2 rounds -- e52 at 320 frames is 260 tiles on 256 CUs -- were measured: they stream the
     // weights twice as often per flop and lose on every layer, e52 0.229 -> 0.260 ms, d11 0.247 -> 0.353)
-    if (!wide) return launch16w<256, 128, 4, 2>(d, st);
+    if (!wide && alt128 == 2) return launch16w<256, 128, 4, 2>(d, st);
+    // 128 output channels: 192 pixels x 128 channels per block (wave tile 96 x 32, 102 registers) = 80 KB of LDS, i.e. TWO blocks per CU
+    // whose prologues, epilogues and DMA waits cover each other: e32 0.554 -> 0.526 ms, d21 0.227 -> 0.216, d22 0.109 -> 0.102 against
+    // the 256 x 128 tile (one block per CU)
+    if (!wide) return launch16w<192, 128, 2, 4>(d, st);
     // One block per CU: a grid of n blocks costs ceil(n / 256) rounds, and the deep layers' grids are 1..5 rounds (e52 at 320 frames:
     // 260 tiles of 256 pixels = two rounds for 1.02 rounds of work). The pixel tile is therefore chosen among 192 / 256 / 320 (3 / 4 / 5
     // MFMA tiles per wave; 158 / 202 / 242 registers) to minimise rounds x tile pixels x a per-pixel cost factor measured on the U-Net
