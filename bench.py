@@ -49,8 +49,8 @@ PMC_TRAFFIC = {"C2": ("r4_C2_pmc_traffic.json", "r3_C2_pmc_traffic.json", "r2_pm
 CONFIGS = {
     "C2": dict(streams=64, windows=5, epw=60_000, sensor=(260, 346), vit="tiny", dtype="f32", model="composite"),
     # C3 runs the velocity model on a second HIP stream (evfly_amd/pipeline.py): with the ViT-base trunk in bf16 it is a third of the
-    # step and made of launches that leave most of the chip idle (90.7 -> 79.2 ms per step). C2 / C4 do not: the fp32 Winograd
-    # kernels hold every CU's LDS, the gain is 1-2 % (21.4 -> 21.0 / 115.0 -> 113.3 ms) and kernels of two streams sharing the chip
+    # step and made of launches that leave most of the chip idle (80.2 -> 76.1 ms per step). C2 / C4 do not: the fp32 Winograd
+    # kernels hold every CU's LDS, the gain is 1-2 % (21.4 -> 21.0 ms at C2) and kernels of two streams sharing the chip
     # stretch the HIP-event durations the roofline is computed from (--overlap / --no-overlap override)
     "C3": dict(streams=256, windows=10, epw=200_000, sensor=(480, 640), vit="base", dtype="bf16", model="composite", overlap=True),
     "C4": dict(streams=256, windows=5, epw=60_000, sensor=(260, 346), vit="base", dtype="f32", model="composite"),

@@ -1187,6 +1187,34 @@ extern "C" int evfly_e2v_forward(evfly_model *m, const float *frames, const floa
     const int per = std::max(1, kChunkFrames / T);
     const int H = m->cfg.input_h, Wd = m->cfg.input_w;
     const int64_t fr = (int64_t)H * Wd;
+    if (depth_out && n_streams > per) {
+        // More than one chunk and the caller takes the depth maps: the depth model runs over all its 320-frame chunks first (depth
+        // lands in the caller's buffer), then the velocity model reads it back in chunks four times as large, like evfly_vit_forward
+        // does -- its launches are small, at 320 frames most of them leave the chip half empty (C4 shard, 1280 frames: 115.5 ->
+        // 113 ms; the per-frame arithmetic is the same)
+        for (int s0 = 0; s0 < n_streams; s0 += per) {
+            const int S = std::min(per, n_streams - s0);
+            const int64_t f0 = (int64_t)s0 * T;
+            auto body = [&]() {
+                float *depth = nullptr;
+                return unet_chunk(m, frames + f0 * fr, S, T, h_state ? h_state + (int64_t)s0 * 104 * 512 : nullptr,
+                                  c_state ? c_state + (int64_t)s0 * 104 * 512 : nullptr, depth_out + f0 * fr,
+                                  upconv_out ? upconv_out + f0 * 68 * 148 : nullptr, &depth);
+            };
+            if (int rc = with_arena(m, body)) return rc;
+        }
+        const int perv = std::max(1, 4 * kChunkFrames / T);
+        for (int s0 = 0; s0 < n_streams; s0 += perv) {
+            const int S = std::min(perv, n_streams - s0);
+            const int64_t f0 = (int64_t)s0 * T;
+            auto body = [&]() {
+                return vit_chunk(m, depth_out + f0 * fr, H, Wd, 1, desvel + f0, nullptr, S, T, lstm_h ? lstm_h + (int64_t)s0 * 384 : nullptr,
+                                 lstm_c ? lstm_c + (int64_t)s0 * 384 : nullptr, vel_out + f0 * 3);
+            };
+            if (int rc = with_arena(m, body)) return rc;
+        }
+        return 0;
+    }
     for (int s0 = 0; s0 < n_streams; s0 += per) {
         const int S = std::min(per, n_streams - s0);
         const int64_t f0 = (int64_t)s0 * T;
