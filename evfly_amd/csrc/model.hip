@@ -1095,7 +1095,10 @@ int check_model(evfly_model *m, void *stream) {
     return 0;
 }
 
-constexpr int kChunkFrames = 320;
+// frames per chunk of the depth model: 640 (the arena is ~32 GB in fp32, of 288). Larger launches lose less to partly empty last
+// rounds: C4 shard 112.4 -> 111.4 ms, C3 75.8 -> 74.1 ms against 320; 1280 gains another 0.7 % at C4 but pushes the bf16 pipeline's
+// full-resolution maps past the 4 GB its kernels address with 32-bit offsets. EVFLY_CHUNK_FRAMES overrides (A/B runs).
+static const int kChunkFrames = getenv("EVFLY_CHUNK_FRAMES") ? std::min(640, std::max(16, atoi(getenv("EVFLY_CHUNK_FRAMES")))) : 640;
 
 }  // namespace
 
