@@ -84,6 +84,7 @@ SIGNATURES = {
     "evfly_op_pool2d_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "evfly_op_velpred_vec": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "evfly_op_grouped_conv_gelu": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "evfly_op_mixffn_block_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "evfly_op_convlstm_gates": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p]),
     "evfly_convlstm_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "evfly_convlstm_forward": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i64, c_p]),

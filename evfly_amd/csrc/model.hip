@@ -493,6 +493,20 @@ int pack_vit(evfly_model *m) {
                               "%sdepthwise.weight: expected (Ce, 8, 3, 3)", F.c_str());
                 gconv_pack_host(dwt->v.data(), (int)dwt->shape[0], m->stage(NL + "dw.wp", dwt->v.size()));
             }
+            if (w16) {   // fused MixFFN of the bf16 pipeline (mixffn16.hip): grouped-conv weights in lane order, two-term bf16 bias of mlp1
+                const HostTensor *dwt = m->find(F + "depthwise.weight", kVitP), *dwb = m->find(F + "depthwise.bias", kVitP),
+                                 *b1 = m->find(F + "mlp1.bias", kVitP);
+                EVFLY_REQUIRE(dwb && b1 && dwb->v.size() == (size_t)dwt->shape[0] && b1->v.size() == (size_t)dwt->shape[0] && dwt->shape[0] % 32 == 0,
+                              "%s: MixFFN biases do not match the hidden width", F.c_str());
+                const int Ce = (int)dwt->shape[0];
+                std::vector<float> wp(dwt->v.size());
+                gconv_pack_host(dwt->v.data(), Ce, wp.data());
+                std::vector<unsigned char> rec(mixffn16_rec_bytes(Ce), 0);
+                std::vector<bf16_t> b1p((size_t)Ce * 8, 0);
+                mixffn16_pack_host(wp.data(), dwb->v.data(), b1->v.data(), Ce, rec.data(), b1p.data());
+                std::memcpy(m->stage(NL + "ffn.rec", (rec.size() + 3) / 4), rec.data(), rec.size());
+                std::memcpy(m->stage16(NL + "mlp1.b16", b1p.size()), b1p.data(), b1p.size() * 2);
+            }
             if (int rc = pack_linear(m, kVitP, F + "mlp2", NL + "mlp2", true, nullptr, w16)) return rc;
             if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".weight", NL + "ln.g")) return rc;
             if (int rc = pack_vec(m, kVitP, P + "_lNorm." + std::to_string(l) + ".bias", NL + "ln.beta")) return rc;
@@ -969,6 +983,14 @@ static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W,
         // --- MixFFN (:98-120)
         const bool last = l == c.vit_layers[s] - 1;
         float *xn = (last && y_out) ? y_out : m->alloc_act(rows * C);
+        if (a16 && m->has(NL + "ffn.rec") && m->wld[NL + "mlp1"] == C && m->wld[NL + "mlp2"] == E && mixffn16_fits(h, w, C, E)) {
+            // one launch, the hidden tensor never in HBM (mixffn16.hip): mlp1 -> grouped conv + GELU -> mlp2 -> + x1 -> LayerNorm
+            RUN(m, "vit_mixffn_fused", 4.0 * rows * C * E + 2.0 * rows * E * 72, 2 * eb * rows * C,
+                launch_mixffn16(x1, n, h, w, C, E, m->W(NL + "mlp1.w"), m->W(NL + "mlp1.b16"), m->W(NL + "ffn.rec"), m->W(NL + "mlp2.w"),
+                                m->W(NL + "mlp2.b"), m->W(NL + "ln.g"), m->W(NL + "ln.beta"), xn, st));
+            xcur = xn;
+            continue;
+        }
         float *h1 = m->alloc_act(rows * E);
         if (int rc = linear(m, "vit_linear", NL + "mlp1", x1, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E, io)) return rc;
         float *h2 = m->alloc_act(rows * E);
@@ -1463,6 +1485,40 @@ extern "C" int evfly_op_grouped_conv_gelu(const void *x, int n, int h, int w, in
     if (int rc = scratch_get((size_t)ce * 72 * 4, &wp, as_stream(stream), 1)) return rc;
     if (int rc = gconv_pack_device(weight, ce, static_cast<float *>(wp), as_stream(stream))) return rc;
     return launch_gconv_gelu(x, n, h, w, ce, static_cast<const float *>(wp), bias, y, bf16 != 0, as_stream(stream));
+}
+
+// Tail of a Mix-Transformer block (ViTsubmodules.py:85-120,145-146) in the bf16 pipeline as a stateless operator:
+// y = LayerNorm(x + MixFFN(x)), one launch (mixffn16.hip). The fp32 state-dict tensors are rounded and packed per call
+// (host round trip, synchronous: a test / tooling entry -- model handles pack once at finalize).
+extern "C" int evfly_op_mixffn_block_bf16(const void *x, int n, int h, int w, int c, int e, const float *w1, const float *b1, const float *dw_w,
+                                          const float *dw_b, const float *w2, const float *b2, const float *ln_g, const float *ln_b, void *y,
+                                          void *stream) {
+    EVFLY_REQUIRE(x && w1 && b1 && dw_w && dw_b && w2 && b2 && ln_g && ln_b && y && n > 0, "op_mixffn_block_bf16: null or empty argument");
+    EVFLY_REQUIRE(mixffn16_fits(h, w, c, e), "op_mixffn_block_bf16: %dx%d tokens x %d channels (hidden %d) have no fused kernel", h, w, c, e);
+    hipStream_t st = as_stream(stream);
+    EVFLY_HIP(hipStreamSynchronize(st));
+    std::vector<float> hw1((size_t)e * c), hb1(e), hdw((size_t)e * 72), hdb(e), hw2((size_t)c * e), wp((size_t)e * 72);
+    EVFLY_HIP(hipMemcpy(hw1.data(), w1, hw1.size() * 4, hipMemcpyDeviceToHost));
+    EVFLY_HIP(hipMemcpy(hb1.data(), b1, hb1.size() * 4, hipMemcpyDeviceToHost));
+    EVFLY_HIP(hipMemcpy(hdw.data(), dw_w, hdw.size() * 4, hipMemcpyDeviceToHost));
+    EVFLY_HIP(hipMemcpy(hdb.data(), dw_b, hdb.size() * 4, hipMemcpyDeviceToHost));
+    EVFLY_HIP(hipMemcpy(hw2.data(), w2, hw2.size() * 4, hipMemcpyDeviceToHost));
+    gconv_pack_host(hdw.data(), e, wp.data());
+    const size_t nrec = mixffn16_rec_bytes(e), o1 = round_up((int64_t)nrec, 256), o2 = o1 + (size_t)e * 16, o3 = o2 + (size_t)e * c * 2,
+                 total = o3 + (size_t)c * e * 2;
+    std::vector<unsigned char> host(total, 0);
+    mixffn16_pack_host(wp.data(), hdb.data(), hb1.data(), e, host.data(), reinterpret_cast<bf16_t *>(host.data() + o1));
+    bf16_t *pw1 = reinterpret_cast<bf16_t *>(host.data() + o2), *pw2 = reinterpret_cast<bf16_t *>(host.data() + o3);
+    for (size_t i = 0; i < hw1.size(); ++i) pw1[i] = host_f2bf(hw1[i]);
+    for (size_t i = 0; i < hw2.size(); ++i) pw2[i] = host_f2bf(hw2[i]);
+    unsigned char *dev = nullptr;
+    EVFLY_HIP(hipMalloc(reinterpret_cast<void **>(&dev), total));
+    int rc = 0;
+    if (hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) rc = fail(-2, "op_mixffn_block_bf16: upload failed");
+    if (!rc) rc = launch_mixffn16(x, n, h, w, c, e, dev + o2, dev + o1, dev, dev + o3, b2, ln_g, ln_b, y, st);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(-2, "op_mixffn_block_bf16: kernel failed");
+    (void)hipFree(dev);
+    return rc;
 }
 
 extern "C" int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, float *vel, void *stream) {

@@ -50,6 +50,13 @@ bool gconv_fits(int H, int W, int Ce);
 void gconv_pack_host(const float *w, int Ce, float *out);
 int gconv_pack_device(const float *w, int Ce, float *out, hipStream_t st);
 int launch_gconv_gelu(const void *x, int n, int H, int W, int Ce, const float *wp, const float *bias, void *y, bool bf16, hipStream_t st);
+// mixffn16.hip: the whole MixFFN of a block + residual + LayerNorm in one launch (bf16 pipeline, ViT-base stage 1: C = 128). W1 / W2 are
+// the bf16 GEMM weights ([E][C], [C][E]); rec / b1p come from mixffn16_pack_host (wp = gconv_pack_host's layout).
+bool mixffn16_fits(int H, int W, int C, int E);
+size_t mixffn16_rec_bytes(int E);
+void mixffn16_pack_host(const float *wp, const float *dw_bias, const float *b1, int E, unsigned char *rec, unsigned short *b1p);
+int launch_mixffn16(const void *x1, int n, int H, int W, int C, int E, const void *W1, const void *b1p, const void *rec, const void *W2,
+                    const float *b2, const float *ln_g, const float *ln_b, void *y, hipStream_t st);
 int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st);
 // x517 assembly (vitfly_models.py:144): cols [512] = desvel/10, [513..516] = quat (or 1,0,0,0), rest of the pad 0
 int launch_meta_fill(float *x517, int64_t rows, int ld, const float *desvel, const float *quat, hipStream_t st);

@@ -350,6 +350,14 @@ int evfly_op_pool2d_nhwc(const float *x, int n, int h, int w, int c, int k, int 
 int evfly_op_grouped_conv_gelu(const void *x, int n, int h, int w, int ce, const float *weight, const float *bias, void *y,
                                int bf16, void *stream);
 
+/* Tail of one Mix-Transformer block in the bf16 pipeline, learner/ViTsubmodules.py:143-146 with MixFFN.forward :98-120 inlined:
+ * y = LayerNorm(x + mlp2(GELU(depthwise(mlp1(x))))) in ONE launch, the (n, h*w, e) hidden tensor only in LDS. x, y (n, h*w, c) bf16
+ * raw bits; w1 (e, c), b1 (e), dw_w (e, 8, 3, 3), dw_b (e), w2 (c, e), b2 (c), ln_g / ln_b (c) fp32 device tensors as the state
+ * dict holds them (rounded to bf16 and packed per call: synchronous). Error if (h, w, c, e) has no fused kernel (c = 128 today). */
+int evfly_op_mixffn_block_bf16(const void *x, int n, int h, int w, int c, int e, const float *w1, const float *b1,
+                               const float *dw_w, const float *dw_b, const float *w2, const float *b2, const float *ln_g,
+                               const float *ln_b, void *y, void *stream);
+
 /* Tail of VelPredictor.forward learner/learner_models.py:309-334 for num_out 1 / 2 (3 is the identity):
  * y (rows, num_out) -> vel (rows, 3) = [sqrt(clip(1 - y^2, 0, 1)), y, 0]  /  [sqrt(clip(1 - y0^2 - y1^2, 0, 1)), y0, y1]. */
 int evfly_op_velpred_vec(const float *y, int64_t rows, int num_out, float *vel, void *stream);

@@ -192,6 +192,58 @@ def test_vit_bf16_pipeline(gpu_device, trunk):
         om.use_trunk()
 
 
+def _vit_base_taps(n_frames=5, seed=11):
+    """LSTMNetVIT with the ViT-base trunk in the bf16 pipeline on a seeded batch: velocities and the two stage outputs."""
+    import evfly_amd.vitfly_models as vm
+    net = vm.LSTMNetVIT(**vm.BASE)
+    sd = syn.fill_state_dict(net.state_dict(), "vitfly_vitlstm.")
+    net.load_state_dict(sd)
+    net.set_compute_dtype("bf16")
+    net = net.to("cuda").eval()
+    rs = np.random.RandomState(seed)
+    img = torch.from_numpy(rs.rand(n_frames, 1, 60, 90).astype(np.float32))
+    desvel = torch.full((n_frames, 1), 4.0)
+    v, _ = net([img.cuda(), desvel.cuda(), None])
+    hh = net.hip()
+    return {"v": v.float().cpu(), "s1": hh.tap("s1").float().cpu(), "s2": hh.tap("s2").float().cpu()}, sd, img, desvel
+
+
+def test_mixffn16_fused_equals_unfused_launches(gpu_device, tmp_path):
+    """mixffn16.hip (stage 1 of the ViT-base trunk: mlp1 -> grouped conv + GELU -> mlp2 -> residual -> LayerNorm in one launch, the
+    hidden tensor only in LDS) against the five launches it replaces (EVFLY_NO_MIXFFN16=1, read once per process: subprocess).
+    Same rounding points (h1, h2, x2 rounded to bf16 once each); what differs is the K order of mlp2's sum and the two-term bf16
+    bias of mlp1, i.e. fp32 noise that can flip a bf16 rounding: the bar is a few bf16 ulps on the stage-1 output (2^-8 relative each,
+    four blocks deep), the pipeline's 3e-2 behind it and against the fp32 oracle."""
+    import os
+    import subprocess
+    import sys
+    from evfly_amd import _lib as L
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "unfused.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, test_gpu_bf16 as t\n"
+            "taps, _, _, _ = t._vit_base_taps()\n"
+            "torch.save(taps, %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_NO_MIXFFN16="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+    ref = torch.load(out)
+    got, sd, img, desvel = _vit_base_taps()
+    if os.environ.get("EVFLY_NO_MIXFFN16") is None:
+        assert not torch.equal(got["s1"], ref["s1"])          # the fused kernel really ran (different summation order)
+    # (s1 is the four fused blocks' own output; s2 / v sit four more blocks -- each with its own bf16 roundings -- behind it)
+    for k, bar in (("s1", 1.5e-2), ("s2", TOL), ("v", TOL)):
+        assert torch.isfinite(got[k]).all()
+        assert rel_err(got[k], ref[k]) < bar, (k, rel_err(got[k], ref[k]))
+    import evfly_amd.vitfly_models as vm
+    cfg = vm.BASE
+    om.use_trunk(heads=cfg["heads"], layers=cfg["layers"], reductions=cfg["reductions"])
+    try:
+        want = om.lstmnetvit_forward(sd, [img, desvel, None])
+    finally:
+        om.use_trunk()
+    assert rel_err(got["v"], want[0]) < TOL
+
+
 def test_mix_stage_bf16_standalone_entry(gpu_device):
     """evfly_vit_stage_forward keeps its fp32 ABI in the bf16 pipeline (input rounded / output widened inside)."""
     import evfly_amd.ViTsubmodules as vs
