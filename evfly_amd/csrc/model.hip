@@ -1516,6 +1516,20 @@ extern "C" int evfly_op_mixffn_block_bf16(const void *x, int n, int h, int w, in
     int rc = 0;
     if (hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) rc = fail(-2, "op_mixffn_block_bf16: upload failed");
     if (!rc) rc = launch_mixffn16(x, n, h, w, c, e, dev + o2, dev + o1, dev, dev + o3, b2, ln_g, ln_b, y, st);
+    if (const char *rep = getenv("EVFLY_MIXFFN_TIME")) {      // developer switch (tools/mixffn_check.py): time <n> more launches
+        const int reps = std::max(1, atoi(rep));
+        hipEvent_t e0, e1;
+        if (!rc && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < reps && !rc; ++i) rc = launch_mixffn16(x, n, h, w, c, e, dev + o2, dev + o1, dev, dev + o3, b2, ln_g, ln_b, y, st);
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            fprintf(stderr, "mixffn16: %d frames, %.4f ms per launch\n", n, ms / reps);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+    }
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(-2, "op_mixffn_block_bf16: kernel failed");
     (void)hipFree(dev);
     return rc;

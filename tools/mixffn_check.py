@@ -17,7 +17,11 @@ def ref(x, w1, b1, dw, db, w2, b2, g, bt, h, w):
     x2 = bf(x + (h2 @ bf(w2).t() + b2))
     return bf(F.layer_norm(x2, (C,), g, bt, 1e-5)), h1, h2, x2
 
-def run(n=3, h=15, w=23, C=128, E=1024, seed=0, probe=None):
+S2 = os.environ.get('MF_STAGE') == '2'
+
+
+def run(n=3, h=8 if S2 else 15, w=12 if S2 else 23, C=256 if S2 else 128, E=None, seed=0, probe=None, check=True):
+    E = E or 8 * C
     rs = np.random.RandomState(seed)
     x = bf(torch.from_numpy(rs.standard_normal((n, h * w, C)).astype(np.float32)))
     w1 = torch.from_numpy((rs.standard_normal((E, C)) / np.sqrt(C)).astype(np.float32))
@@ -34,13 +38,14 @@ def run(n=3, h=15, w=23, C=128, E=1024, seed=0, probe=None):
     if probe == "w2zero": w2.zero_()
     if probe == "w1zero": w1.zero_(); dw.zero_(); db.zero_(); [dw.__setitem__((c, c % 8, 1, 1), 1.0) for c in range(E)]
     if probe == "w1zero_b0": w1.zero_(); b1.zero_()
-    want, h1, h2, x2 = ref(x, w1, b1, dw, db, w2, b2, g, bt, h, w)
+    if check: want, h1, h2, x2 = ref(x, w1, b1, dw, db, w2, b2, g, bt, h, w)
     L = _lib.lib()
     dev = [t.cuda().contiguous() for t in (w1, b1, dw, db, w2, b2, g, bt)]
     xb = x.to(torch.bfloat16).view(torch.int16).cuda().contiguous()
     y = torch.zeros(n, h * w, C, dtype=torch.int16, device="cuda")
     _lib.check(L.evfly_op_mixffn_block_bf16(_lib.ptr(xb), n, h, w, C, E, *[_lib.ptr(t) for t in dev], _lib.ptr(y), _lib.cur_stream()))
     torch.cuda.synchronize()
+    if not check: return 0.0
     got = y.view(torch.bfloat16).float().cpu()
     dbg = os.environ.get("MF_DBG")           # "1:sl" / "2:sl": a developer build that dumps a slab of h1 / h2 (EVFLY_LIB variant)
     if dbg:
@@ -59,9 +64,6 @@ def run(n=3, h=15, w=23, C=128, E=1024, seed=0, probe=None):
               "chans", sorted(set(bad[:, 2].tolist()))[:40])
     return err.max().item() / max(want.abs().max().item(), 1e-30)
 
-if __name__ == "__main__" and not os.environ.get("MF_PROBE_W1"):
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    for pr in os.environ.get("MF_PROBES", "w2zero,w1zero,w1zero_b0,nodw,None").split(","): run(n, probe=None if pr == "None" else pr)
 
 
 def probe_w1_rows(n=1, h=15, w=23, C=128, E=1024):
@@ -88,6 +90,25 @@ def probe_w1_rows(n=1, h=15, w=23, C=128, E=1024):
         print("hidden", sl * 32 + e, "<- x column", k, "err", round(err, 4), "" if k == perm[sl * 32 + e].item() else "  <-- WRONG, want %d" % perm[sl * 32 + e].item())
 
 
+if os.environ.get("MF_TS"):            # phase timeline of block 0 (an -DEVFLY_MF_TS build selected with EVFLY_LIB)
+    import ctypes
+    E = int(os.environ.get("MF_E", "0")) or (2048 if S2 else 1024)
+    run(int(os.environ.get("MF_TS_FRAMES", "2560")), E=E, seed=2, check=False)
+    buf = np.zeros(12 * 8, dtype=np.uint64)
+    L = _lib.lib()
+    L.evfly_debug_mixffn_ts.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    assert L.evfly_debug_mixffn_ts(buf.ctypes.data, buf.size) == 0
+    t = buf.reshape(12, 8).astype(np.float64) / (E // 32)         # s_memtime ticks (100 MHz) per slab
+    names = ["mlp1", "wait+bar1", "gconv+gelu", "wait+bar2", "mlp2", "prologue", "epilogue", "-"]
+    print("ticks of the 100 MHz counter per slab (x ~24 = shader cycles at 2.4 GHz); prologue / epilogue per frame")
+    for w in range(12):
+        row = t[w].copy(); row[5] *= E // 32; row[6] *= E // 32
+        print("wave %2d " % w + "  ".join("%s %.1f" % (names[i], row[i]) for i in range(7)))
+    sys.exit(0)
+if os.environ.get("MF_TIME"):          # MF_TIME=<frames>: EVFLY_MIXFFN_TIME launches of the full-size problem (prints ms per launch)
+    os.environ.setdefault("EVFLY_MIXFFN_TIME", "20")
+    run(int(os.environ["MF_TIME"]), E=int(os.environ.get("MF_E", "0")) or None, seed=2, check=False)
+    sys.exit(0)
 if os.environ.get("MF_PROBE_W1"):
     probe_w1_rows()
 
@@ -120,3 +141,8 @@ def probe_h1_values():
 
 if os.environ.get("MF_PROBE_H1"):
     probe_h1_values()
+
+
+if __name__ == "__main__" and not os.environ.get("MF_PROBE_W1") and not os.environ.get("MF_PROBE_H1"):
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    for pr in os.environ.get("MF_PROBES", "w2zero,w1zero,w1zero_b0,nodw,None").split(","): run(n, probe=None if pr == "None" else pr)
