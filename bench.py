@@ -514,6 +514,10 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                            "gbs_algorithmic": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] else None}
                           for p in sorted(prof, key=lambda p: -p["ms"])]
         out["model_ms_per_step"] = round(model_ms, 3)
+        if os.environ.get("BENCH_DUMP_LAYERS"):      # developer switch: every launch site of the bracketed step, not only the families
+            out["layers"] = [{"name": p["name"], "ms": round(p["ms"], 4), "launches": p["launches"],
+                              "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1) if p["flops"] and p["ms"] else None,
+                              "gbs": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] else None} for p in layers]
         out["conv_layers"] = [{"name": p["name"], "ms_per_step": round(p["ms"], 3),
                                "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)}
                               for p in layers if p["name"].startswith(dom["name"] + "/")]

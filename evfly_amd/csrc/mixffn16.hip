@@ -98,26 +98,24 @@ __device__ __forceinline__ mf_f32x2 pk_mul(mf_f32x2 a, mf_f32x2 b) { mf_f32x2 d;
 __device__ __forceinline__ mf_f32x2 pk_fma_s(mf_f32x2 a, mf_f32x2 b, mf_f32x2 c) { mf_f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c)); return d; }
 __device__ __forceinline__ mf_f32x2 pk_fma_ss(mf_f32x2 a, mf_f32x2 s, mf_f32x2 c) { mf_f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(s), "v"(c)); return d; }
 
-// erf-GELU of two values: erf(v) = v P(v^2) / Q(v^2) on [-4, 4], the rational of gconv.hip (|error| <= 4.5e-7), Horner steps packed
+// erf-GELU of two values. erf(v) = v P(v^2) / Q(v^2) on |v| <= 3.5 with cubic P and Q (minimax fit, tools/mixffn_check.py MF_GELU=1:
+// |error| <= 1.3e-5 against erf, <= 7e-5 on the GELU -- two orders below the bf16 rounding of the result; gconv.hip's sixth / fourth
+// degree form (4.5e-7) costs four more packed FMAs per pair, and this phase is VALU-bound), Horner steps packed
 #define MF_C2(x) (mf_f32x2{(x), (x)})
 __device__ __forceinline__ mf_f32x2 mf_gelu2(mf_f32x2 a) {
     // (the first reader of `a` is compiler-visible code: the caller's `a` comes out of an MFMA, and hipcc's hazard recogniser puts
     // the wait states between the matrix pipe's write and a VALU read only in front of instructions it can see -- an inline-asm
     // consumer right behind the last MFMA of a task read the registers early)
     mf_f32x2 v;
-    v[0] = __builtin_amdgcn_fmed3f(a[0] * 0.70710678118654752440f, -4.f, 4.f);
-    v[1] = __builtin_amdgcn_fmed3f(a[1] * 0.70710678118654752440f, -4.f, 4.f);
+    v[0] = __builtin_amdgcn_fmed3f(a[0] * 0.70710678118654752440f, -3.5f, 3.5f);
+    v[1] = __builtin_amdgcn_fmed3f(a[1] * 0.70710678118654752440f, -3.5f, 3.5f);
     const mf_f32x2 v2 = pk_mul(v, v);
-    mf_f32x2 p = pk_fma_ss(v2, MF_C2(-2.72614225801306e-10f), MF_C2(2.77068142495902e-08f));
-    p = pk_fma_s(p, v2, MF_C2(-2.10102402082508e-06f));
-    p = pk_fma_s(p, v2, MF_C2(-5.69250639462346e-05f));
-    p = pk_fma_s(p, v2, MF_C2(-7.34990630326855e-04f));
-    p = pk_fma_s(p, v2, MF_C2(-2.95459980854025e-03f));
-    p = pk_fma_s(p, v2, MF_C2(-1.60960333262415e-02f));
-    mf_f32x2 q = pk_fma_ss(v2, MF_C2(-1.45660718464996e-05f), MF_C2(-2.13374055278905e-04f));
-    q = pk_fma_s(q, v2, MF_C2(-1.68282697438203e-03f));
-    q = pk_fma_s(q, v2, MF_C2(-7.37332916720468e-03f));
-    q = pk_fma_s(q, v2, MF_C2(-1.42647390514189e-02f));
+    mf_f32x2 p = pk_fma_ss(v2, MF_C2(0.0007302758749574423f), MF_C2(0.04286076873540878f));
+    p = pk_fma_s(p, v2, MF_C2(0.15528972446918488f));
+    p = pk_fma_s(p, v2, MF_C2(1.1283745765686035f));
+    mf_f32x2 q = pk_fma_ss(v2, MF_C2(0.009142078459262848f), MF_C2(0.09490722417831421f));
+    q = pk_fma_s(q, v2, MF_C2(0.470951646566391f));
+    q = pk_fma_s(q, v2, MF_C2(1.0f));
     // (the reciprocals from inside the asm, with the wait state gfx950 wants between a transcendental result and the VALU
     // instruction that reads it: hipcc's hazard recogniser does not look into the inline-asm consumer and left none -- the
     // second element of every pair came out wrong)

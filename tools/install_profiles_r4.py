@@ -2,7 +2,7 @@
 import json, os, shutil, sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
-for c in ("C2", "C5"):
+for c in ("C2", "C5", "C3"):
     for f in ("bench.json", "bench_under_rocprof.json", "rocprofv3_kernel_stats.csv", "pmc_traffic.json", "pmc_mfma.json"):
         shutil.copy(os.path.join(src, f"{c}_{f}"), os.path.join("profiles", f"r4_{c}_{f}"))
 for c in ("C3", "C4"):

@@ -90,6 +90,33 @@ def probe_w1_rows(n=1, h=15, w=23, C=128, E=1024):
         print("hidden", sl * 32 + e, "<- x column", k, "err", round(err, 4), "" if k == perm[sl * 32 + e].item() else "  <-- WRONG, want %d" % perm[sl * 32 + e].item())
 
 
+if os.environ.get("MF_GELU"):          # the cubic / cubic erf rational of mixffn16.hip: minimax fit on |v| <= 3.5 and its error (CPU only)
+    from scipy.special import erf
+    from scipy.optimize import least_squares
+    m, n_, c = 3, 3, 3.5
+    v = np.linspace(1e-3, c, 6000); t = v * v; yv = erf(v) / v
+    model = lambda p, t: sum(p[i] * t ** i for i in range(m + 1)) / (1 + sum(p[m + 1 + i] * t ** (i + 1) for i in range(n_)))
+    res = lambda p: (model(p, t) - yv) * v
+    A = np.concatenate([np.stack([t ** i for i in range(m + 1)], 1), -np.stack([yv * t ** (i + 1) for i in range(n_)], 1)], 1)
+    p = np.linalg.lstsq(A, yv, rcond=None)[0]
+    best = None
+    for it in range(40):                 # growing exponent: least squares -> minimax
+        p = least_squares(lambda q: np.sign(res(q)) * np.abs(res(q)) ** (1 + it * 0.3), p, xtol=1e-15, ftol=1e-15, max_nfev=4000).x
+        e = np.abs(res(p)).max()
+        if best is None or e < best[0]: best = (e, p.copy())
+    e, p = best
+    print("max |erf error| on [0, %.1f]: %.3e" % (c, e))
+    print("P (v^0, v^2, v^4, v^6):", [float(np.float32(x)) for x in p[:m + 1]])
+    print("Q:", [1.0] + [float(np.float32(x)) for x in p[m + 1:]])
+    a = np.linspace(-12, 12, 2400001).astype(np.float32)
+    v32 = np.clip(a * np.float32(0.70710678118), -c, c).astype(np.float32); t32 = v32 * v32
+    P = [np.float32(x) for x in p[:m + 1]]; Q = [np.float32(1)] + [np.float32(x) for x in p[m + 1:]]
+    num = ((P[3] * t32 + P[2]) * t32 + P[1]) * t32 + P[0]
+    den = ((Q[3] * t32 + Q[2]) * t32 + Q[1]) * t32 + Q[0]
+    g = a * ((v32 * num * (np.float32(1) / den)) * np.float32(0.5) + np.float32(0.5))
+    gt = 0.5 * a.astype(np.float64) * (1 + erf(a.astype(np.float64) / np.sqrt(2)))
+    print("max |GELU error| in fp32 arithmetic on [-12, 12]: %.3e" % np.abs(g - gt).max())
+    sys.exit(0)
 if os.environ.get("MF_TS"):            # phase timeline of block 0 (an -DEVFLY_MF_TS build selected with EVFLY_LIB)
     import ctypes
     E = int(os.environ.get("MF_E", "0")) or (2048 if S2 else 1024)

@@ -1,15 +1,16 @@
 # usage: bash tools/scripts/profile_round4.sh <tag>      (on the GPU box through gpurun; writes gpurun_out/<tag>/)
 # Round-4 evidence set, one gpurun call:
 #   C2 (headline, fp32): default `python bench.py` line, rocprofv3 kernel stats of the same command, FETCH_SIZE / WRITE_SIZE
-#   passes (roofline.traffic), SQ_VALU_MFMA_BUSY_CYCLES pass;  C5 (bf16 pipeline): the same four;  C3 / C4: bench lines.
+#   passes (roofline.traffic), SQ_VALU_MFMA_BUSY_CYCLES pass;  C5 and C3 (bf16 pipeline; C3 on one stream under the profiler): the same
+#   four;  C3 / C4: bench lines.
 # PMC passes are separate rocprofv3 runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section); the program goes
 # straight behind `--`.
 T=${1:-r4x}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$T; mkdir -p $O
-for c in C2 C5; do
-  X=""; [ $c = C5 ] && X="--config C5"
+for c in C2 C5 C3; do
+  X=""; [ $c = C5 ] && X="--config C5"; [ $c = C3 ] && X="--config C3 --no-overlap"
   # (the default C2 line carries the compact C5 / C3 / C4 objects under `other_configs`, exactly as the driver runs it)
   python3 bench.py $X > $O/${c}_bench.json 2> $O/${c}_bench.err
   rocprofv3 --kernel-trace --stats -d $O/${c}_prof -o p --output-format csv -- python3 bench.py $X --no-cpu-baseline --no-alt --no-stage-rates --no-other-configs > $O/${c}_bench_under_rocprof.json 2> $O/${c}_prof.err
