@@ -983,7 +983,8 @@ static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W,
         // --- MixFFN (:98-120)
         const bool last = l == c.vit_layers[s] - 1;
         float *xn = (last && y_out) ? y_out : m->alloc_act(rows * C);
-        if (a16 && m->has(NL + "ffn.rec") && m->wld[NL + "mlp1"] == C && m->wld[NL + "mlp2"] == E && mixffn16_fits(h, w, C, E)) {
+        if (a16 && m->has(NL + "ffn.rec") && m->wld[NL + "mlp1"] == C && m->wld[NL + "mlp2"] == E && mixffn16_fits(h, w, C, E) &&
+            rows * C * 2 < ((int64_t)1 << 32)) {
             // one launch, the hidden tensor never in HBM (mixffn16.hip): mlp1 -> grouped conv + GELU -> mlp2 -> + x1 -> LayerNorm
             RUN(m, "vit_mixffn_fused", 4.0 * rows * C * E + 2.0 * rows * E * 72, 2 * eb * rows * C,
                 launch_mixffn16(x1, n, h, w, C, E, m->W(NL + "mlp1.w"), m->W(NL + "mlp1.b16"), m->W(NL + "ffn.rec"), m->W(NL + "mlp2.w"),

@@ -244,6 +244,41 @@ def test_mixffn16_fused_equals_unfused_launches(gpu_device, tmp_path):
     assert rel_err(got["v"], want[0]) < TOL
 
 
+@pytest.mark.parametrize("shape", [(3, 15, 23, 128), (5, 8, 12, 256), (1, 8, 12, 256)])
+def test_mixffn_block_op(gpu_device, shape):
+    """evfly_op_mixffn_block_bf16 (mixffn16.hip: the whole tail of a Mix-Transformer block in one launch, ViTsubmodules.py:98-120,143-146)
+    against a torch restatement of the unfused bf16 launches with the same rounding points (h1, h2, x2 rounded to bf16 once each; bf16
+    weights; fp32 accumulation): what is left is summation order, the two-term bf16 bias of mlp1 and the cubic / cubic erf rational
+    (7e-5 on the GELU) -- the bar is two bf16 ulps of the LayerNorm output's range. Both ViT-base stages; odd frame counts exercise the
+    half-empty last block of the two-frames-per-block stage."""
+    n, h, w, C = shape
+    E = 8 * C
+    bf = lambda t: t.to(torch.bfloat16).float()
+    rs = np.random.RandomState(n * 100 + C)
+    rnd = lambda *sh: torch.from_numpy(rs.standard_normal(sh).astype(np.float32))
+    x = bf(rnd(n, h * w, C))
+    w1, b1 = rnd(E, C) / np.sqrt(C), 0.1 * rnd(E)
+    dw, db = rnd(E, 8, 3, 3) / np.sqrt(72), 0.1 * rnd(E)
+    w2, b2 = rnd(C, E) / np.sqrt(E), 0.1 * rnd(C)
+    g, bt = 1 + 0.1 * rnd(C), 0.1 * rnd(C)
+    h1 = bf(x @ bf(w1).t() + b1)
+    t = F.conv2d(h1.transpose(1, 2).reshape(n, E, h, w), bf(dw), db, padding=1, groups=E // 8)
+    h2 = bf(F.gelu(t).flatten(2).transpose(1, 2))
+    x2 = bf(x + (h2 @ bf(w2).t() + b2))
+    want = bf(F.layer_norm(x2, (C,), g, bt, 1e-5))
+    L = _lib.lib()
+    dev = [v.cuda().contiguous() for v in (w1, b1, dw, db, w2, b2, g, bt)]
+    xb = x.to(torch.bfloat16).view(torch.int16).cuda().contiguous()
+    y = torch.zeros(n, h * w, C, dtype=torch.int16, device="cuda")
+    _lib.check(L.evfly_op_mixffn_block_bf16(_lib.ptr(xb), n, h, w, C, E, *[_lib.ptr(v) for v in dev], _lib.ptr(y), _lib.cur_stream()))
+    torch.cuda.synchronize()
+    got = y.view(torch.bfloat16).float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < 2 * 2.0 ** -8, rel_err(got, want)
+    # a shape without a fused kernel is an error, not a silent fallback
+    assert L.evfly_op_mixffn_block_bf16(_lib.ptr(xb), n, h, w, 64, E, *[_lib.ptr(v) for v in dev], _lib.ptr(y), _lib.cur_stream()) != 0
+
+
 def test_mix_stage_bf16_standalone_entry(gpu_device):
     """evfly_vit_stage_forward keeps its fp32 ABI in the bf16 pipeline (input rounded / output widened inside)."""
     import evfly_amd.ViTsubmodules as vs
