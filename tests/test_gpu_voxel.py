@@ -172,6 +172,46 @@ def test_region_of_interest_equals_crop(gpu_device, roi):
         voxelizer.voxelize_windows(ev, Hh, Ww, roi=(300, 0, 200, 640))
 
 
+def test_hot_pixel_wraps_16_bit_counter_and_falls_back(gpu_device):
+    """Optimistic mode of the banded kernel (voxel.hip): sorted windows with more than 65 535 events run on the 16-bit-counter kernel,
+    which proves afterwards that no half wrapped (sum of all halves == events it accepted) and hands the frame to the 32-bit kernel if
+    one did. Stream 0: 70 000 positive events on ONE pixel (wraps the P half and carries into N), stream 1: 66 000 negative events on one
+    pixel (the N half wraps, the carry leaves the word), stream 2: 90 000 events spread over a few pixels (no wrap: stays on the
+    16-bit kernel), a frame whose wrap sits in a different row band than its other events. Counts must be the exact integers."""
+    from evfly_amd import voxelizer
+    T, Hh, Ww = 2, 480, 640
+    rs = np.random.RandomState(17)
+    streams = []
+    for sidx, (n_hot, sign, spread) in enumerate(((70_000, 1, 1), (66_000, -1, 1), (90_000, 0, 40))):
+        ev, e = syn.make_stream(sidx, T, Hh, Ww, 3_000, seed_base=900)
+        hx = (rs.randint(0, spread, n_hot) + 300).astype(np.uint16)
+        hy = (rs.randint(0, spread, n_hot) + (5 if sidx == 0 else 470)).astype(np.uint16)          # first / last row band
+        hp = (np.full(n_hot, sign) if sign else 2 * rs.randint(0, 2, n_hot) - 1).astype(np.int8)
+        ht = rs.randint(e[0], e[1], n_hot).astype(np.int64)
+        evh = dict(x=np.r_[ev["x"], hx], y=np.r_[ev["y"], hy], t=np.r_[ev["t"], ht], p=np.r_[ev["p"], hp])
+        o = np.argsort(evh["t"], kind="stable")
+        streams.append(({k: v[o] for k, v in evh.items()}, e))
+    batch = {k: np.concatenate([s[0][k] for s in streams]) for k in ("x", "y", "t", "p")}
+    batch["offsets"] = np.cumsum([0] + [len(s[0]["x"]) for s in streams]).astype(np.int64)
+    batch["edges"] = np.stack([s[1] for s in streams]).astype(np.int64)
+    ev = voxelizer.upload_events(batch)
+    assert ev["skip_kernels"] != 2
+    cnt = voxelizer.voxelize_windows(ev, Hh, Ww, out="counts").cpu().numpy()          # (B, T, 2, H, W)
+    for b, (evs, e) in enumerate(streams):
+        for w in range(T):
+            m = (evs["t"] >= e[w]) & (evs["t"] < e[w + 1])
+            xs, ys, ps = np.minimum(evs["x"][m], Ww - 1).astype(np.int64), np.minimum(evs["y"][m], Hh - 1).astype(np.int64), evs["p"][m]
+            ok = (evs["x"][m] <= Ww) & (evs["y"][m] <= Hh)
+            P = np.bincount((ys * Ww + xs)[ok & (ps > 0)], minlength=Hh * Ww).reshape(Hh, Ww)
+            Nn = np.bincount((ys * Ww + xs)[ok & (ps < 0)], minlength=Hh * Ww).reshape(Hh, Ww)
+            assert np.array_equal(cnt[b, w, 0], P) and np.array_equal(cnt[b, w, 1], Nn), (b, w)
+    assert cnt[0, 0, 0].max() >= 70_000 and cnt[1, 0, 1].max() >= 66_000
+    # ... and with the region of interest of run.py:345-350 (three row bands of the 16-bit kernel)
+    r = (100, 200, 380, 346)
+    cr = voxelizer.voxelize_windows(ev, Hh, Ww, out="counts", roi=r).cpu().numpy()
+    assert np.array_equal(cr, cnt[:, :, :, r[0]:r[0] + r[2], r[1]:r[1] + r[3]])
+
+
 def test_unsorted_ragged_hot_and_empty(gpu_device):
     """General path: an unsorted stream, a window with > 65535 events, an empty stream, ragged
     lengths, events outside every window and outside the sensor."""
