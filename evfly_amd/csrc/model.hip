@@ -342,6 +342,16 @@ int pack_unet(evfly_model *m) {
                     wx[(size_t)o * hid + i] = host_f2bf(t->v[(size_t)o * I + i]);
                     wh[(size_t)o * hid + i] = host_f2bf(t->v[(size_t)o * I + hid + i]);
                 }
+            // the same two matrices with gate-interleaved rows (row 4 cell + gate) for the one-launch recurrence (clstm16.hip)
+            std::vector<bf16_t> wxs(wx, wx + (size_t)O * hid), whs(wh, wh + (size_t)O * hid);
+            m->stage16("clstm.wx_i", (size_t)O * hid);
+            m->stage16("clstm.wh_i", (size_t)O * hid);
+            clstm16_interleave_host(wxs.data(), hid, hid, reinterpret_cast<bf16_t *>(m->wstage.data() + m->woff["clstm.wx_i"]));
+            {   // the hidden side also in MFMA fragment order: the kernel's weight requests are then 1 KiB of consecutive bytes
+                std::vector<bf16_t> whi((size_t)O * hid);
+                clstm16_interleave_host(whs.data(), hid, hid, whi.data());
+                clstm16_fragment_host(whi.data(), hid, reinterpret_cast<bf16_t *>(m->wstage.data() + m->woff["clstm.wh_i"]));
+            }
         } else {
         m->stage("clstm.wx", (size_t)O * hid);
         m->stage("clstm.wh", (size_t)O * hid);   // staging may reallocate: take the pointers afterwards
@@ -726,8 +736,11 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     if (c.num_recurrent_unet > 0) {
         const int rpi = 8 * 13, hid = 512;
         float *zx = m->alloc((int64_t)F * rpi * 4 * hid);          // fp32 pre-activations in every pipeline
+        // bf16 pipeline: the T steps of a chunk in ONE launch (clstm16.hip: a 1x1 ConvLSTM is an independent LSTM per position) on
+        // gate-interleaved pre-activations; otherwise a GEMM + a gate launch per step
+        const bool seq = a16 && m->has("clstm.wh_i") && clstm16_seq_available((int64_t)S * rpi);
         {   // input-side 1x1 conv for every frame at once
-            ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W("clstm.wx"); d.ldw = hid;
+            ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W(seq ? "clstm.wx_i" : "clstm.wx"); d.ldw = hid;
             conv_finish(d); d.Nc = 4 * hid; d.y = zx; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             RUN(m, "convlstm_x_gemm", igemm_flops(d), d.M * (a16 ? 2.0 : 4.0) * hid + d.M * 16.0 * hid + (a16 ? 2.0 : 4.0) * 4.0 * hid * hid,
                 igemm_launch(d, st));
@@ -747,6 +760,10 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         if (a16 && !m->planning) {
             if (int rc = launch_f32_to_bf16(hs, (int64_t)S * rpi * hid, h16, st)) return rc;
         }
+        if (seq)
+            RUN(m, "convlstm_seq", 2.0 * S * rpi * 4.0 * hid * hid * (h_state ? T : T - 1), (double)F * rpi * hid * (16.0 + 2.0) + 2.0 * 4.0 * hid * hid,
+                launch_clstm16_seq(zx, m->W("clstm.wh_i"), S, T, rpi, hs, cs, h16, hseq, !h_state, st));
+        else
         for (int t = 0; t < T; ++t) {
             // fresh streams (no incoming state): h0 = 0, so conv(h0) contributes exactly nothing to step 0 -- its GEMM is skipped
             // and the cell reads zx[:, 0] in place

@@ -57,6 +57,12 @@ size_t mixffn16_rec_bytes(int E);
 void mixffn16_pack_host(const float *wp, const float *dw_bias, const float *b1, int E, unsigned char *rec, unsigned short *b1p);
 int launch_mixffn16(const void *x1, int n, int H, int W, int C, int E, const void *W1, const void *b1p, const void *rec, const void *W2,
                     const float *b2, const float *ln_g, const float *ln_b, void *y, hipStream_t st);
+// clstm16.hip: the whole T-step recurrence of the 1x1 ConvLSTM for a chunk of streams in one launch (bf16 pipeline). zx / whi with
+// gate-interleaved columns / rows (clstm16_interleave_host); h, c fp32 states updated in place, h16 / hseq bf16.
+bool clstm16_seq_available(int64_t state_rows);
+void clstm16_interleave_host(const unsigned short *w_src, int hid, int ld, unsigned short *dst);
+void clstm16_fragment_host(const unsigned short *wi, int hid, unsigned short *dst);
+int launch_clstm16_seq(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, hipStream_t st);
 int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st);
 // x517 assembly (vitfly_models.py:144): cols [512] = desvel/10, [513..516] = quat (or 1,0,0,0), rest of the pad 0
 int launch_meta_fill(float *x517, int64_t rows, int ld, const float *desvel, const float *quat, hipStream_t st);

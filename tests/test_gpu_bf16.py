@@ -164,6 +164,44 @@ def test_unet_bf16_stateful_split_equals_one_call(gpu_device):
     assert torch.equal(up_b, up_b2)
 
 
+def _clstm_seq_outputs():
+    """Two streams x four windows through the bf16 U-Net, fresh and then with the carried state: depth maps and the ConvLSTM states."""
+    net, sd = _unet("cuda")
+    x = cond_frames(73, 8).cuda()                       # batch-as-time: 2 streams x 4 windows
+    d1, (_, up1, (st1, _)) = net([x.clone(), None, None])
+    d2, (_, up2, (st2, _)) = net([x.clone(), None, (st1, None)])
+    return {"up1": up1.float().cpu(), "up2": up2.float().cpu(), "h1": st1[0][0].float().cpu(), "c1": st1[0][1].float().cpu(),
+            "h2": st2[0][0].float().cpu(), "c2": st2[0][1].float().cpu()}, sd, x.cpu()
+
+
+def test_convlstm_sequence_kernel_equals_per_step_launches(gpu_device, tmp_path):
+    """clstm16.hip (the T steps of a chunk in one launch: h in LDS, c in registers, weights streamed from L2, gates on the accumulators)
+    against the per-step GEMM + gate launches it replaces for large chunks. Forced for this small batch with
+    EVFLY_CLSTM16_SEQ_MIN_ROWS=0 (read once per process: subprocess); fresh state and carried state. Differences: MFMA summation
+    order inside a k step and exp2 / rcp against expf / tanhf in the gates (~1e-6) ahead of the bf16 rounding of h -- the bar is a few
+    bf16 ulps on the states, the pipeline's bound on the depth output."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "seq.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, test_gpu_bf16 as t\n"
+            "o, _, _ = t._clstm_seq_outputs()\n"
+            "torch.save(o, %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_CLSTM16_SEQ_MIN_ROWS="0"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+    seq = torch.load(out)
+    ref, _, _ = _clstm_seq_outputs()
+    if os.environ.get("EVFLY_CLSTM16_SEQ_MIN_ROWS") is None:
+        assert not torch.equal(seq["h1"], ref["h1"])                       # the sequence kernel really ran in the child
+    for k in ("h1", "c1", "h2", "c2"):
+        assert torch.isfinite(seq[k]).all()
+        assert rel_err(seq[k], ref[k]) < 1e-2, (k, rel_err(seq[k], ref[k]))
+    for k in ("up1", "up2"):
+        assert rel_err(seq[k], ref[k]) < TOL, (k, rel_err(seq[k], ref[k]))
+
+
 @pytest.mark.parametrize("trunk", ["tiny", "base"])
 def test_vit_bf16_pipeline(gpu_device, trunk):
     import evfly_amd.vitfly_models as vm
