@@ -17,7 +17,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
 }
-enum OutMode { OUT_ROWS = 0, OUT_UPCONV2X2 = 1 };
+enum OutMode { OUT_ROWS = 0, OUT_UPCONV2X2 = 1, OUT_LSTM = 2 };
 
 struct ConvDesc {
     const float *x = nullptr;   // input pixels, row (pixel) stride ldx floats, channels [0, C)
@@ -41,6 +41,12 @@ struct ConvDesc {
     int64_t ldy = 0;
     int out_mode = OUT_ROWS;
     int up_cout = 0;            // OUT_UPCONV2X2: n = (dy*2+dx)*up_cout + co, bias indexed by co
+    // OUT_LSTM (igemm16 only; ConvLSTM step, convlstm.py:44-51): the Nc = 4 hid columns are GATE-INTERLEAVED (column 4 cell + gate, gates
+    // i f o g), res = the input-side pre-activations in the same layout; the epilogue applies the cell update instead of writing
+    // y: c, h fp32 (M, hid) updated in place, h16 a bf16 copy of h, hseq row (m / res_rpi) * lstm_seq_img_rows + m % res_rpi a bf16 copy
+    float *lstm_c = nullptr, *lstm_h = nullptr;
+    void *lstm_h16 = nullptr, *lstm_hseq = nullptr;
+    int64_t lstm_seq_img_rows = 0;
     int dtype = EVFLY_DTYPE_F32;
     // bf16 pipeline (dtype == EVFLY_DTYPE_BF16 with in_bf16): x, w point at bf16 elements (strides ldx / ldw stay in
     // ELEMENTS; w is [Nc][ldw] bf16 rounded at pack time, ldw a multiple of 64) and go HBM/L2 -> LDS -> MFMA operands

@@ -32,6 +32,10 @@ constexpr int ROWF = 32;   // floats (4-B slots) per LDS tile row = 128 B
 __device__ __forceinline__ int lds_off16(int row, int chunk) { return row * ROWF + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 // epilogue of one 8-column piece: v = tile + bias (already), + res, act, store (bf16 16 B / fp32 2 x 16 B)
+// ConvLSTM gates of the OUT_LSTM epilogue: v_exp_f32 + v_rcp_f32 (clstm16.hip's forms)
+__device__ __forceinline__ float lstm_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float lstm_tanh(float v) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)), -1.0f); }
+
 __device__ __forceinline__ void act8(float (&v)[8], int act) {
     if (act == ACT_NONE) return;
 #pragma unroll
@@ -305,6 +309,26 @@ __global__ __launch_bounds__(256) void k_igemm16(ConvDesc d, int n_mt, int n_nt,
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rq[k][e];
                 }
+                if (d.out_mode == OUT_LSTM) {      // 8 adjacent columns = gates (i, f, o, g) of two cells
+                    const int hid = d.Nc >> 2, cell = n >> 2;
+                    float *cp = d.lstm_c + m * hid + cell;
+                    const float2 c0 = *reinterpret_cast<const float2 *>(cp);
+                    float cn[2], hn[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        cn[e] = lstm_sigmoid(v[4 * e + 1]) * (e ? c0.y : c0.x) + lstm_sigmoid(v[4 * e]) * lstm_tanh(v[4 * e + 3]);      // convlstm.py:50
+                        hn[e] = lstm_sigmoid(v[4 * e + 2]) * lstm_tanh(cn[e]);                                                      // :51
+                    }
+                    *reinterpret_cast<float2 *>(cp) = make_float2(cn[0], cn[1]);
+                    *reinterpret_cast<float2 *>(d.lstm_h + m * hid + cell) = make_float2(hn[0], hn[1]);
+                    const unsigned hb = pack_bf2(hn[0], hn[1]);
+                    *reinterpret_cast<unsigned *>(static_cast<bf16_t *>(d.lstm_h16) + m * hid + cell) = hb;
+                    if (d.lstm_hseq) {
+                        const int64_t g = m / d.res_rpi;
+                        *reinterpret_cast<unsigned *>(static_cast<bf16_t *>(d.lstm_hseq) + (g * d.lstm_seq_img_rows + (m - g * d.res_rpi)) * hid + cell) = hb;
+                    }
+                    continue;
+                }
                 act8(v, act);
                 const int64_t o = out_index(m, n);
                 if (d.out_bf16) Elem<bf16_t>::store(y16 + o, v);
@@ -405,7 +429,9 @@ int igemm16_launch(const ConvDesc &d_in, hipStream_t st) {
     EVFLY_REQUIRE(d.ldw % BKE == 0 && d.ldw >= d.K, "igemm16: weights must be zero padded to a multiple of 64 (ldw=%d K=%d)", d.ldw, d.K);
     EVFLY_REQUIRE(((uintptr_t)d.w) % 16 == 0 && ((uintptr_t)d.x) % 16 == 0 && d.ldx % 8 == 0, "igemm16: operands not 16-byte aligned");
     EVFLY_REQUIRE(d.M < (int64_t)1 << 31, "igemm16: more than 2^31 output pixels in one launch");
-    EVFLY_REQUIRE(d.out_mode == OUT_ROWS || (d.up_cout > 0 && d.Nc == 4 * d.up_cout && !d.res && d.act == ACT_NONE), "igemm16: bad upconv epilogue");
+    EVFLY_REQUIRE(d.out_mode != OUT_UPCONV2X2 || (d.up_cout > 0 && d.Nc == 4 * d.up_cout && !d.res && d.act == ACT_NONE), "igemm16: bad upconv epilogue");
+    EVFLY_REQUIRE(d.out_mode != OUT_LSTM || (d.Nc % 128 == 0 && d.res && !d.res_bf16 && d.res_rpi > 0 && d.lstm_c && d.lstm_h && d.lstm_h16 && !d.bias &&
+                                            d.ldres % 4 == 0 && ((uintptr_t)d.res) % 16 == 0), "igemm16: bad ConvLSTM epilogue");
     const bool plain = d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1;
     return plain ? launch_by_n16<true>(d, st) : launch_by_n16<false>(d, st);
 }

@@ -347,6 +347,8 @@ int pack_unet(evfly_model *m) {
             m->stage16("clstm.wx_i", (size_t)O * hid);
             m->stage16("clstm.wh_i", (size_t)O * hid);
             clstm16_interleave_host(wxs.data(), hid, hid, reinterpret_cast<bf16_t *>(m->wstage.data() + m->woff["clstm.wx_i"]));
+            m->stage16("clstm.wh_ir", (size_t)O * hid);      // (row-major: the GEMM kernel's operand for the gate-fused per-step path)
+            clstm16_interleave_host(whs.data(), hid, hid, reinterpret_cast<bf16_t *>(m->wstage.data() + m->woff["clstm.wh_ir"]));
             {   // the hidden side also in MFMA fragment order: the kernel's weight requests are then 1 KiB of consecutive bytes
                 std::vector<bf16_t> whi((size_t)O * hid);
                 clstm16_interleave_host(whs.data(), hid, hid, whi.data());
@@ -739,8 +741,13 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         // bf16 pipeline: the T steps of a chunk in ONE launch (clstm16.hip: a 1x1 ConvLSTM is an independent LSTM per position) on
         // gate-interleaved pre-activations; otherwise a GEMM + a gate launch per step
         const bool seq = a16 && m->has("clstm.wh_i") && clstm16_seq_available((int64_t)S * rpi);
+        // small chunks: per-step launches, the cell update in the hidden-side GEMM's epilogue (igemm16 OUT_LSTM) on the same interleaved
+        // layout -- the step's fp32 pre-activations no longer go through HBM twice and the gate launch is gone
+        static const bool no_gate_fusion = getenv("EVFLY_NO_CLSTM16_GATE_FUSION") != nullptr;
+        const bool gfuse = a16 && !seq && m->has("clstm.wh_ir") && !no_gate_fusion;
+        const bool il = seq || gfuse;                              // interleaved pre-activations
         {   // input-side 1x1 conv for every frame at once
-            ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W(seq ? "clstm.wx_i" : "clstm.wx"); d.ldw = hid;
+            ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W(il ? "clstm.wx_i" : "clstm.wx"); d.ldw = hid;
             conv_finish(d); d.Nc = 4 * hid; d.y = zx; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             RUN(m, "convlstm_x_gemm", igemm_flops(d), d.M * (a16 ? 2.0 : 4.0) * hid + d.M * 16.0 * hid + (a16 ? 2.0 : 4.0) * 4.0 * hid * hid,
                 igemm_launch(d, st));
@@ -770,15 +777,21 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             const bool skip0 = t == 0 && !h_state;
             const float *zt = skip0 ? zx : z;
             const int64_t zrows = skip0 ? (int64_t)T * rpi : 0;
-            ConvDesc d; d.x = a16 ? h16 : hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W("clstm.wh"); d.ldw = hid;
+            ConvDesc d; d.x = a16 ? h16 : hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W(gfuse ? "clstm.wh_ir" : "clstm.wh"); d.ldw = hid;
             conv_finish(d); d.Nc = 4 * hid; d.y = z; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             d.res = zx + (int64_t)t * rpi * 4 * hid; d.ldres = 4 * hid; d.res_rpi = rpi; d.res_img_rows = (int64_t)T * rpi;
+            if (gfuse && !skip0) {
+                d.out_mode = OUT_LSTM; d.lstm_c = cs; d.lstm_h = hs; d.lstm_h16 = h16; d.lstm_hseq = m->eoff(hseq, (int64_t)t * rpi * hid);
+                d.lstm_seq_img_rows = (int64_t)T * rpi;
+                RUN(m, "convlstm_h_gemm", igemm_flops(d), d.M * 2.0 * hid + d.M * 16.0 * hid + d.M * (16.0 + 4.0) * hid + 2.0 * 4.0 * hid * hid, igemm_launch(d, st));
+                continue;
+            }
             if (!skip0)
             RUN(m, "convlstm_h_gemm", igemm_flops(d), d.M * (a16 ? 2.0 : 4.0) * hid + d.M * 32.0 * hid + (a16 ? 2.0 : 4.0) * 4.0 * hid * hid,
                 igemm_launch(d, st));
             if (a16)
                 RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
-                    launch16_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, h16, m->eoff(hseq, (int64_t)t * rpi * hid), rpi, (int64_t)T * rpi, st, zrows));
+                    launch16_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, h16, m->eoff(hseq, (int64_t)t * rpi * hid), rpi, (int64_t)T * rpi, st, zrows, gfuse));
             else
             RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
                 launch_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, hseq + (int64_t)t * rpi * hid, rpi, (int64_t)T * rpi, st, zrows));

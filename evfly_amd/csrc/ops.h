@@ -86,7 +86,7 @@ int launch16_bilinear(const void *x, int n, int Hi, int Wi, int C, int64_t ldx, 
 int launch16_crop(const void *x, int n, int Hi, int Wi, int C, int top, int left, void *y, int Ho, int Wo, int64_t ldy, hipStream_t st);
 // z, c, h fp32 (state updated in place); h16 = bf16 copy of h (next step's GEMM operand), h_copy = bf16 hseq row
 int launch16_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *h16, void *h_copy, int rpi,
-                            int64_t copy_img_rows, hipStream_t st, int64_t z_img_rows = 0);
+                            int64_t copy_img_rows, hipStream_t st, int64_t z_img_rows = 0, bool interleaved = false);
 int launch16_dot_out(const void *x, int64_t rows, int C, const float *w, const float *bias, float *y, hipStream_t st);
 int launch16_layernorm(const void *a, int64_t rows, int C, const float *gamma, const float *beta, void *y, hipStream_t st);
 int launch16_attention(const void *q, const void *kv, int frames, int N, int nkv, int C, int heads, void *out, hipStream_t st);

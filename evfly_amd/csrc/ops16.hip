@@ -139,18 +139,27 @@ __global__ __launch_bounds__(256) void k16_crop(const uint4 *__restrict__ x, int
 // convlstm.py:44-51 on fp32 pre-activations z [i|f|o|g] and the fp32 state (c, h updated in place); additionally the bf16
 // copies the pipeline consumes: h16 (A operand of the next step's hidden-side GEMM) and the (stream, t) row of hseq.
 __device__ __forceinline__ float sigmoid16(float v) { return 1.0f / (1.0f + expf(-v)); }
+// interleaved != 0: z's columns are gate-interleaved (column 4 cell + gate), the layout the fused ConvLSTM paths keep their pre-activations in
 __global__ __launch_bounds__(256) void k16_convlstm_gates(const float *__restrict__ z, int64_t rows, int hid, float *__restrict__ c,
                                                            float *__restrict__ h, bf16_t *__restrict__ h16, bf16_t *__restrict__ h_copy,
-                                                           int rpi, int64_t copy_img_rows, int64_t z_img_rows) {
+                                                           int rpi, int64_t copy_img_rows, int64_t z_img_rows, int interleaved) {
     const int h4 = hid / 4;
     const int64_t total = rows * h4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / h4;
         const int j = (int)(i - r * h4) * 4;
         const int64_t zrow = z_img_rows > 0 ? (r / rpi) * z_img_rows + r % rpi : r;      // (k_convlstm_gates)
-        const float *zr = z + zrow * 4 * hid + j;
-        const float4 zi = *reinterpret_cast<const float4 *>(zr), zf = *reinterpret_cast<const float4 *>(zr + hid);
-        const float4 zo = *reinterpret_cast<const float4 *>(zr + 2 * hid), zg = *reinterpret_cast<const float4 *>(zr + 3 * hid);
+        const float *zr = z + zrow * 4 * hid + (interleaved ? 4 * j : j);
+        float4 zi, zf, zo, zg;
+        if (interleaved) {      // four cells = four (i, f, o, g) vectors
+            const float4 q0 = *reinterpret_cast<const float4 *>(zr), q1 = *reinterpret_cast<const float4 *>(zr + 4);
+            const float4 q2 = *reinterpret_cast<const float4 *>(zr + 8), q3 = *reinterpret_cast<const float4 *>(zr + 12);
+            zi = make_float4(q0.x, q1.x, q2.x, q3.x); zf = make_float4(q0.y, q1.y, q2.y, q3.y);
+            zo = make_float4(q0.z, q1.z, q2.z, q3.z); zg = make_float4(q0.w, q1.w, q2.w, q3.w);
+        } else {
+            zi = *reinterpret_cast<const float4 *>(zr); zf = *reinterpret_cast<const float4 *>(zr + hid);
+            zo = *reinterpret_cast<const float4 *>(zr + 2 * hid); zg = *reinterpret_cast<const float4 *>(zr + 3 * hid);
+        }
         const float4 c0 = *reinterpret_cast<const float4 *>(c + r * hid + j);
         const float vi[4] = {zi.x, zi.y, zi.z, zi.w}, vf[4] = {zf.x, zf.y, zf.z, zf.w}, vo[4] = {zo.x, zo.y, zo.z, zo.w};
         const float vg[4] = {zg.x, zg.y, zg.z, zg.w}, vc[4] = {c0.x, c0.y, c0.z, c0.w};
@@ -464,10 +473,10 @@ int launch16_crop(const void *x, int n, int Hi, int Wi, int C, int top, int left
 }
 
 int launch16_convlstm_gates(const float *z, int64_t rows, int hid, float *c, float *h, void *h16, void *h_copy, int rpi,
-                            int64_t copy_img_rows, hipStream_t st, int64_t z_img_rows) {
+                            int64_t copy_img_rows, hipStream_t st, int64_t z_img_rows, bool interleaved) {
     EVFLY_REQUIRE(hid % 4 == 0, "gates16: hid %% 4");
     hipLaunchKernelGGL(k16_convlstm_gates, dim3(grid16(rows * hid / 4, 256)), dim3(256), 0, st, z, rows, hid, c, h, static_cast<bf16_t *>(h16),
-                       static_cast<bf16_t *>(h_copy), rpi, copy_img_rows, z_img_rows);
+                       static_cast<bf16_t *>(h_copy), rpi, copy_img_rows, z_img_rows, interleaved ? 1 : 0);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

@@ -174,32 +174,41 @@ def _clstm_seq_outputs():
             "h2": st2[0][0].float().cpu(), "c2": st2[0][1].float().cpu()}, sd, x.cpu()
 
 
-def test_convlstm_sequence_kernel_equals_per_step_launches(gpu_device, tmp_path):
-    """clstm16.hip (the T steps of a chunk in one launch: h in LDS, c in registers, weights streamed from L2, gates on the accumulators)
-    against the per-step GEMM + gate launches it replaces for large chunks. Forced for this small batch with
-    EVFLY_CLSTM16_SEQ_MIN_ROWS=0 (read once per process: subprocess); fresh state and carried state. Differences: MFMA summation
-    order inside a k step and exp2 / rcp against expf / tanhf in the gates (~1e-6) ahead of the bf16 rounding of h -- the bar is a few
-    bf16 ulps on the states, the pipeline's bound on the depth output."""
+def test_convlstm_fused_paths_equal_per_step_launches(gpu_device, tmp_path):
+    """The two fused ConvLSTM paths of the bf16 pipeline against the GEMM + gate launch per time step they replace
+    (EVFLY_NO_CLSTM16_GATE_FUSION=1, expf / tanhf gates): (a) clstm16.hip, the T steps of a chunk in one launch (h in LDS, c in registers,
+    weights streamed from L2, gates on the accumulators) -- taken from 4096 state rows on, forced for this small batch with
+    EVFLY_CLSTM16_SEQ_MIN_ROWS=0; (b) the cell update in the hidden-side GEMM's epilogue (igemm16 OUT_LSTM), the default for small chunks
+    (this process). Environment switches are read once per process: subprocesses. Fresh state and carried state. Differences: exp2 / rcp
+    against expf / tanhf in the gates (~1e-6) ahead of the bf16 rounding of h -- a few bf16 ulps on the states, the pipeline's bound on the
+    depth output."""
     import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / "seq.pt")
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import torch, test_gpu_bf16 as t\n"
-            "o, _, _ = t._clstm_seq_outputs()\n"
-            "torch.save(o, %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_CLSTM16_SEQ_MIN_ROWS="0"))
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
-    seq = torch.load(out)
-    ref, _, _ = _clstm_seq_outputs()
-    if os.environ.get("EVFLY_CLSTM16_SEQ_MIN_ROWS") is None:
-        assert not torch.equal(seq["h1"], ref["h1"])                       # the sequence kernel really ran in the child
-    for k in ("h1", "c1", "h2", "c2"):
-        assert torch.isfinite(seq[k]).all()
-        assert rel_err(seq[k], ref[k]) < 1e-2, (k, rel_err(seq[k], ref[k]))
-    for k in ("up1", "up2"):
-        assert rel_err(seq[k], ref[k]) < TOL, (k, rel_err(seq[k], ref[k]))
+
+    def child(tag, **env):
+        out = str(tmp_path / (tag + ".pt"))
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import torch, test_gpu_bf16 as t\n"
+                "o, _, _ = t._clstm_seq_outputs()\n"
+                "torch.save(o, %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+        return torch.load(out)
+
+    ref = child("steps", EVFLY_NO_CLSTM16_GATE_FUSION="1", EVFLY_NO_CLSTM16_SEQ="1")
+    seq = child("seq", EVFLY_CLSTM16_SEQ_MIN_ROWS="0")
+    fused, _, _ = _clstm_seq_outputs()
+    for got in (seq, fused):
+        for k in ("h1", "c1", "h2", "c2"):
+            assert torch.isfinite(got[k]).all()
+            assert rel_err(got[k], ref[k]) < 1e-2, (k, rel_err(got[k], ref[k]))
+        for k in ("up1", "up2"):
+            assert rel_err(got[k], ref[k]) < TOL, (k, rel_err(got[k], ref[k]))
+    # the two fused paths run the same arithmetic in the same order: same bits
+    for k in ("h1", "c1", "h2", "c2", "up1", "up2"):
+        assert torch.equal(seq[k], fused[k]), k
 
 
 @pytest.mark.parametrize("trunk", ["tiny", "base"])
