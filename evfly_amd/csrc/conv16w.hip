@@ -58,7 +58,9 @@ __device__ __forceinline__ void dma_piece(unsigned voff, i32x4 srd, unsigned sof
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
 
-template <int BP, int BC, int WP, int WC>
+// UP: the 1x1 form with the 2x2 scatter epilogue of nn.ConvTranspose2d(k = 2, s = 2) (learner_models.py:553-583: the decoder's upconvs as
+// ONE GEMM with N = 4 C_out, column (2 dy + dx) C_out + co): same tile pipeline, a K-tile is 64 input channels, weights plain [N][C]
+template <int BP, int BC, int WP, int WC, bool UP>
 __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt, int cpx) {
     static_assert(WP * WC == NW, "8 waves");
     constexpr int TP = BP / WP / 32, TC = BC / WC / 32;       // 32-wide pixel / channel MFMA tiles per wave
@@ -103,21 +105,24 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
             const int c = ls ^ ((r >> 1) & 7);
             const int m = min(m0 + r, Mi - 1);
             const int img = m / ohw, rem = m - img * ohw, oy = rem / d.OW, ox = rem - oy * d.OW;
-            xoff[i] = (unsigned)((((int64_t)img * d.H + oy) * d.W + ox) * d.ldx * 2) + (unsigned)c * 16u;
+            xoff[i] = UP ? (unsigned)((int64_t)m * d.ldx * 2) + (unsigned)c * 16u
+                         : (unsigned)((((int64_t)img * d.H + oy) * d.W + ox) * d.ldx * 2) + (unsigned)c * 16u;
         }
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int r = (wv * WPW + i) * 8 + lr;
             const int c = ls ^ ((r >> 1) & 7);
-            woff[i] = (unsigned)(n0 + r) * (unsigned)d.ldw * 2u + (unsigned)(c >> 2) * (9u * 64u) + (unsigned)(c & 3) * 16u;
+            woff[i] = UP ? (unsigned)(n0 + r) * (unsigned)d.ldw * 2u + (unsigned)c * 16u
+                         : (unsigned)(n0 + r) * (unsigned)d.ldw * 2u + (unsigned)(c >> 2) * (9u * 64u) + (unsigned)(c & 3) * 16u;
         }
     }
     // ---- K walk: tile kt = (64-channel chunk j, tap t); scalar offsets of the tile the next DMA fetches
-    const int nk = (d.C >> 6) * 9;
+    const int nk = UP ? (d.C >> 6) : (d.C >> 6) * 9;
     int kj = 0, kty = 0, ktx = 0;
-    auto soff_x = [&]() { return (unsigned)(((kty * d.W + ktx) * (int)d.ldx + 64 * kj) * 2); };
-    auto soff_w = [&]() { return (unsigned)((2 * kj * 9 + kty * 3 + ktx) * 64); };
+    auto soff_x = [&]() { return UP ? (unsigned)(128 * kj) : (unsigned)(((kty * d.W + ktx) * (int)d.ldx + 64 * kj) * 2); };
+    auto soff_w = [&]() { return UP ? (unsigned)(128 * kj) : (unsigned)((2 * kj * 9 + kty * 3 + ktx) * 64); };
     auto advance = [&]() {
+        if (UP) { ++kj; return; }
         if (++ktx == 3) { ktx = 0; if (++kty == 3) { kty = 0; ++kj; } }
     };
     auto issue = [&](int q, unsigned sx, unsigned sw, int stage, i32x4 sdx, i32x4 sdw) {       // request q of the next tile
@@ -221,9 +226,11 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int nb = n0 + (wc * TC + i) * 32;
+        // UP: the 32 columns of a channel tile lie inside one (dy, dx) quadrant (C_out a multiple of 32): bias by output channel
+        const int quad = UP ? nb / d.up_cout : 0, cb = UP ? nb - quad * d.up_cout : nb;
         float4 b4[4];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) b4[rg] = d.bias ? *reinterpret_cast<const float4 *>(d.bias + nb + 8 * rg + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int rg = 0; rg < 4; ++rg) b4[rg] = d.bias ? *reinterpret_cast<const float4 *>(d.bias + cb + 8 * rg + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int m = m0 + (wp * TP + j) * 32 + frow;
@@ -238,7 +245,12 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
             }
             // lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: after the swaps lane l owns
             // channels 0-7 and 16-23, lane l + 32 channels 8-15 and 24-31 (16 B each)
-            bf16_t *dst = y16 + (int64_t)(ok ? m : 0) * d.ldy + nb + fh * 8;
+            int64_t orow = ok ? m : 0;                         // output pixel row: UP scatters input pixel (iy, ix) to (2 iy + dy, 2 ix + dx)
+            if (UP) {
+                const int hw = d.OH * d.OW, mi = (int)orow, img = mi / hw, rem = mi - img * hw, iy = rem / d.OW, ix = rem - iy * d.OW;
+                orow = ((int64_t)img * 2 * d.OH + 2 * iy + (quad >> 1)) * (2 * d.OW) + 2 * ix + (quad & 1);
+            }
+            bf16_t *dst = y16 + orow * d.ldy + cb + fh * 8;
 #pragma unroll
             for (int grp = 0; grp < 2; ++grp) {
                 unsigned o[4];
@@ -253,11 +265,11 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
     }
 }
 
-template <int BP, int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC, bool UP = false>
 int launch16w(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv((int)d.M, BP), n_nt = d.Nc / BC, cpx = cdiv(n_mt, kNumXCD);
     const int lds = 2 * (BP + BC) * 128;
-    auto kern = k_conv16w<BP, BC, WP, WC>;
+    auto kern = k_conv16w<BP, BC, WP, WC, UP>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
@@ -281,6 +293,34 @@ bool conv16w_applicable(const ConvDesc &d) {
            d.ldw % 64 == 0 && d.ldw >= d.K && d.M >= 64 * 256 && d.M < ((int64_t)1 << 31) &&
            (int64_t)d.NI * d.H * d.W * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.Nc * d.ldw * 2 < ((int64_t)1 << 32) &&
            (!d.bias || ((uintptr_t)d.bias) % 16 == 0);
+}
+
+// the decoder's ConvTranspose2d(k = 2, s = 2) layers (up1 .. up4): 256 x 256 (192 x 128 for up4) tiles with the accumulator-direct epilogue
+// instead of igemm16's 128 x 128 with its LDS-transposed one (C5, 320 frames: up1 0.090 -> 0.061 ms, up2 0.078 -> 0.054, up3 0.089 -> 0.063,
+// up4 0.133 -> 0.095; EVFLY_NO_CONV16W_UP=1 restores the GEMM kernel)
+bool conv16w_up_applicable(const ConvDesc &d) {
+    static const bool off = getenv("EVFLY_NO_CONV16W_UP") != nullptr;
+    return !off && d.in_bf16 && d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 &&
+           d.out_mode == OUT_UPCONV2X2 && d.up_cout % 32 == 0 && d.Nc == 4 * d.up_cout && d.Nc % 128 == 0 && d.C % 64 == 0 && d.C >= 64 && !d.res &&
+           d.act == ACT_NONE && d.ldx % 8 == 0 && d.ldy % 8 == 0 && ((uintptr_t)d.x) % 16 == 0 && ((uintptr_t)d.y) % 16 == 0 && ((uintptr_t)d.w) % 16 == 0 &&
+           d.ldw % 64 == 0 && d.ldw >= d.K && d.M >= 64 * 256 && d.M < ((int64_t)1 << 31) && (int64_t)d.M * d.ldx * 2 < ((int64_t)1 << 32) &&
+           (int64_t)d.Nc * d.ldw * 2 < ((int64_t)1 << 32) && (!d.bias || ((uintptr_t)d.bias) % 16 == 0);
+}
+
+int conv16w_up_launch(const ConvDesc &d, hipStream_t st) {
+    EVFLY_REQUIRE(conv16w_up_applicable(d), "conv16w: upconv layer not eligible");
+    if (d.Nc % 256 != 0) return launch16w<192, 128, 2, 4, true>(d, st);      // up4 (64 -> 4 x 32 channels): one K-tile, two blocks per CU
+    const int nt = d.Nc / 256;
+    auto cost = [&](int bp) {
+        const double per_pixel = bp == 192 ? 1.12 : bp == 320 ? 0.94 : 1.0;
+        return (double)cdiv(cdiv((int)d.M, bp) * nt, kNumCU) * bp * per_pixel;
+    };
+    int bp = 256;
+    if (cost(192) < cost(bp)) bp = 192;
+    if (cost(320) < cost(bp)) bp = 320;
+    if (bp == 192) return launch16w<192, 256, 2, 4, true>(d, st);
+    if (bp == 320) return launch16w<320, 256, 2, 4, true>(d, st);
+    return launch16w<256, 256, 2, 4, true>(d, st);
 }
 
 int conv16w_launch(const ConvDesc &d, hipStream_t st) {

@@ -118,6 +118,9 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
 // no padding, bf16 in / out, bias + ReLU / none; reads the [Nc][ldw] bf16 GEMM weights of igemm16_launch.
 bool conv16w_applicable(const ConvDesc &d);
 int conv16w_launch(const ConvDesc &d, hipStream_t st);
+// ... and its 1x1 form with the 2x2 scatter epilogue (the decoder's ConvTranspose2d layers with C_in >= 128)
+bool conv16w_up_applicable(const ConvDesc &d);
+int conv16w_up_launch(const ConvDesc &d, hipStream_t st);
 
 // >= 256 B of zeros in global memory on the current device (source of masked LDS-DMA rows)
 int igemm_zero_page(const float **out);

@@ -861,7 +861,8 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             d.ldw = m->planning ? dc : m->wld[un]; d.bias = m->W(un + ".b");
             conv_finish(d); d.Nc = 4 * co; d.y = up_dst; d.ldy = ccat; d.out_mode = OUT_UPCONV2X2; d.up_cout = co;
             d.dtype = c.compute_dtype; d.in_bf16 = d.out_bf16 = a16;
-            RUN(m, ("upconv2x2/" + un).c_str(), igemm_flops(d), (a16 ? 2.0 : 4.0) * F * dh * dw * (dc + 4.0 * co), igemm_launch(d, st));
+            RUN(m, ("upconv2x2/" + un).c_str(), igemm_flops(d), (a16 ? 2.0 : 4.0) * F * dh * dw * (dc + 4.0 * co),
+                (a16 && !m->planning && conv16w_up_applicable(d)) ? conv16w_up_launch(d, st) : igemm_launch(d, st));
         }
         float *a = m->alloc_act((int64_t)F * (uh - 2) * (uw - 2) * co);
         const std::string n1 = "d" + std::to_string(l) + "1", n2 = "d" + std::to_string(l) + "2";
