@@ -60,8 +60,11 @@ __device__ __forceinline__ void dma_piece(unsigned voff, i32x4 srd, unsigned sof
 
 // UP: the 1x1 form with the 2x2 scatter epilogue of nn.ConvTranspose2d(k = 2, s = 2) (learner_models.py:553-583: the decoder's upconvs as
 // ONE GEMM with N = 4 C_out, column (2 dy + dx) C_out + co): same tile pipeline, a K-tile is 64 input channels, weights plain [N][C]
-template <int BP, int BC, int WP, int WC, bool UP>
+// MODE 2: a plain GEMM (1x1, row-major fp32 output, optional bias): the ConvLSTM's input-side pre-activations for all frames at once
+template <int BP, int BC, int WP, int WC, int MODE>
 __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt, int cpx) {
+    constexpr bool UP = MODE != 0;                            // 1x1 K walk and addressing (MODE 1: the 2x2 scatter epilogue on top)
+    constexpr bool SCATTER = MODE == 1, F32OUT = MODE == 2;
     static_assert(WP * WC == NW, "8 waves");
     constexpr int TP = BP / WP / 32, TC = BC / WC / 32;       // 32-wide pixel / channel MFMA tiles per wave
     constexpr int XPW = BP / 64, WPW = BC / 64;               // 1-KiB DMA pieces per wave and K-tile (8 rows each)
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
     for (int i = 0; i < TC; ++i) {
         const int nb = n0 + (wc * TC + i) * 32;
         // UP: the 32 columns of a channel tile lie inside one (dy, dx) quadrant (C_out a multiple of 32): bias by output channel
-        const int quad = UP ? nb / d.up_cout : 0, cb = UP ? nb - quad * d.up_cout : nb;
+        const int quad = SCATTER ? nb / d.up_cout : 0, cb = SCATTER ? nb - quad * d.up_cout : nb;
         float4 b4[4];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) b4[rg] = d.bias ? *reinterpret_cast<const float4 *>(d.bias + cb + 8 * rg + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -235,6 +238,16 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
         for (int j = 0; j < TP; ++j) {
             const int m = m0 + (wp * TP + j) * 32 + frow;
             const bool ok = m < Mi;
+            if constexpr (F32OUT) {      // channel quads {0-3, 8-11, 16-19, 24-27} + 4 fh of the lane's pixel: 16-B stores of four fp32 values
+                float *dst32 = d.y + (int64_t)(ok ? m : 0) * d.ldy + nb + 4 * fh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o = make_float4(acc[i][j][4 * q] + b4[q].x, acc[i][j][4 * q + 1] + b4[q].y, acc[i][j][4 * q + 2] + b4[q].z, acc[i][j][4 * q + 3] + b4[q].w);
+                    if (relu) { o.x = o.x < 0.f ? 0.f : o.x; o.y = o.y < 0.f ? 0.f : o.y; o.z = o.z < 0.f ? 0.f : o.z; o.w = o.w < 0.f ? 0.f : o.w; }
+                    if (ok) *reinterpret_cast<float4 *>(dst32 + 8 * q) = o;
+                }
+                continue;
+            }
             unsigned pk[8];
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
             // lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: after the swaps lane l owns
             // channels 0-7 and 16-23, lane l + 32 channels 8-15 and 24-31 (16 B each)
             int64_t orow = ok ? m : 0;                         // output pixel row: UP scatters input pixel (iy, ix) to (2 iy + dy, 2 ix + dx)
-            if (UP) {
+            if (SCATTER) {
                 const int hw = d.OH * d.OW, mi = (int)orow, img = mi / hw, rem = mi - img * hw, iy = rem / d.OW, ix = rem - iy * d.OW;
                 orow = ((int64_t)img * 2 * d.OH + 2 * iy + (quad >> 1)) * (2 * d.OW) + 2 * ix + (quad & 1);
             }
@@ -265,11 +278,11 @@ __global__ __launch_bounds__(512) void k_conv16w(ConvDesc d, int n_mt, int n_nt,
     }
 }
 
-template <int BP, int BC, int WP, int WC, bool UP = false>
+template <int BP, int BC, int WP, int WC, int MODE = 0>
 int launch16w(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv((int)d.M, BP), n_nt = d.Nc / BC, cpx = cdiv(n_mt, kNumXCD);
     const int lds = 2 * (BP + BC) * 128;
-    auto kern = k_conv16w<BP, BC, WP, WC, UP>;
+    auto kern = k_conv16w<BP, BC, WP, WC, MODE>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
@@ -309,7 +322,7 @@ bool conv16w_up_applicable(const ConvDesc &d) {
 
 int conv16w_up_launch(const ConvDesc &d, hipStream_t st) {
     EVFLY_REQUIRE(conv16w_up_applicable(d), "conv16w: upconv layer not eligible");
-    if (d.Nc % 256 != 0) return launch16w<192, 128, 2, 4, true>(d, st);      // up4 (64 -> 4 x 32 channels): one K-tile, two blocks per CU
+    if (d.Nc % 256 != 0) return launch16w<192, 128, 2, 4, 1>(d, st);      // up4 (64 -> 4 x 32 channels): one K-tile, two blocks per CU
     const int nt = d.Nc / 256;
     auto cost = [&](int bp) {
         const double per_pixel = bp == 192 ? 1.12 : bp == 320 ? 0.94 : 1.0;
@@ -318,9 +331,35 @@ int conv16w_up_launch(const ConvDesc &d, hipStream_t st) {
     int bp = 256;
     if (cost(192) < cost(bp)) bp = 192;
     if (cost(320) < cost(bp)) bp = 320;
-    if (bp == 192) return launch16w<192, 256, 2, 4, true>(d, st);
-    if (bp == 320) return launch16w<320, 256, 2, 4, true>(d, st);
-    return launch16w<256, 256, 2, 4, true>(d, st);
+    if (bp == 192) return launch16w<192, 256, 2, 4, 1>(d, st);
+    if (bp == 320) return launch16w<320, 256, 2, 4, 1>(d, st);
+    return launch16w<256, 256, 2, 4, 1>(d, st);
+}
+
+// plain bf16 GEMMs with fp32 rows out and a long M (the ConvLSTM's input-side GEMM: 33 k .. 66 k rows x 2048 x 512): C5 0.17 -> 0.13 ms, C3 1.60 -> 1.27
+// (its 273 MB of fp32 output per 320 frames is the floor; EVFLY_NO_CONV16W_GEMM=1 restores the 128 x 128 kernel)
+bool conv16w_gemm_applicable(const ConvDesc &d) {
+    static const bool off = getenv("EVFLY_NO_CONV16W_GEMM") != nullptr;
+    return !off && d.in_bf16 && !d.out_bf16 && d.dtype == EVFLY_DTYPE_BF16 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 &&
+           d.out_mode == OUT_ROWS && d.Nc % 256 == 0 && d.C % 64 == 0 && d.C >= 128 && !d.res && (d.act == ACT_NONE || d.act == ACT_RELU) &&
+           d.ldx % 8 == 0 && d.ldy % 4 == 0 && ((uintptr_t)d.x) % 16 == 0 && ((uintptr_t)d.y) % 16 == 0 && ((uintptr_t)d.w) % 16 == 0 && d.ldw % 64 == 0 &&
+           d.ldw >= d.K && d.M >= 64 * 256 && d.M < ((int64_t)1 << 31) && (int64_t)d.M * d.ldx * 2 < ((int64_t)1 << 32) &&
+           (int64_t)d.Nc * d.ldw * 2 < ((int64_t)1 << 32) && (!d.bias || ((uintptr_t)d.bias) % 16 == 0);
+}
+
+int conv16w_gemm_launch(const ConvDesc &d, hipStream_t st) {
+    EVFLY_REQUIRE(conv16w_gemm_applicable(d), "conv16w: GEMM not eligible");
+    const int nt = d.Nc / 256;
+    auto cost = [&](int bp) {
+        const double per_pixel = bp == 192 ? 1.12 : bp == 320 ? 0.94 : 1.0;
+        return (double)cdiv(cdiv((int)d.M, bp) * nt, kNumCU) * bp * per_pixel;
+    };
+    int bp = 256;
+    if (cost(192) < cost(bp)) bp = 192;
+    if (cost(320) < cost(bp)) bp = 320;
+    if (bp == 192) return launch16w<192, 256, 2, 4, 2>(d, st);
+    if (bp == 320) return launch16w<320, 256, 2, 4, 2>(d, st);
+    return launch16w<256, 256, 2, 4, 2>(d, st);
 }
 
 int conv16w_launch(const ConvDesc &d, hipStream_t st) {

@@ -121,6 +121,9 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st);
 // ... and its 1x1 form with the 2x2 scatter epilogue (the decoder's ConvTranspose2d layers with C_in >= 128)
 bool conv16w_up_applicable(const ConvDesc &d);
 int conv16w_up_launch(const ConvDesc &d, hipStream_t st);
+// ... and as a plain bf16 GEMM with fp32 rows out (long M, N a multiple of 256)
+bool conv16w_gemm_applicable(const ConvDesc &d);
+int conv16w_gemm_launch(const ConvDesc &d, hipStream_t st);
 
 // >= 256 B of zeros in global memory on the current device (source of masked LDS-DMA rows)
 int igemm_zero_page(const float **out);

@@ -750,7 +750,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W(il ? "clstm.wx_i" : "clstm.wx"); d.ldw = hid;
             conv_finish(d); d.Nc = 4 * hid; d.y = zx; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             RUN(m, "convlstm_x_gemm", igemm_flops(d), d.M * (a16 ? 2.0 : 4.0) * hid + d.M * 16.0 * hid + (a16 ? 2.0 : 4.0) * 4.0 * hid * hid,
-                igemm_launch(d, st));
+                (a16 && !m->planning && conv16w_gemm_applicable(d)) ? conv16w_gemm_launch(d, st) : igemm_launch(d, st));
         }
         float *z = m->alloc((int64_t)S * rpi * 4 * hid);
         float *hseq = m->alloc_act((int64_t)F * rpi * hid);
