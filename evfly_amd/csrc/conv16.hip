@@ -71,8 +71,11 @@ __device__ __forceinline__ int patch_off(int q, int c) { return q * 64 + ((c ^ (
 // (learner_models.py:476-494,533; C_in = 32, one frame channel), computed by the VALU from a staged frame patch while
 // the matrix cores work on the previous tile -- the 32-channel e11 map (11 MB per frame in fp32, 5.7 MB in bf16) never
 // exists in HBM. Same fmaf order as k16_e11 and the same single bf16 rounding: bitwise the unfused result.
-template <int ROWS, int NTB, bool POOL, bool PRE>
+// DOT: a 1x1 consumer with one output channel in the epilogue (the U-Net's unet_out on d42's output, learner_models.py:583):
+// dot_y[pixel] = dot_b[0] + sum_c dot_w[c] * bf16(act(y)[pixel][c]) INSTEAD of the 32-channel map, which is then never written
+template <int ROWS, int NTB, bool POOL, bool PRE, bool DOT = false>
 __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const bf16_t *__restrict__ wd) {
+    static_assert(!DOT || (NTB == 1 && !POOL && !PRE), "the fused 1x1 consumer is built for the plain one-channel-tile variants");
     constexpr int TH = NWAVE * ROWS, PH = TH + 2, NPIX = PH * PWD;
     constexpr int FH = PH + 2, FW = PWD + 2, FPIX = FH * FW;           // PRE: frame patch behind the weights, double-buffered
     constexpr int NPIECE = (NPIX * 64 + 1023) / 1024;          // 1-KiB DMA pieces per patch
@@ -309,6 +312,14 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y16, 0, (int)(unsigned)((int64_t)d.NI * d.OH * d.OW * d.ldy * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
         POOL ? reinterpret_cast<bf16_t *>(g.y_pool) : y16, 0, POOL ? (int)(unsigned)((int64_t)d.NI * (d.OH / 2) * (d.OW / 2) * d.Nc * 2) : 0, 0x00020000);
+    // DOT: the lane's 16 consumer weights (its channels (e & 3) + 8 (e >> 2) + 4 fh) and the result of each of its rows
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(DOT ? d.dot_y : reinterpret_cast<float *>(y16), 0,
+                                                                        DOT ? (int)(unsigned)((int64_t)d.NI * d.OH * d.OW * 4) : 0, 0x00020000);
+    float dw[DOT ? 16 : 1], dq[DOT ? ROWS : 1];
+    if constexpr (DOT) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dw[e] = d.dot_w[(e & 3) + 8 * (e >> 2) + 4 * fh];
+    }
     // The finished tile is packed (bias, activation, bf16, pool) behind its MFMAs, STAGED (lane swaps, byte offsets) at the top of
     // the next step and stored during that step: with one block per CU nothing else hides the stores' acknowledgement (round 3:
     // 12 k cycles per step for 2.3 k cycles of MFMAs when the step-closing wait covered them), and -- PRE, round 4 -- issuing a
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     unsigned pk[ROWS][NTB][8];           // packed bf16 pairs of the finished tile: [row][n-tile][r-group 0..3][dword 0..1]
     unsigned pm[POOL ? NTB : 1][8];
     int st_tile = -1;
-    constexpr int NST_Y = ROWS * NTB * 2, NST = NST_Y + (POOL ? NTB * 2 : 0);     // 16-B stores per lane and tile
+    constexpr int NST_Y = DOT ? ROWS : ROWS * NTB * 2, NST = NST_Y + (POOL ? NTB * 2 : 0);     // stores per lane and tile (16 B; DOT: 4 B per row)
     // SPREAD: the previous tile's stores are issued one or two per fragment-loop iteration instead of in one burst at the top of the
     // step (a burst held every wave ~2 k (e12) .. 4.4 k (e21) cycles in the store issue, tools/conv16_ts*.py). Measured per variant in the
     // C5 step: e12 0.91 -> 0.86 ms, e21 0.379 -> 0.348, e31 0.265 -> 0.259 -- but e22 (two chunks, pool: 12 stores) 0.575 -> 0.68 and the
@@ -335,7 +346,9 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int oy = oy0 + r;
-            st_off[r] = (col_ok && oy < d.OH) ? (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2) : OOB;
+            st_off[r] = !(col_ok && oy < d.OH) ? OOB
+                        : DOT ? (fh == 0 ? (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * 4) : OOB)        // (one lane of the pair stores the pixel's value)
+                              : (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2);
         }
         st_off[ROWS] = OOB;
         if constexpr (POOL && ROWS == 2) {
@@ -354,6 +367,10 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             if (k < k0 || k >= k1) continue;
+            if constexpr (DOT) {      // store k = row k's value
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dq[k < ROWS ? k : 0]), dr, (int)st_off[k < ROWS ? k : 0], 0, 0);
+                continue;
+            }
             const bool pool = k >= NST_Y;
             const int kk = pool ? k - NST_Y : k, grp = kk & 1, j = (kk >> 1) % NTB, r = (kk >> 1) / NTB;
             const unsigned(&p)[8] = pool ? pm[POOL ? j : 0] : pk[r][j];
@@ -481,6 +498,19 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                         if constexpr (!(kAbl16 & 32)) { v0 = (relu && v0 <= 0.f) ? 0.f : v0; v1 = (relu && v1 <= 0.f) ? 0.f : v1; }
                         pk[r][j][e >> 1] = pack_bf2(v0, v1);
                     }
+            if constexpr (DOT) {
+                const float db = d.dot_b[0];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    float sd = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {      // the ROUNDED outputs, like the stand-alone kernel reads them from the bf16 map
+                        sd = fmaf(bf_lo(pk[r][0][e >> 1]), dw[e], sd);
+                        sd = fmaf(bf_hi(pk[r][0][e >> 1]), dw[e + 1], sd);
+                    }
+                    dq[r] = (sd + __shfl_xor(sd, 32)) + db;
+                }
+            }
             if constexpr (POOL && ROWS == 2) {
                 // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes (one DPP
                 // quad permute per packed pair: no LDS round trip). The max of bf16-rounded values is the rounded max (rounding is
@@ -537,11 +567,11 @@ namespace evfly {
 namespace {
 #endif
 
-template <int ROWS, int NTB, bool POOL, bool PRE>
+template <int ROWS, int NTB, bool POOL, bool PRE, bool DOT = false>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
     const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + NTB * 128 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0);
-    auto kern = k_conv16<ROWS, NTB, POOL, PRE>;
+    auto kern = k_conv16<ROWS, NTB, POOL, PRE, DOT>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
@@ -615,6 +645,12 @@ int conv16_pack_device(const float *w_otc, int cout, int cin, void *out, hipStre
 }
 
 // y_pool: optional bf16 (NI, OH / 2, OW / 2, Nc) 2x2 max pool of the activated output
+// d.dot_w / dot_b / dot_y set: a 32-channel output with nothing else fused and 32-bit byte offsets
+bool conv16_dot_fusable(const ConvDesc &d) {
+    static const bool off = getenv("EVFLY_NO_OUT16_FUSION") != nullptr;
+    return !off && d.Nc == 32 && !d.pre_frames && d.dot_w && d.dot_b && d.dot_y && (int64_t)d.NI * d.OH * d.OW * 4 < ((int64_t)1 << 32);
+}
+
 int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t st) {
     EVFLY_REQUIRE(conv16_applicable(d), "conv16: layer not eligible");
     const int ntb = conv16_ntb(d.Nc);
@@ -638,6 +674,10 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
         EVFLY_REQUIRE(d.C == 32 && d.pre_cin == 1 && d.pre_w && d.pre_b && ntb == 1 && rows == 2, "conv16: the fused first-conv producer needs C_in = 32, "
                       "one frame channel and C_out = 32");
         return pool ? launch16d<2, 1, true, true>(d, g, w, st) : launch16d<2, 1, false, true>(d, g, w, st);
+    }
+    if (d.dot_y) {          // unet_out in the epilogue instead of the 32-channel map (the caller checked conv16_dot_fusable)
+        EVFLY_REQUIRE(conv16_dot_fusable(d) && !pool, "conv16: this layer cannot take the 1x1 consumer");
+        return rows == 2 ? launch16d<2, 1, false, false, true>(d, g, w, st) : launch16d<1, 1, false, false, true>(d, g, w, st);
     }
     if (rows == 2) {
         if (ntb == 2) return pool ? launch16d<2, 2, true, false>(d, g, w, st) : launch16d<2, 2, false, false>(d, g, w, st);

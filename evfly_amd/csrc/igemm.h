@@ -113,6 +113,8 @@ size_t conv16_weight_elems(int cout, int cin, int ntb);
 void conv16_pack_host(const float *w_oihw, int cout, int cin, unsigned short *out);
 int conv16_pack_device(const float *w_otc, int cout, int cin, void *out, hipStream_t st);
 int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t st);
+// d.dot_w / dot_b / dot_y set: can this layer's kernel apply the 1x1 one-channel consumer in its epilogue (and skip the map)?
+bool conv16_dot_fusable(const ConvDesc &d);
 
 // Wide-tile implicit GEMM of the bf16 pipeline for the deep 3x3 layers (conv16w.hip): C % 64 == 0, C >= 128, Nc % 128 == 0, stride 1,
 // no padding, bf16 in / out, bias + ReLU / none; reads the [Nc][ldw] bf16 GEMM weights of igemm16_launch.

@@ -634,6 +634,11 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     }
     if (f16 == IO16 && m->has(wname + ".wd") && (m->planning || conv16_applicable(d))) {   // bf16 pipeline, C_in <= 64: direct conv from an LDS patch
         if (pool_fused) *pool_fused = y_pool != nullptr;
+        if (want_dot && !y_pool && !skip_y && !m->planning) {      // 1x1 consumer in the epilogue instead of the map
+            d.dot_w = m->dot.w; d.dot_b = m->dot.b; d.dot_y = dot_y;
+            if (conv16_dot_fusable(d)) { m->dot.done = true; m->dot_used = true; }
+            else d.dot_w = d.dot_b = nullptr, d.dot_y = nullptr;
+        }
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes + (y_pool ? 0.5 * d.M * cout : 0.0), conv16_launch(d, m->W(wname + ".wd"), y_pool, m->st));
         return 0;
     }
@@ -869,7 +874,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         if (int rc = conv(m, "conv3x3", n1, cat, F, uh, uw, ccat, ccat, co, 3, 3, 1, 0, ACT_RELU, nullptr, 0, a, co, nullptr, nullptr, nullptr,
                           0, 0, 0, nullptr, io)) return rc;
         float *b = m->alloc_act((int64_t)F * (uh - 4) * (uw - 4) * co);
-        if (l == 4 && !a16 && !m->full_encoder_outputs && !no_dot_fuse) {      // unet_out in d42's epilogue (fp32 Winograd path)
+        if (l == 4 && !m->full_encoder_outputs && !no_dot_fuse) {      // unet_out in d42's epilogue (fp32: Winograd kernel; bf16: conv16.hip)
             up_fused = upconv_out ? upconv_out : m->alloc((int64_t)F * 68 * 148);
             m->dot.w = m->W("out.w"); m->dot.b = m->W("out.b"); m->dot.y = up_fused;
         }

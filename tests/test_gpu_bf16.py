@@ -121,9 +121,12 @@ TOL = 3e-2      # bf16 pipeline vs the fp32 oracle, max|a - b| / max|b|  (bf16 h
 
 @pytest.mark.parametrize("kw", [dict(skip_type="interp", form_BEV=2), dict(skip_type="crop", form_BEV=0),
                                 dict(skip_type="none", form_BEV=1, num_recurrent=[0, 0])])
-def test_unet_bf16_pipeline_layers(gpu_device, kw):
+def test_unet_bf16_pipeline_layers(gpu_device, kw, monkeypatch):
     """Per-layer taps of the bf16 pipeline against the fp32 oracle: localises a wrong bf16 kernel (pool, skip resample /
-    crop, transposed conv scatter, gate kernel) instead of letting it hide in the end-to-end bound."""
+    crop, transposed conv scatter, gate kernel) instead of letting it hide in the end-to-end bound. (Complete maps for the taps:
+    by default unet_out runs in d42's epilogue and the 32-channel map "d4" is never written --
+    test_out16_fused_equals_dot_kernel covers that path.)"""
+    monkeypatch.setenv("EVFLY_FULL_ENCODER_OUTPUTS", "1")        # read when the native handle is created
     net, sd = _unet(gpu_device, **kw)
     x = cond_frames(71, 3)
     _, (depth, up, (st, _)) = net([x.clone().to(gpu_device), None, None])
@@ -145,6 +148,34 @@ def test_unet_bf16_pipeline_layers(gpu_device, kw):
     assert rel_err(up.cpu(), up_ref) < TOL and rel_err(depth.cpu(), d_ref) < TOL
     if st is not None:
         assert rel_err(st[0][0].cpu(), st_ref[0][0]) < TOL and rel_err(st[0][1].cpu(), st_ref[0][1]) < TOL
+
+
+def _unet_depth_outputs():
+    net, _ = _unet("cuda")
+    x = cond_frames(74, 5).cuda()
+    d, (_, up, (st, _)) = net([x.clone(), None, None])
+    return {"depth": d.float().cpu(), "up": up.float().cpu()}
+
+
+def test_out16_fused_equals_dot_kernel(gpu_device, tmp_path):
+    """unet_out (1x1, 32 -> 1; learner_models.py:583) in the epilogue of d42's kernel (conv16.hip DOT: the dot product over the ROUNDED
+    outputs, the 32-channel map never written) against the stand-alone kernel over the bf16 map (EVFLY_NO_OUT16_FUSION=1, read once per
+    process: subprocess). Same products, a different fp32 summation order: 1e-5 of the output range."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "dot.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, test_gpu_bf16 as t\n"
+            "torch.save(t._unet_depth_outputs(), %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_NO_OUT16_FUSION="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+    ref = torch.load(out)
+    got = _unet_depth_outputs()
+    for k in ("depth", "up"):
+        assert torch.isfinite(got[k]).all()
+        assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
 
 
 def test_unet_bf16_stateful_split_equals_one_call(gpu_device):
