@@ -380,7 +380,9 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             g1.record(); torch.cuda.synchronize()
             gather_us = round(1e3 * g0.elapsed_time(g1) / 50, 2)
     if composite:
-        assert out_dev.shape == (world * B * T, 3) and torch.isfinite(vel_host).all() and torch.equal(vel_host, out_dev.cpu())
+        assert out_dev.shape == (world * B * T, 3), f"velocity rows {tuple(out_dev.shape)}"
+        assert torch.isfinite(vel_host).all(), f"{int((~torch.isfinite(vel_host)).sum())} non-finite velocity values"
+        assert torch.equal(vel_host, out_dev.cpu()), "published host copy differs from the device rows"
     else:
         assert out_dev.shape == (B * T, 1, H, W) and torch.isfinite(out_dev).all()
 

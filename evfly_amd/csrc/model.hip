@@ -768,7 +768,11 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             }
         }
         // bf16 pipeline: the hidden-side GEMM reads a bf16 copy of h that the gate kernel keeps beside the fp32 state
+        // The per-step path keeps TWO copies and alternates: with the cell update in the GEMM's epilogue (OUT_LSTM) the launch that
+        // reads h(t - 1) as its A operand also writes h(t), and a block that starts late -- a grid of more blocks than the chip holds, or
+        // a chip shared with another stream's kernels -- must not find rows its neighbours have already replaced
         float *h16 = a16 ? m->alloc_act((int64_t)S * rpi * hid) : nullptr;
+        float *h16_alt = a16 && !seq ? m->alloc_act((int64_t)S * rpi * hid) : nullptr;
         if (a16 && !m->planning) {
             if (int rc = launch_f32_to_bf16(hs, (int64_t)S * rpi * hid, h16, st)) return rc;
         }
@@ -782,11 +786,17 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             const bool skip0 = t == 0 && !h_state;
             const float *zt = skip0 ? zx : z;
             const int64_t zrows = skip0 ? (int64_t)T * rpi : 0;
-            ConvDesc d; d.x = a16 ? h16 : hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W(gfuse ? "clstm.wh_ir" : "clstm.wh"); d.ldw = hid;
+            float *h16_in = h16, *h16_out = a16 ? h16_alt : nullptr;      // step t reads h16_in, writes h16_out
+#ifdef EVFLY_CLSTM_INPLACE_H16      // (variant build only: the single-copy form, to show that the test below it catches the hazard)
+            h16_out = h16;
+#else
+            std::swap(h16, h16_alt);
+#endif
+            ConvDesc d; d.x = a16 ? h16_in : hs; d.ldx = hid; d.NI = S * rpi; d.C = hid; d.w = m->W(gfuse ? "clstm.wh_ir" : "clstm.wh"); d.ldw = hid;
             conv_finish(d); d.Nc = 4 * hid; d.y = z; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             d.res = zx + (int64_t)t * rpi * 4 * hid; d.ldres = 4 * hid; d.res_rpi = rpi; d.res_img_rows = (int64_t)T * rpi;
             if (gfuse && !skip0) {
-                d.out_mode = OUT_LSTM; d.lstm_c = cs; d.lstm_h = hs; d.lstm_h16 = h16; d.lstm_hseq = m->eoff(hseq, (int64_t)t * rpi * hid);
+                d.out_mode = OUT_LSTM; d.lstm_c = cs; d.lstm_h = hs; d.lstm_h16 = h16_out; d.lstm_hseq = m->eoff(hseq, (int64_t)t * rpi * hid);
                 d.lstm_seq_img_rows = (int64_t)T * rpi;
                 RUN(m, "convlstm_h_gemm", igemm_flops(d), d.M * 2.0 * hid + d.M * 16.0 * hid + d.M * (16.0 + 4.0) * hid + 2.0 * 4.0 * hid * hid, igemm_launch(d, st));
                 continue;
@@ -796,7 +806,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
                 igemm_launch(d, st));
             if (a16)
                 RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
-                    launch16_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, h16, m->eoff(hseq, (int64_t)t * rpi * hid), rpi, (int64_t)T * rpi, st, zrows, gfuse));
+                    launch16_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, h16_out, m->eoff(hseq, (int64_t)t * rpi * hid), rpi, (int64_t)T * rpi, st, zrows, gfuse));
             else
             RUN(m, "convlstm_gates", 0, 4.0 * S * rpi * hid * 8,
                 launch_convlstm_gates(zt, (int64_t)S * rpi, hid, cs, hs, hseq + (int64_t)t * rpi * hid, rpi, (int64_t)T * rpi, st, zrows));

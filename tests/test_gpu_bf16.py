@@ -242,6 +242,42 @@ def test_convlstm_fused_paths_equal_per_step_launches(gpu_device, tmp_path):
         assert torch.equal(seq[k], fused[k]), k
 
 
+def test_convlstm_gate_fused_gemm_keeps_two_copies_of_h(gpu_device):
+    """igemm16's OUT_LSTM epilogue writes h(t) from the launch that reads h(t - 1) as its A operand: the model alternates between two
+    bf16 copies of h. With ONE copy a block that starts after its row block's neighbours have finished reads rows that are already
+    replaced -- which happens as soon as the chip is shared with another stream's kernels (found with `bench.py --config C3` on two
+    streams at EVFLY_CHUNK_FRAMES=320: the pipelined steps' depth maps differed from the one-stream ones in a third of the frames;
+    alone on the chip the blocks of a row block start and finish together and nothing shows). Here: 32 streams x 10 windows (3 328
+    state rows: the per-step path) alone, then three times while the ViT-base velocity model works on 1 280 frames on a side stream --
+    depth maps and states bit-identical. (`tools/scripts/build_variant.sh inplace model.hip -DEVFLY_CLSTM_INPLACE_H16` builds the
+    one-copy form this test fails on.)"""
+    import evfly_amd.vitfly_models as vm
+    net, _ = _unet(gpu_device)
+    vit = vm.LSTMNetVIT(**vm.BASE)
+    vit.load_state_dict(syn.fill_state_dict(vit.state_dict(), "vitfly_vitlstm."))
+    vit.set_compute_dtype("bf16")
+    vit = vit.to(gpu_device).eval()
+    S, T = 32, 10
+    x = cond_frames(21, 8).repeat(S * T // 8, 1, 1, 1)
+    x = (x * torch.linspace(0.5, 1.0, S * T).view(-1, 1, 1, 1)).to(gpu_device)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big = torch.rand(1280, 1, 260, 346, device=gpu_device, generator=g)
+    desvel = torch.full((1280, 1), 4.0, device=gpu_device)
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        d0, _, st0 = net.forward_streams(x, None, S, T)
+        vit._run([big, desvel, None], 128, 10, clip2x=1)        # (handle and arena built outside the overlapped region)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            with torch.cuda.stream(side):
+                vit._run([big, desvel, None], 128, 10, clip2x=1)
+            d1, _, st1 = net.forward_streams(x, None, S, T)
+            torch.cuda.synchronize()
+            bad = (d0 != d1).flatten(1).any(1).nonzero().flatten()
+            assert bad.numel() == 0, (rep, bad.numel(), bad[:10].tolist())
+            assert torch.equal(st0[0][0], st1[0][0]) and torch.equal(st0[0][1], st1[0][1])
+
+
 @pytest.mark.parametrize("trunk", ["tiny", "base"])
 def test_vit_bf16_pipeline(gpu_device, trunk):
     import evfly_amd.vitfly_models as vm
