@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "bf16.h"
@@ -296,7 +297,261 @@ int launch16w(const ConvDesc &d, hipStream_t st) {
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_conv16p: the same contraction with the input pixels staged ONCE per 32-channel half-chunk instead of once per tap. k_conv16w
+// fetches a 256-pixel x 64-channel tile per tap (nine shifted copies of almost the same pixels) and is bound by the CU's global ->
+// LDS path (~22 B/clk with the data in cache): 64 KB per 2048 matrix-pipe cycles. Here a block keeps the PATCH of its pixel run -- the
+// flat range of input pixels [base(m0), base(m_last) + 2 W + 2] of the padded map, 64 B per pixel -- in LDS, and a tap is a row
+// offset dy W + dx into it. K-tile = (32-channel half-chunk h, kernel row dy): 96 deep, its weights are the 192 contiguous bytes
+// (h, 3 dy .. 3 dy + 2, 0 .. 31) of every output channel's K row, laid out as three [BC][64 B] arrays (one per dx). Per K-tile the
+// CU takes 3 BC 64 B of weights + a third of the next patch: 57.6 KB per 3072 matrix-pipe cycles at 256 x 256 (0.6 of k_conv16w's
+// bytes per flop). Two patch stages + two weight stages, one raw barrier per K-tile, requests behind every second MFMA.
+// LDS rows are 64 B: 16-B chunk c of row r sits in slot c ^ ((r >> 2) & 3) (16 consecutive rows x one chunk = 16 distinct 16-B
+// bank groups). Sub-step (dx, e) of a K-tile consumes chunks 2e (lanes 0-31) / 2e + 1 (lanes 32-63) of both operands.
+template <int BP, int BC, int WP, int WC>
+__global__ __launch_bounds__(512) void k_conv16p(ConvDesc d, int n_mt, int n_nt, int cpx, int npp) {
+    static_assert(WP * WC == NW, "8 waves");
+    constexpr int TP = BP / WP / 32, TC = BC / WC / 32;
+    constexpr int WSB = 3 * BC * 64;                           // weight stage: [dx][BC rows][64 B]
+    constexpr int WG = BC / 16;                                // 16-row groups (1-KiB DMA pieces) per dx
+    constexpr int WU = (WG + NW - 1) / NW;                     // ... per wave
+    constexpr int PPK = 3;                                     // patch pieces per wave and K-tile (host: npp <= 8 * 9)
+    constexpr int NREQ = 3 * WU + PPK, NMFMA = 6 * TP * TC;
+    static_assert(2 * NREQ <= NMFMA, "one request behind every second MFMA");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
+    const int psb = npp * 1024;                                // patch stage bytes
+
+    const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
+    const int mt = xcd * cpx + slot / n_nt, nt = slot % n_nt;
+    if (mt >= n_mt) return;
+    const int m0 = mt * BP, n0 = nt * BC;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wv / WC, wc = wv % WC;
+    const int pr = lane >> 2, sc = lane & 3, lc = sc ^ (pr >> 2);      // DMA: row inside a 16-row piece, slot, logical chunk
+    const int frow = lane & 31, fh = lane >> 5;
+    const int Mi = (int)d.M, ohw = d.OH * d.OW;
+    auto base_of = [&](int m) {
+        const int img = m / ohw, rem = m - img * ohw, oy = rem / d.OW, ox = rem - oy * d.OW;
+        return (img * d.H + oy) * d.W + ox;
+    };
+    const int p0 = __builtin_amdgcn_readfirstlane(base_of(m0));
+    // pieces THIS block's run needs (npp is the bound over all tiles: a run that crosses neither many rows nor an image needs fewer)
+    const int npb = __builtin_amdgcn_readfirstlane(min(npp, (base_of(min(m0 + BP, Mi) - 1) - p0 + 2 * d.W + 3 + 15) >> 4));
+
+    i32x4 srdx, srdw;
+    {
+        const uint64_t xb = (uint64_t)(uintptr_t)d.x, wb = (uint64_t)(uintptr_t)d.w_patch;
+        const unsigned xbytes = (unsigned)((int64_t)d.NI * d.H * d.W * d.ldx * 2), wbytes = (unsigned)((int64_t)9 * d.C * d.Nc * 2);
+        srdx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        srdx[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffff));
+        srdx[2] = __builtin_amdgcn_readfirstlane((int)xbytes);
+        srdx[3] = 0x00020000;
+        srdw[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wb);
+        srdw[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(wb >> 32) & 0xffff));
+        srdw[2] = __builtin_amdgcn_readfirstlane((int)wbytes);
+        srdw[3] = 0x00020000;
+    }
+    // patch piece q = wv + 8 i: rows 16 q .. 16 q + 15 of the patch = input pixels p0 + row (past the tensor: zeros, never multiplied
+    // into a stored output); the piece index and the half-chunk are the instruction's scalar offset
+    const unsigned voff_p = (unsigned)(p0 + wv * 16 + pr) * (unsigned)(d.ldx * 2) + (unsigned)lc * 16u;
+    const unsigned pstep = 128u * (unsigned)(d.ldx * 2);       // eight pieces further
+    unsigned voff_w[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) voff_w[u] = (unsigned)(n0 + (wv + NW * u) * 16) * 64u + (unsigned)lane * 16u;      // (packed stream: a piece is 1 KiB of memory)
+    const unsigned wstep = (unsigned)d.Nc * 64u;              // one (K-tile, dx) array
+
+    const int nh = d.C >> 5, nkt = nh * 3;
+    // request r of K-tile (h, dy) -> the NEXT K-tile's weights (3 WU pieces) and a third of the NEXT half-chunk's patch
+    auto issue = [&](int r, int h, int dy, int kt) {
+        if (r < 3 * WU) {
+            const int dx = r / WU, u = r % WU, g = wv + NW * u;
+            if (g < WG && kt + 1 < nkt && !(kAblW & 4))
+                dma_piece(voff_w[u], srdw, (unsigned)((kt + 1) * 3 + dx) * wstep,
+                          __builtin_amdgcn_readfirstlane(lds0 + 2u * psb + (unsigned)(((kt + 1) & 1) * WSB + dx * (BC * 64) + g * 1024)));
+        } else {
+            const int i = (r - 3 * WU) * 3 + dy, q = wv + NW * i;
+            if (q < npb && h + 1 < nh && !(kAblW & 2))
+                dma_piece(voff_p, srdx, (unsigned)i * pstep + (unsigned)((h + 1) * 64), __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((h + 1) & 1) * psb + q * 1024)));
+        }
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: weights by (dx, e) with immediates on top of aoff[e]; pixels by patch row rho = irow[j] + dy W + dx
+    int aoff[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) aoff[e] = (wc * TC * 32 + frow) * 64 + (((2 * e + fh) ^ ((frow >> 2) & 3)) << 4);
+    int irow[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) irow[j] = base_of(min(m0 + (wp * TP + j) * 32 + frow, Mi - 1)) - p0;
+    auto baddr = [&](int rho, int e) { return (rho << 6) | ((((2 * e + fh) << 4)) ^ ((rho & 12) << 2)); };
+
+    {   // prologue: patch of half-chunk 0 -> stage 0, weights of K-tile 0 -> stage 0
+        for (int i = 0; wv + NW * i < npb; ++i)
+            dma_piece(voff_p, srdx, (unsigned)i * pstep, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((wv + NW * i) * 1024)));
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int u = 0; u < WU; ++u)
+                if (wv + NW * u < WG)
+                    dma_piece(voff_w[u], srdw, (unsigned)dx * wstep, __builtin_amdgcn_readfirstlane(lds0 + 2u * psb + (unsigned)(dx * (BC * 64) + (wv + NW * u) * 1024)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int h = 0, dy = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned char *ps = smem + (h & 1) * psb;
+        const unsigned char *ws = smem + 2 * psb + (kt & 1) * WSB;
+        const int tap0 = dy * d.W;
+        bf16x8 wq[2][TC], xq[2][TP];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) wq[0][i] = *reinterpret_cast<const bf16x8 *>(ws + i * 2048 + aoff[0]);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) xq[0][j] = *reinterpret_cast<const bf16x8 *>(ps + baddr(irow[j] + tap0, 0));
+        int issued = 0;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            if (s + 1 < 6) {
+                const int dx1 = (s + 1) >> 1, e1 = (s + 1) & 1;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) wq[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(ws + dx1 * (BC * 64) + i * 2048 + aoff[e1]);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) xq[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(ps + baddr(irow[j] + tap0 + dx1, e1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s & 1][i], xq[s & 1][j], acc[i][j], 0, 0, 0);
+                    const int idx = (s * TP + j) * TC + i;
+                    const int due = std::min(NREQ, idx / 2 + 1);
+                    if (issued < due) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < NREQ; ++r)
+                            if (r >= issued && r < due) issue(r, h, dy, kt);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issued = due;
+                    }
+                }
+        }
+        if (++dy == 3) { dy = 0; ++h; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue (k_conv16w's): bias, activation, one RNE rounding, 16-B NHWC stores straight from the accumulators
+    bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
+    const bool relu = d.act == ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int nb = n0 + (wc * TC + i) * 32;
+        float4 b4[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) b4[rg] = d.bias ? *reinterpret_cast<const float4 *>(d.bias + nb + 8 * rg + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int m = m0 + (wp * TP + j) * 32 + frow;
+            const bool ok = m < Mi;
+            unsigned pk[8];
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float b0 = (e & 2) ? b4[e >> 2].z : b4[e >> 2].x, b1 = (e & 2) ? b4[e >> 2].w : b4[e >> 2].y;
+                float v0 = acc[i][j][e] + b0, v1 = acc[i][j][e + 1] + b1;
+                v0 = (relu && v0 < 0.f) ? 0.f : v0; v1 = (relu && v1 < 0.f) ? 0.f : v1;
+                pk[e >> 1] = pack_bf2(v0, v1);
+            }
+            bf16_t *dst = y16 + (int64_t)(ok ? m : 0) * d.ldy + nb + fh * 8;
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                unsigned o[4];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const auto sw2 = __builtin_amdgcn_permlane32_swap(pk[(2 * grp) * 2 + w], pk[(2 * grp + 1) * 2 + w], false, false);
+                    o[w] = sw2[0]; o[2 + w] = sw2[1];
+                }
+                if (ok) *reinterpret_cast<uint4 *>(dst + grp * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// patch rows a BP-pixel run can span (bound over all tiles): the run itself, two pad columns per row crossing, two pad rows per image
+// crossing, and the two input rows + two pixels below / right of its last pixel
+int conv16p_rows(const ConvDesc &d, int bp) {
+    const int rc = (d.OW - 1 + bp - 1) / d.OW, ic = (d.OH * d.OW - 1 + bp - 1) / (d.OH * d.OW);
+    return (bp - 1) + 2 * rc + 2 * d.W * ic + 2 * d.W + 3;
+}
+template <int BC>
+int conv16p_lds(const ConvDesc &d, int bp) { return 2 * cdiv(conv16p_rows(d, bp), 16) * 1024 + 2 * 3 * BC * 64; }
+
+template <int BP, int BC, int WP, int WC>
+int launch16p(const ConvDesc &d, hipStream_t st) {
+    const int n_mt = cdiv((int)d.M, BP), n_nt = d.Nc / BC, cpx = cdiv(n_mt, kNumXCD);
+    const int npp = cdiv(conv16p_rows(d, BP), 16);
+    const int lds = conv16p_lds<BC>(d, BP);
+    EVFLY_REQUIRE(lds <= kMaxLds && npp <= 72, "conv16p: patch of %d rows does not fit", npp * 16);
+    auto kern = k_conv16p<BP, BC, WP, WC>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt), dim3(512), lds, st, d, n_mt, n_nt, cpx, npp);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
+
+size_t conv16p_weight_elems(int cout, int cin) { return (size_t)9 * cin * cout; }
+
+// out chunk ((kt * 3 + kx) * Nc + n) * 4 + slot  <-  w16[n][(kt / 3) * 288 + (3 * (kt % 3) + kx) * 32 + 8 * (slot ^ ((n >> 2) & 3)) ..+ 8]
+void conv16p_pack_host(const void *w16, int cout, int cin, int ldw, void *out) {
+    const uint4 *src = static_cast<const uint4 *>(w16);
+    uint4 *dst = static_cast<uint4 *>(out);
+    const int nkt = cin / 32 * 3;
+    for (int kt = 0; kt < nkt; ++kt)
+        for (int kx = 0; kx < 3; ++kx)
+            for (int n = 0; n < cout; ++n)
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int lc = sl ^ ((n >> 2) & 3);
+                    dst[((size_t)(kt * 3 + kx) * cout + n) * 4 + sl] = src[((size_t)n * ldw + (kt / 3) * 288 + (3 * (kt % 3) + kx) * 32 + 8 * lc) / 8];
+                }
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_conv16p_pack(const uint4 *__restrict__ src, int cout, int cin, int ldw, uint4 *__restrict__ dst) {
+    const int64_t total = (int64_t)cin / 32 * 9 * cout * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int sl = (int)(i & 3);
+        const int64_t r = i >> 2;
+        const int n = (int)(r % cout), a = (int)(r / cout), kx = a % 3, kt = a / 3;
+        const int lc = sl ^ ((n >> 2) & 3);
+        dst[i] = src[((size_t)n * ldw + (kt / 3) * 288 + (3 * (kt % 3) + kx) * 32 + 8 * lc) / 8];
+    }
+}
+}  // namespace
+
+int conv16p_pack_device(const void *w16, int cout, int cin, int ldw, void *out, hipStream_t st) {
+    EVFLY_REQUIRE(cin % 32 == 0 && ldw % 8 == 0, "conv16p pack: C_in %% 32, ldw %% 8");
+    const int64_t total = (int64_t)cin / 32 * 9 * cout * 4;
+    hipLaunchKernelGGL(k_conv16p_pack, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, st, static_cast<const uint4 *>(w16), cout, cin, ldw,
+                       static_cast<uint4 *>(out));
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
 
 bool conv16w_applicable(const ConvDesc &d) {
     static const bool off = getenv("EVFLY_NO_CONV16W") != nullptr;
@@ -371,6 +626,42 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st) {
     static const int alt128 = getenv("EVFLY_CONV16W_ALT128") ? atoi(getenv("EVFLY_CONV16W_ALT128")) : 0;
     bool wide = d.Nc % 256 == 0;
     if (force == 128) wide = false;
+    // k_conv16p (pixels staged once per 32-channel half-chunk) wherever its patch fits the LDS; EVFLY_NO_CONV16P=1 keeps the per-tap tiles
+    static const bool no_patch = getenv("EVFLY_NO_CONV16P") != nullptr;
+    static const int patch_bp = getenv("EVFLY_CONV16P_BP") ? atoi(getenv("EVFLY_CONV16P_BP")) : 0;      // tuning switch
+    const bool tail_ok = (int64_t)d.NI * d.H * d.W * d.ldx * 2 + (int64_t)1200 * d.ldx * 2 < ((int64_t)1 << 32);      // (rows past the tensor stay 32-bit offsets)
+    if (!no_patch && tail_ok && alt128 == 0 && d.w_patch && ((uintptr_t)d.w_patch) % 16 == 0 && (int64_t)9 * d.C * d.Nc * 2 < ((int64_t)1 << 32)) {
+        auto fits = [&](int bp, int bc) { return 2 * cdiv(conv16p_rows(d, bp), 16) * 1024 + 6 * bc * 64 <= kMaxLds && cdiv(conv16p_rows(d, bp), 16) <= 72; };
+        // measured on the U-Net shapes at 320 frames (tools/layer_ab.py, ms per layer, per-tap -> patch): d11 0.260 -> 0.216, d12 0.120 -> 0.098,
+        // d21 0.203 -> 0.171, d22 0.093 -> 0.084, e51 0.128 -> 0.104, e41 0.184 -> 0.176, e42 0.314 -> 0.291, e32 0.482 -> 0.466 (256 x 128;
+        // 192 x 128 at one block per CU loses: 0.554). Not taken: 64 output channels (d31 0.203 -> 0.216: its patch is 2.4 x the run) and
+        // layers whose per-tap kernel can take a tile the patch does not fit (e52: 320 pixels = one round, 0.152 against 0.165)
+        if (d.Nc % 128 != 0) {
+        } else if (!wide) {
+            if (fits(256, 128) && patch_bp != 192) return launch16p<256, 128, 4, 2>(d, st);
+            if (fits(192, 128) && patch_bp == 192) return launch16p<192, 128, 2, 4>(d, st);
+        } else {
+            const int ntp = d.Nc / 256;
+            auto cost = [&](int bp, bool patch) {
+                if (patch && !fits(bp, 256)) return 1e30;
+                const double per_pixel = bp == 192 ? 1.12 : bp == 320 ? 0.94 : 1.0;
+                return (double)cdiv(cdiv((int)d.M, bp) * ntp, kNumCU) * bp * per_pixel;
+            };
+            int bp = 256;
+            if (cost(192, true) < cost(bp, true)) bp = 192;
+            if (cost(320, true) < cost(bp, true)) bp = 320;
+            if (patch_bp == 192 || patch_bp == 256 || patch_bp == 320) bp = patch_bp;
+            const double tap_best = std::min(cost(192, false), std::min(cost(256, false), cost(320, false)));
+            static const bool dbg = getenv("EVFLY_CONV16P_DBG") != nullptr;
+            if (dbg) fprintf(stderr, "conv16p: M %lld %dx%d C %d Nc %d -> bp %d (patch cost %.0f, per-tap best %.0f) rows %d\n", (long long)d.M, d.OH, d.OW, d.C, d.Nc, bp,
+                             cost(bp, true), tap_best, conv16p_rows(d, bp));
+            if (cost(bp, true) < 1e29 && (cost(bp, true) <= 1.15 * tap_best || patch_bp)) {
+                if (bp == 192) return launch16p<192, 256, 2, 4>(d, st);
+                if (bp == 320) return launch16p<320, 256, 2, 4>(d, st);
+                return launch16p<256, 256, 2, 4>(d, st);
+            }
+        }
+    }
     // 64 output channels (d31)
     if (d.Nc % 128 != 0 && alt128 == 2) return launch16w<512, 64, 8, 1>(d, st);
     if (d.Nc % 128 != 0) return launch16w<256, 64, 4, 2>(d, st);      // 80 KB of LDS: two blocks per CU (d31 0.243 -> 0.229 ms against 512 x 64)

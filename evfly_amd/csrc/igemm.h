@@ -25,6 +25,7 @@ struct ConvDesc {
     int NI = 1, H = 1, W = 1, C = 0;
     const float *w = nullptr;   // [Nc][ldw], k = (ky*KW + kx)*C + c
     int ldw = 0;
+    const void *w_patch = nullptr;   // bf16 pipeline, deep 3x3 layers: the same weights in k_conv16p's streamed order (conv16p_pack_*), or null
     const float *bias = nullptr;
     int KH = 1, KW = 1, stride = 1, pad = 0;
     int OH = 1, OW = 1;
@@ -119,6 +120,11 @@ bool conv16_dot_fusable(const ConvDesc &d);
 // Wide-tile implicit GEMM of the bf16 pipeline for the deep 3x3 layers (conv16w.hip): C % 64 == 0, C >= 128, Nc % 128 == 0, stride 1,
 // no padding, bf16 in / out, bias + ReLU / none; reads the [Nc][ldw] bf16 GEMM weights of igemm16_launch.
 bool conv16w_applicable(const ConvDesc &d);
+// k_conv16p's weight stream: [K-tile kt = (c / 32) * 3 + ky][kx][n][32 channels], the four 16-B chunks of a row in slot
+// c ^ ((n >> 2) & 3) -- every 1-KiB LDS-DMA piece of the kernel is 1 KiB of contiguous memory. elems = 9 * C * Nc
+size_t conv16p_weight_elems(int cout, int cin);
+void conv16p_pack_host(const void *w16, int cout, int cin, int ldw, void *out);
+int conv16p_pack_device(const void *w16, int cout, int cin, int ldw, void *out, hipStream_t st);
 int conv16w_launch(const ConvDesc &d, hipStream_t st);
 // ... and its 1x1 form with the 2x2 scatter epilogue (the decoder's ConvTranspose2d layers with C_in >= 128)
 bool conv16w_up_applicable(const ConvDesc &d);

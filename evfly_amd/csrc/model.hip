@@ -292,6 +292,11 @@ int pack_unet(evfly_model *m) {
         if (int rc = pack_conv(m, kUnetP, std::string("unet_") + n, n, true, false, w16)) return rc;
         if (w16) {   // bf16 pipeline, shallow layers: the direct-convolution kernel's weight stream (conv16.hip)
             const HostTensor *tw = m->find(std::string("unet_") + n + ".weight", kUnetP);
+            if (tw && tw->shape[1] >= 128 && tw->shape[1] % 64 == 0 && tw->shape[0] % 64 == 0) {      // deep layers: k_conv16p's stream (conv16w.hip)
+                const int O = (int)tw->shape[0], I = (int)tw->shape[1];
+                m->stage16(std::string(n) + ".wp", conv16p_weight_elems(O, I));      // (staging may reallocate: pointers afterwards)
+                conv16p_pack_host(m->wstage.data() + m->woff[std::string(n) + ".w"], O, I, m->wld[n], m->wstage.data() + m->woff[std::string(n) + ".wp"]);
+            }
             if (tw && (tw->shape[1] == 32 || tw->shape[1] == 64) && tw->shape[0] % 32 == 0) {
                 const int O = (int)tw->shape[0], I = (int)tw->shape[1];
                 conv16_pack_host(tw->v.data(), O, I, m->stage16(std::string(n) + ".wd", conv16_weight_elems(O, I, conv16_ntb(O))));
@@ -645,6 +650,7 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
     EVFLY_REQUIRE(!d.pre_frames, "the fused first conv needs the Winograd / direct-convolution kernels");
     if (pool_fused) *pool_fused = false;
     if (f16 == IO16 && !m->planning && conv16w_applicable(d)) {    // bf16 pipeline, deep 3x3 layers: 256-pixel tiles, 8 waves
+        if (m->has(wname + ".wp")) d.w_patch = m->W(wname + ".wp");
         RUN(m, pn.c_str(), igemm_flops(d), bytes, conv16w_launch(d, m->st));
         return 0;
     }
@@ -1506,7 +1512,13 @@ extern "C" int evfly_op_conv2d_nhwc_bf16(const uint16_t *x, int n, int h, int w,
         if (int rc = conv16_pack_device(w_packed, cout, cin, wdp, as_stream(stream))) return rc;
         return conv16_launch(d, wdp, nullptr, as_stream(stream));
     }
-    if (conv16w_applicable(d)) return conv16w_launch(d, as_stream(stream));      // the deep 3x3 layers
+    if (conv16w_applicable(d)) {      // the deep 3x3 layers
+        void *wpp = nullptr;
+        if (int rc = scratch_get(conv16p_weight_elems(cout, cin) * 2, &wpp, as_stream(stream), 1)) return rc;
+        if (int rc = conv16p_pack_device(scr, cout, cin, ld, wpp, as_stream(stream))) return rc;
+        d.w_patch = wpp;
+        return conv16w_launch(d, as_stream(stream));
+    }
     return igemm_launch(d, as_stream(stream));
 }
 

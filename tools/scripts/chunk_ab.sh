@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 for c in 640 320 160; do
-  EVFLY_CHUNK_FRAMES=$c BENCH_DUMP_LAYERS=1 python3 bench.py --config C3 --no-cpu-baseline --no-other-configs --no-alt > gpurun_out/c3_chunk$c.json 2>/dev/null
+  EVFLY_CHUNK_FRAMES=$c BENCH_DUMP_LAYERS=1 python3 bench.py --config C3 --no-overlap --no-cpu-baseline --no-other-configs --no-alt > gpurun_out/c3_chunk$c.json 2>/dev/null
   python3 - <<PY
 import json
 j=json.loads(open("gpurun_out/c3_chunk$c.json").read().strip().splitlines()[-1])
