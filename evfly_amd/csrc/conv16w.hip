@@ -638,6 +638,7 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st) {
         // layers whose per-tap kernel can take a tile the patch does not fit (e52: 320 pixels = one round, 0.152 against 0.165)
         if (d.Nc % 128 != 0) {
         } else if (!wide) {
+            if (fits(512, 128) && (patch_bp == 0 || patch_bp == 512) && d.M >= 512 * 512) return launch16p<512, 128, 8, 1>(d, st);
             if (fits(256, 128) && patch_bp != 192) return launch16p<256, 128, 4, 2>(d, st);
             if (fits(192, 128) && patch_bp == 192) return launch16p<192, 128, 2, 4>(d, st);
         } else {
