@@ -454,10 +454,10 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in PMC_TRAFFIC.get(cname, ())) if os.path.exists(q)), None)
         if pmc and cfg == CONFIGS[cname]:
             ks = json.load(open(pmc))["kernels"]
-            # fp32: the 17 Winograd launches; bf16 pipeline: the 3x3 convs run on three kernels (direct conv for C_in <= 64, the
-            # wide-tile implicit GEMM for the deep layers, igemm16 for what is left; that family's count also holds the ViT / velpred
+            # fp32: the 17 Winograd launches; bf16 pipeline: the 3x3 convs run on four kernels (direct conv for C_in <= 64, the
+            # wide-tile implicit GEMMs for the deep layers -- per-tap tiles and the patch-staged form --, igemm16 for what is left; that family's count also holds the ViT / velpred
             # convs, a rounding error in bytes)
-            fams = ["wino_conv3x3"] if dtype == "f32" else ["conv16_direct", "conv16w_deep", "igemm16_conv"]
+            fams = ["wino_conv3x3"] if dtype == "f32" else ["conv16_direct", "conv16w_deep", "conv16p_deep", "igemm16_conv"]
             gs = [ks[f] for f in fams if f in ks]
             g = None
             if gs:
@@ -489,6 +489,17 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                                         "without that padding; frac_algorithmic = direct-conv flops (SURVEY.md §8d) over the same time, "
                                         "above 1 because the convolution is computed with 2.25x fewer multiplies") if wino
                                        else "achieved = 2*M*N*K of the launches / their HIP-event time (direct implicit GEMM: issued = useful = algorithmic)"}
+            # The same family against the roofline that bounds EACH layer: t_min(layer) = max(executed flops / MFMA peak, algorithmic bytes /
+            # HBM peak) -- the shallow layers of this U-Net sit below the machine balance (e12: 131 flop/B against 312), the single MFMA
+            # `frac` above prices them against a bound they cannot reach. From the bracketed untimed step (one launch per layer).
+            lay = [p for p in layers if p["name"].startswith(dom["name"] + "/") and p["ms"] > 0]
+            if lay:
+                tmin = sum(max((p["exec_flops"] or p["flops"]) / (peak * 1e12), p["bytes"] / (HBM_PEAK_GBS * 1e9)) for p in lay)
+                tact = sum(p["ms"] for p in lay) * 1e-3
+                out["roofline"]["per_layer_bound"] = {
+                    "frac": round(tmin / tact, 4), "hbm_bound_layers": sum(1 for p in lay if p["bytes"] / (HBM_PEAK_GBS * 1e9) > (p["exec_flops"] or p["flops"]) / (peak * 1e12)),
+                    "layers": len(lay), "note": "sum over the family's layers of max(flops / MFMA peak, algorithmic bytes / 8 TB/s), divided by their measured time "
+                                                "(bracketed untimed step); `frac` above stays flops / MFMA peak for the whole family"}
         else:
             gbs = dom["bytes"] / sec / 1e9
             out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,

@@ -9,7 +9,9 @@ def agg(path):
         k = r["Kernel_Name"]
         mm = re.search(r"\b(k_[a-z0-9_]+)", k)
         fam = ("wino_conv3x3" if "k_wino" in k and "weights" not in k else
-               "conv16w_deep" if "k_conv16w" in k else "conv16_direct" if "k_conv16" in k else
+               "conv16p_deep" if "k_conv16p" in k else
+               ("conv16w_deep" if re.search(r"k_conv16w<[^>]*, *0>", k) else "conv16w_up" if re.search(r"k_conv16w<[^>]*, *1>", k) else "conv16w_gemm") if "k_conv16w" in k else
+               "conv16_direct" if "k_conv16" in k else
                "igemm16_conv" if ("k_igemm16" in k and "false>" in k.replace(" ", "")) else     # bf16 pipeline: non-plain = the convolutions
                "igemm16_gemm" if "k_igemm16" in k else
                "mfma_gemm" if ("k_igemm" in k or "k_conv3x3_halo" in k) else (mm.group(1) if mm else "other"))
