@@ -383,7 +383,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             if constexpr (kAbl16 & 8) { asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }      // timing experiment: no stores
             const unsigned px_off = st_off[pool ? ROWS : r];
             const int nb = n0 + j * 32 + grp * 16 + fh * 8;
-            const unsigned vo = (px_off != OOB && nb < d.Nc) ? px_off + (unsigned)nb * 2u : OOB;
+            unsigned vo = (px_off != OOB && nb < d.Nc) ? px_off + (unsigned)nb * 2u : OOB;
+            if constexpr (kAbl16 & 1) {      // timing experiment: the same bytes as ONE contiguous 1-KiB run per instruction (garbage layout)
+                const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)st_off[pool ? ROWS : 0]);
+                vo = b0 == OOB ? OOB : b0 + (unsigned)(kk * 1024 + (threadIdx.x & 63) * 16);
+            }
             const u32x4 v = {o[0], o[1], o[2], o[3]};
             if (pool) __builtin_amdgcn_raw_buffer_store_b128(v, pr, (int)vo, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)vo, 0, 0);
