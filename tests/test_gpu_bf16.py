@@ -104,6 +104,31 @@ def test_conv_bf16_pipeline_kernel(gpu_device, case):
     _assert_bf16_close(got, ref)
 
 
+def _conv16p_cases():
+    """Geometries for the patch-staged deep-layer kernel (conv16w.hip, k_conv16p): 8 x 13 maps (a 320-pixel run crosses three images and
+    25 rows), a ragged last pixel tile, 64-channel K tails (C = 192: six half-chunks), two 256-channel tiles per pixel tile."""
+    for case in [(310, 10, 15, 256, 256, 3, 1, 0, 1, False), (37, 29, 39, 192, 512, 3, 1, 0, 0, False), (90, 18, 24, 128, 256, 3, 1, 0, 1, False)]:
+        got, ref = _conv_bf16(*case, seed=sum(case[:5]))
+        _assert_bf16_close(got, ref)
+
+
+@pytest.mark.parametrize("bp", ["192", "256", "320", "off"])
+def test_conv16p_tile_variants(gpu_device, bp):
+    """Every pixel-tile instantiation of k_conv16p (EVFLY_CONV16P_BP is read once per process: a child per value) and the per-tap
+    kernel it replaces (EVFLY_NO_CONV16P=1) on the same problems, each against an fp32 convolution of the rounded operands."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_bf16 as t\nt._conv16p_cases()\nprint('ok')\n") % (repo, os.path.join(repo, "tests"))
+    env = dict(os.environ, **({"EVFLY_NO_CONV16P": "1"} if bp == "off" else {"EVFLY_CONV16P_BP": bp, "EVFLY_CONV16P_DBG": "1"}))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+    if bp != "off":      # the forced tile really ran (a patch that does not fit the LDS falls back to the per-tap kernel: 320 on the 27 x 37 maps)
+        assert ("-> bp %s " % bp) in r.stderr, r.stderr[-2000:]
+
+
 def _unet(dev, **kw):
     import evfly_amd.learner_models as lm
     args = dict(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346], velpred=0,
