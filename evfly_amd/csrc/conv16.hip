@@ -88,6 +88,8 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     unsigned char *wl = smem + 2 * PATCH_BYTES;
     float *bl = reinterpret_cast<float *>(wl + (size_t)nchunks * 18 * NTB * 1024);        // bias of the slice (NTB * 32 floats, zero padded)
     float *fbuf = bl + NTB * 32;                                                           // PRE: [2][FPIX] formed frame patches
+    // tap_h > 0: byte tables [OH rows | OW columns], 1 = a tap of the resize that is the map's only reader (ConvDesc::tap_h)
+    unsigned char *taps = reinterpret_cast<unsigned char *>(fbuf + (PRE ? 2 * FPIX : 0));
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slice = blockIdx.x / g.blocks_per_slice, bis = blockIdx.x - slice * g.blocks_per_slice;
@@ -106,6 +108,20 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     }
 
     if (tid < NTB * 32) bl[tid] = (d.bias && n0 + tid < d.Nc) ? d.bias[n0 + tid] : 0.f;        // (published by the prologue barrier)
+    const bool masked = d.tap_h > 0;
+    if (masked) {      // (two passes around a barrier of their own: zero, then every skip row / column marks its two taps)
+        for (int i = tid; i < d.OH + d.OW; i += 512) taps[i] = 0;
+        __syncthreads();
+        const float sh = (float)d.OH / (float)d.tap_h, sw = (float)d.OW / (float)d.tap_w;      // launch16_bilinear's scales
+        for (int i = tid; i < d.tap_h + d.tap_w; i += 512) {
+            const bool row = i < d.tap_h;
+            int i0, i1;
+            float l0, l1;
+            bilinear_src_index(row ? i : i - d.tap_h, row ? d.OH : d.OW, row ? d.tap_h : d.tap_w, row ? sh : sw, 0, i0, i1, l0, l1);
+            unsigned char *t = taps + (row ? 0 : d.OH);
+            t[i0] = 1; t[i1] = 1;
+        }
+    }
 
     // ---- per-lane patch geometry of this wave's DMA pieces: piece p covers patch pixels 16 p .. 16 p + 15; lane l holds
     // slot l & 3 of pixel 16 p + (l >> 2), i.e. logical chunk (l & 3) ^ ((pixel >> 2) & 3)
@@ -342,11 +358,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         int img, ty, tx;
         tile_decode(st_tile, img, ty, tx);
         const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
-        const bool col_ok = ox < d.OW;
+        const bool col_ok = ox < d.OW && (!masked || taps[d.OH + ox]);
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int oy = oy0 + r;
-            st_off[r] = !(col_ok && oy < d.OH) ? OOB
+            st_off[r] = !(col_ok && oy < d.OH && (!masked || taps[oy])) ? OOB
                         : DOT ? (fh == 0 ? (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * 4) : OOB)        // (one lane of the pair stores the pixel's value)
                               : (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2);
         }
@@ -574,7 +590,8 @@ namespace {
 template <int ROWS, int NTB, bool POOL, bool PRE, bool DOT = false>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
-    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + NTB * 128 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0);
+    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + NTB * 128 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0) + (d.tap_h > 0 ? (d.OH + d.OW + 15) / 16 * 16 : 0);
+    EVFLY_REQUIRE(d.tap_h == 0 || (POOL && !DOT && d.tap_w > 0 && d.tap_h <= d.OH && d.tap_w <= d.OW), "conv16: masked stores go with the fused pool");
     auto kern = k_conv16<ROWS, NTB, POOL, PRE, DOT>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;

@@ -65,6 +65,10 @@ struct ConvDesc {
     // one block's output region (wino_skip_grid); launch_bilinear(..., grid) writes the others from y.
     float *skip_y = nullptr;
     int skip_h = 0, skip_w = 0;
+    // conv16.hip (bf16, shallow layers): the map's only readers are the fused 2x2 pool and the bilinear resize to tap_h x tap_w
+    // (align_corners = False, the decoder's 'interp' skip): store only the pixels that resize reads (rows / columns that are one of
+    // its two taps); the rest of y stays unwritten. 0: every pixel
+    int tap_h = 0, tap_w = 0;
     int64_t skip_ld = 0;
     // with skip_y: write y only along the borders of each block's region (first / last row and column) -- all that the
     // resize of the remaining skip pixels reads. For callers whose only other reader of y is the fused pool.

@@ -644,6 +644,13 @@ int conv(evfly_model *m, const char *pname, const std::string &wname, const floa
             if (conv16_dot_fusable(d)) { m->dot.done = true; m->dot_used = true; }
             else d.dot_w = d.dot_b = nullptr, d.dot_y = nullptr;
         }
+        // the map's readers are the fused pool and the decoder's 'interp' resize: only that resize's tap rows / columns are stored (e12: half
+        // of the pixels, e22: 0.6; the debug taps "e1" / "e2" are then partial like the fp32 pipeline's band stores)
+        static const bool no_tap_mask = getenv("EVFLY_NO_SKIP_TAP_STORES") != nullptr;
+        if (y_pool && skip_y && skip_h > 0 && !m->full_encoder_outputs && !no_tap_mask && !d.dot_y && skip_h <= d.OH && skip_w <= d.OW) {
+            d.tap_h = skip_h; d.tap_w = skip_w;
+            if (!m->planning) m->bands_used = true;
+        }
         RUN(m, pn.c_str(), igemm_flops(d) + extra_flops, bytes + (y_pool ? 0.5 * d.M * cout : 0.0), conv16_launch(d, m->W(wname + ".wd"), y_pool, m->st));
         return 0;
     }

@@ -203,6 +203,32 @@ def test_out16_fused_equals_dot_kernel(gpu_device, tmp_path):
         assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
 
 
+def test_skip_tap_stores_equal_full_maps(gpu_device, tmp_path):
+    """e12 / e22 of the bf16 pipeline store only the rows and columns that the decoder's 'interp' resize (F.interpolate, bilinear,
+    align_corners=False; learner_models.py:514) reads -- their other reader, the 2x2 pool, is fused -- against complete maps
+    (EVFLY_NO_SKIP_TAP_STORES=1, read once per process: subprocess): the same bits. Run twice in this process with the arena dirtied in
+    between: a tap the kernel failed to store would read whatever the previous forward left there."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "taps.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, test_gpu_bf16 as t\n"
+            "torch.save(t._unet_depth_outputs(), %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_NO_SKIP_TAP_STORES="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+    ref = torch.load(out)
+    net, _ = _unet("cuda")
+    x = cond_frames(74, 5).cuda()
+    for rep in range(2):
+        d, (_, up, _) = net([x.clone(), None, None])
+        assert torch.equal(d.float().cpu(), ref["depth"]) and torch.equal(up.float().cpu(), ref["up"]), rep
+        net([torch.flip(x, dims=[0, 2]).contiguous() * 3.0, None, None])      # other values in every arena buffer
+    with pytest.raises(RuntimeError, match="partial"):
+        net.hip().tap("e1")
+
+
 def test_unet_bf16_stateful_split_equals_one_call(gpu_device):
     """ConvLSTM state hand-off in the bf16 pipeline: frames [0..3) then [3..5) with the carried fp32 state against five frames
     in one call. Same kernels and rounding points (the bf16 copy of h is re-derived from the fp32 state), but the two call
