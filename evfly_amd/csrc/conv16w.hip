@@ -28,6 +28,9 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <tuple>
+#include <mutex>
+#include <map>
 
 #include "bf16.h"
 
@@ -484,11 +487,29 @@ __global__ __launch_bounds__(512) void k_conv16p(ConvDesc d, int n_mt, int n_nt,
     }
 }
 
-// patch rows a BP-pixel run can span (bound over all tiles): the run itself, two pad columns per row crossing, two pad rows per image
+// patch rows a BP-pixel run can span (maximum over all tiles): the run itself, two pad columns per row crossing, two pad rows per image
 // crossing, and the two input rows + two pixels below / right of its last pixel
 int conv16p_rows(const ConvDesc &d, int bp) {
-    const int rc = (d.OW - 1 + bp - 1) / d.OW, ic = (d.OH * d.OW - 1 + bp - 1) / (d.OH * d.OW);
-    return (bp - 1) + 2 * rc + 2 * d.W * ic + 2 * d.W + 3;
+    // exact: a run's span depends on where in its image it starts, m0 = k bp mod (OH OW) -- at most OH OW / gcd distinct starts; memoised
+    // per geometry (the bound (bp - 1) + 2 ceil-row-crossings + 2 W ceil-image-crossings over-counts runs that can never start late enough
+    // in an image to cross one more: e52's 320-pixel run of 8 x 13 maps crosses three images, never four -- 31 pieces instead of 33)
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int64_t>, int> memo;
+    const auto key = std::make_tuple(d.OH, d.OW, d.W, bp, d.M);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    const int ohw = d.OH * d.OW, hw = d.H * d.W;
+    auto base_of = [&](int64_t m) { const int64_t img = m / ohw; const int rem = (int)(m - img * ohw), oy = rem / d.OW; return img * hw + (int64_t)oy * d.W + (rem - oy * d.OW); };
+    const int64_t n_mt = (d.M + bp - 1) / bp;
+    int64_t span = 0;
+    for (int64_t k = 0; k < n_mt && k < ohw; ++k) {      // (k and k + ohw start at the same place in their images)
+        const int64_t m0 = k * bp, m1 = std::min<int64_t>(m0 + bp, d.M) - 1;
+        span = std::max(span, base_of(m1) - base_of(m0));
+    }
+    const int rows = (int)span + 2 * d.W + 3;
+    memo[key] = rows;
+    return rows;
 }
 template <int BC>
 int conv16p_lds(const ConvDesc &d, int bp) { return 2 * cdiv(conv16p_rows(d, bp), 16) * 1024 + 2 * 3 * BC * 64; }
