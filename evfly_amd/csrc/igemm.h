@@ -44,7 +44,7 @@ struct ConvDesc {
     int up_cout = 0;            // OUT_UPCONV2X2: n = (dy*2+dx)*up_cout + co, bias indexed by co
     // OUT_LSTM (igemm16 only; ConvLSTM step, convlstm.py:44-51): the Nc = 4 hid columns are GATE-INTERLEAVED (column 4 cell + gate, gates
     // i f o g), res = the input-side pre-activations in the same layout; the epilogue applies the cell update instead of writing
-    // y: c, h fp32 (M, hid) updated in place, h16 a bf16 copy of h, hseq row (m / res_rpi) * lstm_seq_img_rows + m % res_rpi a bf16 copy
+    // y: c, h fp32 (M, hid) updated in place (lstm_h may be null: no fp32 h from this step), h16 a bf16 copy of h, hseq row (m / res_rpi) * lstm_seq_img_rows + m % res_rpi a bf16 copy
     float *lstm_c = nullptr, *lstm_h = nullptr;
     void *lstm_h16 = nullptr, *lstm_hseq = nullptr;
     int64_t lstm_seq_img_rows = 0;

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_igemm16(ConvDesc d, int n_mt, int n_nt,
                         hn[e] = lstm_sigmoid(v[4 * e + 2]) * lstm_tanh(cn[e]);                                                      // :51
                     }
                     *reinterpret_cast<float2 *>(cp) = make_float2(cn[0], cn[1]);
-                    *reinterpret_cast<float2 *>(d.lstm_h + m * hid + cell) = make_float2(hn[0], hn[1]);
+                    if (d.lstm_h) *reinterpret_cast<float2 *>(d.lstm_h + m * hid + cell) = make_float2(hn[0], hn[1]);      // (the fp32 state: the chunk's last step only)
                     const unsigned hb = pack_bf2(hn[0], hn[1]);
                     *reinterpret_cast<unsigned *>(static_cast<bf16_t *>(d.lstm_h16) + m * hid + cell) = hb;
                     if (d.lstm_hseq) {
@@ -430,7 +430,7 @@ int igemm16_launch(const ConvDesc &d_in, hipStream_t st) {
     EVFLY_REQUIRE(((uintptr_t)d.w) % 16 == 0 && ((uintptr_t)d.x) % 16 == 0 && d.ldx % 8 == 0, "igemm16: operands not 16-byte aligned");
     EVFLY_REQUIRE(d.M < (int64_t)1 << 31, "igemm16: more than 2^31 output pixels in one launch");
     EVFLY_REQUIRE(d.out_mode != OUT_UPCONV2X2 || (d.up_cout > 0 && d.Nc == 4 * d.up_cout && !d.res && d.act == ACT_NONE), "igemm16: bad upconv epilogue");
-    EVFLY_REQUIRE(d.out_mode != OUT_LSTM || (d.Nc % 128 == 0 && d.res && !d.res_bf16 && d.res_rpi > 0 && d.lstm_c && d.lstm_h && d.lstm_h16 && !d.bias &&
+    EVFLY_REQUIRE(d.out_mode != OUT_LSTM || (d.Nc % 128 == 0 && d.res && !d.res_bf16 && d.res_rpi > 0 && d.lstm_c && d.lstm_h16 && !d.bias &&
                                             d.ldres % 4 == 0 && ((uintptr_t)d.res) % 16 == 0), "igemm16: bad ConvLSTM epilogue");
     const bool plain = d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1;
     return plain ? launch_by_n16<true>(d, st) : launch_by_n16<false>(d, st);

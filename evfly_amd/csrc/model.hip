@@ -809,7 +809,7 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
             conv_finish(d); d.Nc = 4 * hid; d.y = z; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
             d.res = zx + (int64_t)t * rpi * 4 * hid; d.ldres = 4 * hid; d.res_rpi = rpi; d.res_img_rows = (int64_t)T * rpi;
             if (gfuse && !skip0) {
-                d.out_mode = OUT_LSTM; d.lstm_c = cs; d.lstm_h = hs; d.lstm_h16 = h16_out; d.lstm_hseq = m->eoff(hseq, (int64_t)t * rpi * hid);
+                d.out_mode = OUT_LSTM; d.lstm_c = cs; d.lstm_h = t == T - 1 ? hs : nullptr /* nobody reads the fp32 h between steps */; d.lstm_h16 = h16_out; d.lstm_hseq = m->eoff(hseq, (int64_t)t * rpi * hid);
                 d.lstm_seq_img_rows = (int64_t)T * rpi;
                 RUN(m, "convlstm_h_gemm", igemm_flops(d), d.M * 2.0 * hid + d.M * 16.0 * hid + d.M * (16.0 + 4.0) * hid + 2.0 * 4.0 * hid * hid, igemm_launch(d, st));
                 continue;
