@@ -47,13 +47,15 @@ HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC = {"C2": ("r4_C2_pmc_traffic.json", "r3_C2_pmc_traffic.json", "r2_pmc_traffic.json"), "C5": ("r4_C5_pmc_traffic.json", "r3_C5_pmc_traffic.json")}
 
 CONFIGS = {
-    "C2": dict(streams=64, windows=5, epw=60_000, sensor=(260, 346), vit="tiny", dtype="f32", model="composite"),
-    # C3 runs the velocity model on a second HIP stream (evfly_amd/pipeline.py): with the ViT-base trunk in bf16 it is a third of the
-    # step and made of launches that leave most of the chip idle (80.2 -> 76.1 ms per step). C2 / C4 do not: the fp32 Winograd
-    # kernels hold every CU's LDS, the gain is 1-2 % (21.4 -> 21.0 ms at C2) and kernels of two streams sharing the chip
-    # stretch the HIP-event durations the roofline is computed from (--overlap / --no-overlap override)
+    # The composite configs run the velocity model on a second HIP stream (evfly_amd/pipeline.py; --no-overlap: one stream). With the
+    # ViT-base trunk in bf16 (C3) it is a third of the step and made of launches that leave most of the chip idle (80.2 -> 76.1 ms per
+    # step when it was introduced). With the fp32 Winograd kernels holding every CU's LDS the gain is small but repeatable -- C2 same box,
+    # three alternating runs: 21.11 / 21.12 / 21.13 -> 20.91 / 20.88 / 20.86 ms (+ 1.2 %) -- and kernels of two streams sharing the chip stretch
+    # the HIP-event durations the roofline is computed from (`frac` 0.661 -> 0.644 inside the timed region): the line carries
+    # `roofline.one_stream`, the same family over three one-stream steps outside the timed region, beside it.
+    "C2": dict(streams=64, windows=5, epw=60_000, sensor=(260, 346), vit="tiny", dtype="f32", model="composite", overlap=True),
     "C3": dict(streams=256, windows=10, epw=200_000, sensor=(480, 640), vit="base", dtype="bf16", model="composite", overlap=True),
-    "C4": dict(streams=256, windows=5, epw=60_000, sensor=(260, 346), vit="base", dtype="f32", model="composite"),
+    "C4": dict(streams=256, windows=5, epw=60_000, sensor=(260, 346), vit="base", dtype="f32", model="composite", overlap=True),
     "C5": dict(streams=20, windows=16, epw=60_000, sensor=(260, 346), vit="tiny", dtype="bf16", model="unet"),
 }
 
