@@ -654,10 +654,11 @@ int conv16w_launch(const ConvDesc &d, hipStream_t st) {
     if (!no_patch && tail_ok && alt128 == 0 && d.w_patch && ((uintptr_t)d.w_patch) % 16 == 0 && (int64_t)9 * d.C * d.Nc * 2 < ((int64_t)1 << 32)) {
         auto fits = [&](int bp, int bc) { return 2 * cdiv(conv16p_rows(d, bp), 16) * 1024 + 6 * bc * 64 <= kMaxLds && cdiv(conv16p_rows(d, bp), 16) <= 72; };
         // measured on the U-Net shapes at 320 frames (tools/layer_ab.py, ms per layer, per-tap -> patch): d11 0.260 -> 0.216, d12 0.120 -> 0.098,
-        // d21 0.203 -> 0.171, d22 0.093 -> 0.084, e51 0.128 -> 0.104, e41 0.184 -> 0.176, e42 0.314 -> 0.291, e32 0.482 -> 0.466 (256 x 128;
-        // 192 x 128 at one block per CU loses: 0.554). Not taken: 64 output channels (d31 0.203 -> 0.216: its patch is 2.4 x the run) and
-        // layers whose per-tap kernel can take a tile the patch does not fit (e52: 320 pixels = one round, 0.152 against 0.165)
+        // d21 0.203 -> 0.171, d22 0.093 -> 0.084, e51 0.128 -> 0.104, e41 0.184 -> 0.176, e42 0.314 -> 0.291, e32 0.482 -> 0.412 (512 x 128; 256 x 128: 0.466,
+        // 192 x 128 at one block per CU loses: 0.554), d31 0.198 -> 0.166 (512 x 64; 256 x 64: 0.216), e52 0.152 -> 0.133 (320 pixels = one round)
         if (d.Nc % 128 != 0) {
+            // 64 output channels (d31): 512-pixel runs (patch 1.66 x the run of a 78-wide map; 256-pixel runs: 2.4 x and slower than per-tap)
+            if (fits(512, 64) && d.M >= 512 * 512 && (patch_bp == 0 || patch_bp == 512)) return launch16p<512, 64, 8, 1>(d, st);
         } else if (!wide) {
             if (fits(512, 128) && (patch_bp == 0 || patch_bp == 512) && d.M >= 512 * 512) return launch16p<512, 128, 8, 1>(d, st);
             if (fits(256, 128) && patch_bp != 192) return launch16p<256, 128, 4, 2>(d, st);

@@ -107,7 +107,8 @@ def test_conv_bf16_pipeline_kernel(gpu_device, case):
 def _conv16p_cases():
     """Geometries for the patch-staged deep-layer kernel (conv16w.hip, k_conv16p): 8 x 13 maps (a 320-pixel run crosses three images and
     25 rows), a ragged last pixel tile, 64-channel K tails (C = 192: six half-chunks), two 256-channel tiles per pixel tile."""
-    for case in [(310, 10, 15, 256, 256, 3, 1, 0, 1, False), (37, 29, 39, 192, 512, 3, 1, 0, 0, False), (90, 18, 24, 128, 256, 3, 1, 0, 1, False)]:
+    for case in [(310, 10, 15, 256, 256, 3, 1, 0, 1, False), (37, 29, 39, 192, 512, 3, 1, 0, 0, False), (90, 18, 24, 128, 256, 3, 1, 0, 1, False),
+                 (190, 40, 42, 128, 64, 3, 1, 0, 1, False)]:      # d31's channel counts, long enough for the 512 x 64 patch tile
         got, ref = _conv_bf16(*case, seed=sum(case[:5]))
         _assert_bf16_close(got, ref)
 
