@@ -359,6 +359,31 @@ def test_stream_pipeline_equals_composite(gpu_device, dtype):
     assert torch.equal(hv[0], hv2[0]) and torch.equal(hv[1], hv2[1])
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_stream_pipeline_equals_one_stream_at_bench_size(gpu_device, dtype):
+    """The two-stream mode at the size bench.py times (C2: 64 streams x 5 windows; every composite config runs it by default): five
+    pipelined steps on the same batch -- the velocity model of step i shares the chip with the depth model of step i + 1 -- against the
+    one-stream result, depth maps, velocities and states bit-identical. (A kernel that reads a buffer its own launch writes shows up
+    here and nowhere else: tests/test_gpu_bf16.py::test_convlstm_gate_fused_gemm_keeps_two_copies_of_h.)"""
+    from evfly_amd.pipeline import StreamPipeline
+    net, _ = _composite(gpu_device, dtype)
+    pipe = StreamPipeline(net)
+    S, T = 64, 5
+    x = cond_frames(31, 8).repeat(S * T // 8, 1, 1, 1)
+    x = (x * torch.linspace(0.6, 1.0, S * T).view(-1, 1, 1, 1)).to(gpu_device)
+    desvel = torch.full((S * T, 1), 4.0, device=gpu_device)
+    with torch.no_grad():
+        d0, _, hu0 = pipe.unet.forward_streams(x, None, S, T)
+        v0, hv0 = pipe.vit._run([d0, desvel, None], S, T, clip2x=1)
+        torch.cuda.synchronize()
+        outs = [pipe.step(x, desvel, S, T) for _ in range(5)]
+        pipe.wait()
+        torch.cuda.synchronize()
+    for i, (v, (d, up, ((hu, _), hv)), _) in enumerate(outs):
+        assert torch.equal(d, d0) and torch.equal(v, v0), i
+        assert torch.equal(hu[0][0], hu0[0][0]) and torch.equal(hu[0][1], hu0[0][1]) and torch.equal(hv[0], hv0[0]) and torch.equal(hv[1], hv0[1]), i
+
+
 def test_multi_stream_matches_per_stream_oracle(gpu_device):
     """The throughput entry (streams batched, batch-as-time inside each) == every stream run alone."""
     net, sd = _composite(gpu_device)
