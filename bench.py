@@ -44,7 +44,8 @@ H, W = 260, 346
 PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, summarised per kernel family (first existing file wins)
-PMC_TRAFFIC = {"C2": ("r4_C2_pmc_traffic.json", "r3_C2_pmc_traffic.json", "r2_pmc_traffic.json"), "C5": ("r4_C5_pmc_traffic.json", "r3_C5_pmc_traffic.json")}
+PMC_TRAFFIC = {"C2": ("r5_C2_pmc_traffic.json", "r4_C2_pmc_traffic.json", "r3_C2_pmc_traffic.json"), "C5": ("r5_C5_pmc_traffic.json", "r4_C5_pmc_traffic.json"),
+               "C3": ("r5_C3_pmc_traffic.json",)}
 
 CONFIGS = {
     # The composite configs run the velocity model on a second HIP stream (evfly_amd/pipeline.py; --no-overlap: one stream). With the
@@ -79,8 +80,16 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="velocity model of step i on a second HIP stream under the depth model "
                     "of step i + 1 (evfly_amd/pipeline.py) for every composite config")
     ap.add_argument("--no-stage-rates", action="store_true", help="skip the V / D / P-only timings")
+    ap.add_argument("--pmc-pass", action="store_true", help="shape of a rocprofv3 --pmc counter pass: ONE stream, nothing but whole steps "
+                    "(warm-up + one bracketed + K timed; no stage timings, no one-stream probe, no side configs), so that every kernel's "
+                    "dispatch count is a whole multiple of `steps_executed`, which the line carries (tools/pmc_traffic_summary.py reads it)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--side-cpu-seconds", type=float, default=4.0, help="CPU-oracle budget of each `other_configs` / `c4` object (one thread count)")
+    ap.add_argument("--no-c4", action="store_true", help="N > 1 ranks: skip the compact C4 object (BASELINE's 8-GPU config) behind the C2 line")
+    ap.add_argument("--c4-streams", type=int, default=None, help="streams per rank of that C4 object (default: the config's 256; tests shrink it)")
     a = ap.parse_args()
+    if a.pmc_pass:
+        a.no_overlap = a.no_stage_rates = a.no_cpu_baseline = a.no_alt = a.no_other_configs = True
     cfg = dict(CONFIGS[a.config])
     for k, v in (("streams", a.streams), ("windows", a.windows), ("epw", a.events_per_window), ("vit", a.vit), ("dtype", a.dtype)):
         if v is not None:
@@ -105,7 +114,7 @@ def build_model(cfg):
     return m.to("cuda").float().eval(), sd
 
 
-def cpu_baseline(sd, cfg, budget_s):
+def cpu_baseline(sd, cfg, budget_s, only_mid=False):
     """The oracle (CPU port of the reference path) on a bounded sample of the same workload: streams of T windows through
     the C voxelizer port -> (crop +) conditioning -> model forward, at ONE thread and at every core torch sees (§8d)."""
     from evfly_amd import synthetic as syn
@@ -133,11 +142,15 @@ def cpu_baseline(sd, cfg, budget_s):
     nproc = torch.get_num_threads()
     res = {}
     try:
+        if only_mid:
+            torch.set_num_threads(max(1, min(16, nproc)))
         one_stream(0)                                          # warm-up (oneDNN primitive caches)
         # (oneDNN on a many-core host is slower with EVERY core on a T-frame batch than with a few: a middle count is timed too so
         # that `value` is the host's best, not a strawman)
         mid = max(1, min(16, nproc))
         plan = [("threads_1", 1, 0.35), ("threads_nproc", nproc, 0.35)] + ([(f"threads_{mid}", mid, 0.3)] if mid not in (1, nproc) else [])
+        if only_mid:
+            plan = [(f"threads_{mid}", mid, 1.0)]
         for label, th, share in plan:
             torch.set_num_threads(th)
             frames_done, dt, s = 0, 0.0, 0
@@ -153,11 +166,44 @@ def cpu_baseline(sd, cfg, budget_s):
     what = "U-Net + ConvLSTM" if cfg["model"] == "unet" else f"composite ({cfg['vit']} ViT)"
     out = {"value": best["value"], "unit": "event-frames/s", "cores": best["cores"], "kind": "port"}
     out.update(res)
+    if only_mid:
+        r = best
+        out["sample"] = (f"{r['streams']} stream(s) of {T} windows x {epw} events at {hs}x{ws} in {r['seconds']} s at {r['cores']} threads (the count that wins the "
+                         f"headline's three-way comparison on these hosts): C voxelizer port + torch-CPU fp32 oracle forward of the {what}")
+        return out
     out["sample"] = (f"`value` = the FASTEST of {len(res)} thread counts ({', '.join(str(r['cores']) for r in res.values())}; oneDNN on a many-core "
                      f"host is slower on a {T}-frame batch with every core than with a few); streams of {T} windows x {epw} events at {hs}x{ws}: C voxelizer port + torch-CPU fp32 oracle forward of the {what}, "
                      f"batch-as-time; " + ", ".join(f"{r['streams']} stream(s) at {r['cores']} thread(s) ({r['seconds']} s)" for r in res.values()) +
                      "")
     return out
+
+
+def pmc_traffic(cname, dtype, dom_launches_per_step, files=None):
+    """HBM bytes per launch of the dominant family (the 3x3 convs) from a committed PMC summary (tools/pmc_traffic_summary.py over
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `bench.py --pmc-pass`). The file's own bookkeeping is checked, not
+    trusted: every family's launches per step must be a whole number (a pass divided by the wrong step count -- round 4's C2 file:
+    196 / 3 -- is rejected) and the conv family's must equal what this run launched per step. -> (bytes per launch | None, note)."""
+    files = PMC_TRAFFIC.get(cname, ()) if files is None else files
+    pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in files) if os.path.exists(q)), None)
+    if not pmc:
+        return None, "no PMC summary for this shape/dtype"
+    ks = json.load(open(pmc))["kernels"]
+    base = os.path.basename(pmc)
+    bad = [k for k, v in ks.items() if abs(v["launches_per_step"] - round(v["launches_per_step"])) > 1e-6]
+    if bad:
+        return None, f"profiles/{base} rejected: launches_per_step of {bad[0]} = {ks[bad[0]]['launches_per_step']:.2f} is not a whole number (divided by a wrong step count)"
+    # fp32: the Winograd launches; bf16 pipeline: the 3x3 convs run on the direct kernel (C_in <= 64) and the patch-staged /
+    # per-tap wide-tile kernels (deep layers), igemm16 for what is left
+    fams = ["wino_conv3x3"] if dtype == "f32" else ["conv16_direct", "conv16w_deep", "conv16p_deep", "igemm16_conv"]
+    gs = [ks[f] for f in fams if f in ks]
+    if not gs:
+        return None, f"profiles/{base}: no conv3x3 kernels in it"
+    lps = round(sum(x["launches_per_step"] for x in gs))
+    if lps != round(dom_launches_per_step):
+        return None, f"profiles/{base} rejected: {lps} conv3x3 launches per step in the PMC pass, {dom_launches_per_step:.2f} in this run"
+    by = sum(x["fetch_bytes_per_step"] + x["write_bytes_per_step"] for x in gs)
+    return round(by / lps), ("HBM bytes per launch, mean over the %d conv3x3 kernel launches of a step (17 layers): (2 x FETCH_SIZE + WRITE_SIZE) from "
+                             "profiles/%s (%s steps profiled); algorithmic = algorithmic.bytes_per_launch" % (lps, base, json.load(open(pmc)).get("steps_profiled")))
 
 
 def visible_gpus():
@@ -220,6 +266,21 @@ def main():
                 others[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
             out["other_configs"] = others
+    # N > 1 ranks (the driver's SCALE runs launch the default C2 line): BASELINE.json's 8-GPU config IS C4 -- 2048 streams as 256 per
+    # rank, ViT-base, fp32, the all_gather of (256 * 5, 3) velocity rows per rank -- so the same invocation measures it too and
+    # appends it as a compact object; `value` stays C2's (weak-scaled), `c4.value` is the whole job's C4 rate.
+    if a.config == "C2" and dist is not None and not a.no_c4:
+        c4 = dict(CONFIGS["C4"])
+        if a.c4_streams:
+            c4["streams"] = a.c4_streams
+        t0 = time.perf_counter()
+        try:
+            o = run_config(a, "C4", c4, rank, world, dist, detail=False)
+            o = compact(o, time.perf_counter() - t0)
+        except Exception as e:
+            o = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            out["c4"] = o
     # The ONE JSON line goes last: RCCL writes a banner (host name, library path) into the C stdio buffer, which a pipe only
     # flushes at exit -- behind everything Python printed, on every rank. Flush C stdio on all ranks, meet, then print.
     import ctypes
@@ -246,7 +307,10 @@ def compact(o, wall_s):
     if "hbm" in r:
         c["roofline"]["hbm_frac_algorithmic"] = r["hbm"]["frac"]
     if "convlstm" in o:
-        c["convlstm"] = {k: o["convlstm"][k] for k in ("serial_critical_path_ms_per_step", "steps_in_series")}
+        c["convlstm"] = {k: o["convlstm"][k] for k in ("serial_critical_path_ms_per_step", "steps_in_series", "single_stream_sequence_ms", "single_stream_frames_per_s")}
+    for k in ("ranks", "cpu_baseline", "n_gpus", "precision_check"):
+        if k in o:
+            c[k] = o[k]
     return c
 
 
@@ -285,7 +349,10 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         vel_host.copy_(vel_all, non_blocking=True)                                    # lands before the closing synchronize
         return vel_all
 
+    calls = [0]                      # every whole step this config executes (`steps_executed`: what a PMC pass divides by)
+
     def step():
+        calls[0] += 1
         voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi)
         x = voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W))
         if not composite:                                                             # C5: depth maps stay in HBM
@@ -321,9 +388,18 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         for p in layers_all:
             fam_ms[p["name"].split("/")[0]] = fam_ms.get(p["name"].split("/")[0], 0.0) + p["ms"]
         dom_name = max(fam_ms, key=fam_ms.get)
-        L.evfly_model_profile_reset(hip.h)
-        L.evfly_model_set_profile_filter(hip.h, dom_name.encode())
-        L.evfly_model_set_profiling(hip.h, 1)
+
+        def bracket(on):
+            """bracket the dominant family's launches on EVERY handle (it may belong to the velocity model's one), or stop."""
+            for hh in hips:
+                if on:
+                    L.evfly_model_profile_reset(hh.h)
+                L.evfly_model_set_profile_filter(hh.h, dom_name.encode() if on else None)
+                L.evfly_model_set_profiling(hh.h, 1 if on else 0)
+
+        def bracketed():
+            return [p for hh in hips for p in hh.profile()]
+        bracket(True)
         # one event per step boundary on the launch stream (a record is ~1 us of host time, no synchronisation): the spread of
         # the K steps inside the one timed region
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
@@ -335,30 +411,27 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             marks[i + 1].record()
         sync()
         dt = time.perf_counter() - t0
-        L.evfly_model_set_profiling(hip.h, 0)
-        L.evfly_model_set_profile_filter(hip.h, None)
+        bracket(False)
+    timed_rec = bracketed()
     one_stream = None
     if pipe:
         # the same steps on ONE stream, outside the timed region: in the timed region kernels of the two streams share the chip, which
         # stretches the HIP-event durations of the dominant family; this pass times the family alone (3 steps)
         def step_serial():
+            calls[0] += 1
             voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi)
             x = voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W))
             depth, _, _ = pipe.unet.forward_streams(x, None, B, T)
             vel, _ = pipe.vit._run([depth, desvel, None], B, T, clip2x=1)
             return publish(vel)
-        timed_rec = hip.profile()
         with torch.no_grad():
             step_serial(); sync()
-            L.evfly_model_profile_reset(hip.h)
-            L.evfly_model_set_profile_filter(hip.h, dom_name.encode())
-            L.evfly_model_set_profiling(hip.h, 1)
+            bracket(True)
             for _ in range(3):
                 step_serial()
             sync()
-            L.evfly_model_set_profiling(hip.h, 0)
-            L.evfly_model_set_profile_filter(hip.h, None)
-        one_stream = hip.profile()
+            bracket(False)
+        one_stream = bracketed()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     step_ms = {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),
                "note": "GPU time between per-step events on the launch stream inside the timed region"}
@@ -398,13 +471,15 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
-    with torch.no_grad():
-        vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi))
-        cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W)))
-        # the same stage for a batch whose pass-1 tables do not exist yet (fresh events every call, SURVEY.md §8d's definition):
-        # sortedness check + window ranges over the 8-B timestamps, then the accumulation
-        ev_raw = {k: v for k, v in ev.items() if k not in ("starts", "unsorted", "skip_kernels")}
-        vox1_ms = time_stage(lambda: voxelizer.voxelize_windows(ev_raw, Hs, Ws, out="f32", frames=frames, roi=roi))
+    vox_ms = cond_ms = vox1_ms = None
+    if not a.pmc_pass:                                 # (a counter pass holds whole steps only)
+        with torch.no_grad():
+            vox_ms = time_stage(lambda: voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi))
+            cond_ms = time_stage(lambda: voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W)))
+            # the same stage for a batch whose pass-1 tables do not exist yet (fresh events every call, SURVEY.md §8d's definition):
+            # sortedness check + window ranges over the 8-B timestamps, then the accumulation
+            ev_raw = {k: v for k, v in ev.items() if k not in ("starts", "unsorted", "skip_kernels")}
+            vox1_ms = time_stage(lambda: voxelizer.voxelize_windows(ev_raw, Hs, Ws, out="f32", frames=frames, roi=roi))
     # bytes the timed kernel moves: x, y, p of every event once (5 B; the timestamps were consumed by pass 1 at upload) + the
     # (cropped) f32 frames once; with pass 1: + 8 B/event of timestamps = SURVEY.md §8d's 13 B/event
     vox_bytes = 5.0 * n_events + 4.0 * B * T * H * W
@@ -418,7 +493,10 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             for k in ("ms", "flops", "bytes", "launches", "exec_flops", "useful_flops"):
                 f[k] += p[k]
         return list(fam.values())
-    timed = timed_rec if pipe else hip.profile()   # dominant family only, bracketed inside the timed region
+    timed = timed_rec                              # dominant family only, bracketed inside the timed region
+    if not [p for p in timed if p["ms"] > 0]:      # (nothing bracketed: fall back to the untimed step's records of that family, x K)
+        timed = [dict(p, **{k: p[k] * a.steps for k in ("ms", "flops", "bytes", "launches", "exec_flops", "useful_flops")})
+                 for p in layers_all if p["name"].split("/")[0] == dom_name]
     dom = max(families(timed), key=lambda p: p["ms"])
     layers = layers_all                            # every launch site ("family/layer"), from the untimed step
     prof = families(layers)
@@ -438,7 +516,7 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                                f"batch-as-time per stream; depth maps stay in HBM",
                    "streams_per_gpu": B, "windows": T, "events_per_step_per_gpu": n_events, "sensor": [Hs, Ws], "vit_trunk": cfg["vit"] if composite else None,
                    "parallelism": f"streams sharded x{world}, all_gather of velocities" if world > 1 else "single GPU"},
-        "step_ms": step_ms,
+        "step_ms": step_ms, "steps_executed": calls[0],
         "pipeline": ("two HIP streams: velocity model (ViT + LSTM) of step i under voxelize + depth model of step i + 1 "
                      "(evfly_amd/pipeline.py; --no-overlap = one stream)" if pipe else "one HIP stream"),
     }
@@ -453,22 +531,8 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         # --pmc WRITE_SIZE, separate runs of this script at this config's default shape; FETCH doubled per the gfx950
         # calibration in profiles/README.md). PMC counters cannot be read inside this process, so the figure is null for other shapes.
         traffic, tnote = None, "no PMC summary for this shape/dtype"
-        pmc = next((q for q in (os.path.join(REPO, "profiles", f) for f in PMC_TRAFFIC.get(cname, ())) if os.path.exists(q)), None)
-        if pmc and cfg == CONFIGS[cname]:
-            ks = json.load(open(pmc))["kernels"]
-            # fp32: the 17 Winograd launches; bf16 pipeline: the 3x3 convs run on four kernels (direct conv for C_in <= 64, the
-            # wide-tile implicit GEMMs for the deep layers -- per-tap tiles and the patch-staged form --, igemm16 for what is left; that family's count also holds the ViT / velpred
-            # convs, a rounding error in bytes)
-            fams = ["wino_conv3x3"] if dtype == "f32" else ["conv16_direct", "conv16w_deep", "conv16p_deep", "igemm16_conv"]
-            gs = [ks[f] for f in fams if f in ks]
-            g = None
-            if gs:
-                g = {k: sum(x[k] for x in gs) for k in ("fetch_bytes_per_step", "write_bytes_per_step")}
-                # kernel launches of the family per step (17 conv layers; Winograd split plans run two launches for some of them)
-                g["launches_per_step"] = max(1, round(dom["launches"] / a.steps))
-                traffic = round((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / g["launches_per_step"])
-                tnote = ("HBM bytes per launch, mean over the %d conv3x3 kernel launches of a step (17 layers): (2 x FETCH_SIZE + WRITE_SIZE) from "
-                         "profiles/%s; algorithmic = algorithmic.bytes_per_launch" % (g["launches_per_step"], os.path.basename(pmc)))
+        if cfg == CONFIGS[cname]:
+            traffic, tnote = pmc_traffic(cname, dtype, dom["launches"] / a.steps)
         if dom["flops"]:
             # `achieved` = the flops the matrix cores EXECUTE per second in this kernel family (exec_flops, from the launch plans);
             # the algorithmic (direct-conv, SURVEY.md §8d: 2*M*N*K) rate is kept beside it as frac_algorithmic / `algorithmic`.
@@ -536,18 +600,21 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         out["conv_layers"] = [{"name": p["name"], "ms_per_step": round(p["ms"], 3),
                                "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)}
                               for p in layers if p["name"].startswith(dom["name"] + "/")]
-        out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_bytes_moved": vox_bytes,
-                         "voxelize_GBs": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
-                         "voxelize_frac_of_hbm_peak": round(vox_bytes / (vox_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "voxelize_with_pass1_ms": round(vox1_ms, 4), "voxelize_with_pass1_bytes": vox1_bytes,
-                         "voxelize_with_pass1_GBs": round(vox1_bytes / (vox1_ms * 1e-3) / 1e9, 1),
-                         "voxelize_with_pass1_frac_of_hbm_peak": round(vox1_bytes / (vox1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms, 3),
-                         "voxelize_note": "voxelize_ms = what a timed step runs: the events are resident together with the voxelizer's pass-1 "
-                                          "tables (evfly_voxel_prepare at upload: per-stream sortedness, window -> event ranges), so the step's "
-                                          "kernel k_vox_band reads x, y, p (5 B/event) and writes the frames; voxelize_with_pass1 = the same "
-                                          "call on a batch without tables (k_check_sorted + k_window_ranges read the 8-B timestamps first: "
-                                          "13 B/event, SURVEY.md §8d's definition for fresh events); fractions = those bytes / ms / 8 TB/s"}
+        if vox_ms is None:
+            out["stages"] = {"model_ms": round(model_ms, 3)}
+        else:
+            out["stages"] = {"voxelize_ms": round(vox_ms, 4), "voxelize_bytes_moved": vox_bytes,
+                             "voxelize_GBs": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1),
+                             "voxelize_frac_of_hbm_peak": round(vox_bytes / (vox_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "voxelize_with_pass1_ms": round(vox1_ms, 4), "voxelize_with_pass1_bytes": vox1_bytes,
+                             "voxelize_with_pass1_GBs": round(vox1_bytes / (vox1_ms * 1e-3) / 1e9, 1),
+                             "voxelize_with_pass1_frac_of_hbm_peak": round(vox1_bytes / (vox1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "condition_ms": round(cond_ms, 4), "model_ms": round(model_ms, 3),
+                             "voxelize_note": "voxelize_ms = what a timed step runs: the events are resident together with the voxelizer's pass-1 "
+                                              "tables (evfly_voxel_prepare at upload: per-stream sortedness, window -> event ranges), so the step's "
+                                              "kernel k_vox_band reads x, y, p (5 B/event) and writes the frames; voxelize_with_pass1 = the same "
+                                              "call on a batch without tables (k_check_sorted + k_window_ranges read the 8-B timestamps first: "
+                                              "13 B/event, SURVEY.md §8d's definition for fresh events); fractions = those bytes / ms / 8 TB/s"}
         if detail and not a.no_stage_rates:
             # labelled per-stage rates ("publish both P-only and V+D+P"): each stage alone on the same batch,
             # inputs resident, torch events on the launch stream. V = voxelize + condition, D = OrigUNet + ConvLSTM,
@@ -576,7 +643,7 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             serial = sum(p["ms"] for p in prof if p["name"] in ("convlstm_h_gemm", "convlstm_gates"))
             xg = sum(p["ms"] for p in prof if p["name"] == "convlstm_x_gemm")
             one_ms = None
-            if detail and not a.no_stage_rates:
+            if not a.no_stage_rates:
                 with torch.no_grad():
                     x1 = voxelizer.condition_frames(frames.view(B * T, H, W)[:T], out_hw=(H, W))
                     one_ms = time_stage(lambda: model.forward_streams(x1, None, 1, T), reps=5)
@@ -611,6 +678,9 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                 mm.set_compute_dtype("f32")
         if detail and not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, a.cpu_seconds)
+        elif not detail and not a.no_cpu_baseline and a.side_cpu_seconds > 0:
+            # side configs: one thread count (the one that wins on these hosts), a few seconds -- a reported baseline, not a study
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, a.side_cpu_seconds, only_mid=True)
     # release this config's device memory (events, frames, the model handle's arena) before the next one is built
     del model, hip, hips, pipe, ev, frames, out_dev, desvel
     import gc

@@ -96,3 +96,46 @@ def test_bench_configs_are_the_baseline_configs():
     assert c["C5"]["windows"] == 16 and c["C5"]["dtype"] == "bf16" and c["C5"]["model"] == "unet"
     base = json.load(open(os.path.join(REPO, "BASELINE.json")))
     assert len(base["configs"]) == 5 and "batch=256, 480" in base["configs"][2] and "seq_len=16" in base["configs"][4]
+
+
+def _bench_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_pmc_traffic_rejects_a_summary_divided_by_the_wrong_step_count():
+    """Round 4's C2 PMC summary divided a 7-step run by 3 (wino_conv3x3: 65.33 launches per step) and the line claimed 2.36 x the
+    algorithmic traffic. bench.py now checks the file's own bookkeeping instead of trusting it."""
+    b = _bench_mod()
+    t, note = b.pmc_traffic("C2", "f32", 28, files=("r4_C2_pmc_traffic.json",))
+    assert t is None and "rejected" in note and "not a whole number" in note
+    # a consistent file passes, and a file whose conv launch count disagrees with the run is refused as well
+    import tempfile
+    good = {"steps_profiled": 3, "kernels": {"wino_conv3x3": {"fetch_bytes_per_step": 13.8e9, "write_bytes_per_step": 8.8e9, "launches_per_step": 28},
+                                              "k_condition": {"fetch_bytes_per_step": 4e8, "write_bytes_per_step": 1e8, "launches_per_step": 1}}}
+    with tempfile.NamedTemporaryFile("w", suffix=".json", dir=os.path.join(REPO, "profiles"), delete=False) as f:
+        json.dump(good, f)
+    try:
+        t, note = b.pmc_traffic("C2", "f32", 28.0, files=(os.path.basename(f.name),))
+        assert t == round(22.6e9 / 28) and "28 conv3x3" in note
+        t, note = b.pmc_traffic("C2", "f32", 24.0, files=(os.path.basename(f.name),))
+        assert t is None and "rejected" in note
+    finally:
+        os.unlink(f.name)
+
+
+def test_pmc_summary_tool_refuses_partial_steps():
+    """tools/pmc_traffic_summary.py: dispatch counts that are not a whole multiple of the executed steps are an error."""
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("pmc_sum", os.path.join(REPO, "tools", "pmc_traffic_summary.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rows = lambda n: [{"Kernel_Name": "void k_wino9<2, 5, false, false, 1>(ConvDesc)", "Counter_Value": "1000"}] * n
+    doc = m.summarise(rows(84), rows(84), 3)
+    assert doc["kernels"]["wino_conv3x3"]["launches_per_step"] == 28 and doc["steps_profiled"] == 3
+    with pytest.raises(SystemExit):
+        m.summarise(rows(196), rows(196), 3)
