@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "bf16.h"
 
@@ -188,16 +189,24 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             f_off[u] = fy * (d.W + 2) + fx;
         }
     }
+    // The frame values come through a buffer descriptor over all frames: ONE unconditional load per value -- lanes beyond the tile's
+    // part of the frame (and tiles beyond the batch) carry an out-of-range offset and read 0. (Round 4 spelled the edge test as
+    // `in ? fsrc[off] : 0`: an exec-mask branch around every load plus a v_mov 0 into the load's destination, in front of which hipcc
+    // drained the whole vector-memory queue -- `s_waitcnt vmcnt(0)` with the previous tile's six stores in flight -- every step.)
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(PRE ? d.pre_frames : nullptr), 0,
+        PRE ? (int)(unsigned)((int64_t)d.NI * (d.H + 2) * (d.W + 2) * 4) : 0, 0x00020000);
     auto frame_load = [&](int t) {
         if constexpr (kAbl16 & 4) return;          // timing experiment: no frame staging
         int img, ty, tx;
         tile_decode(t, img, ty, tx);
         const int fy0 = ty * TH, fx0 = tx * TW;                        // the frame is (H + 2) x (W + 2): frame pixel = e11 pixel + tap
-        const float *fsrc = d.pre_frames + ((int64_t)img * (d.H + 2) + fy0) * (d.W + 2) + fx0;
+        const unsigned fbase = (unsigned)(((int64_t)img * (d.H + 2) + fy0) * (d.W + 2) + fx0) * 4u;        // (tiles past the batch: past the descriptor)
         const int hrem = d.H + 2 - fy0, wrem = d.W + 2 - fx0;
 #pragma unroll
-        for (int u = 0; u < FPT; ++u)
-            fval[u] = ((f_yx[u] & 0xffff) < hrem && (f_yx[u] >> 16) < wrem) ? fsrc[f_off[u]] : 0.f;
+        for (int u = 0; u < FPT; ++u) {
+            const bool in = (f_yx[u] & 0xffff) < hrem && (f_yx[u] >> 16) < wrem;
+            fval[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fr, in ? (int)(fbase + (unsigned)f_off[u] * 4u) : (int)0xfffffff0u, 0, 0));
+        }
     };
     auto frame_store = [&](int fb) {
         float *f = fbuf + fb * FPIX;
@@ -314,8 +323,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         if (n_steps > 0) issue_patch(bis, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the same wait once more in the form hipcc's waitcnt pass reads: the prologue's ordinary loads -- first-conv weights and bias,
+    // bias16, dw -- are then known to have landed. Without it their wait sinks to the first use INSIDE the step loop, where the
+    // entry path needs vmcnt(0) for them and the loop therefore drains the queue -- stores included -- every step.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-
 
     const int fj = lane & 31, fh = lane >> 5;
     bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
@@ -354,7 +366,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     bool st_pending = false;
     auto stage_tile = [&]() {
         st_pending = st_tile >= 0;
-        if (!st_pending) return;
+        if (!st_pending) {          // (the stores are issued all the same, with out-of-range offsets: a step's vector-memory traffic is then
+#pragma unroll                      //  the same COUNT on every path and hipcc's waits in front of the frame values can be vmcnt(NST))
+            for (int r = 0; r <= ROWS; ++r) st_off[r] = OOB;
+            return;
+        }
         int img, ty, tx;
         tile_decode(st_tile, img, ty, tx);
         const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     // Lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: the swaps of group g hand lane l channels
     // 16 g .. 16 g + 7 and lane l + 32 channels 16 g + 8 .. 16 g + 15 (16 B each)
     auto issue_stores = [&](int k0, int k1) {          // (compile-time range after unrolling)
-        if (!st_pending) return;
+        if (!PRE && !st_pending) return;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             if (k < k0 || k >= k1) continue;
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         // the step) then leaves the younger stores in flight; nothing else in a PRE step waits for vector memory, the stores of tile
         // t drain under the steps of tiles t + 1, t + 2
         if constexpr (PRE) {
-            if (s + 2 < n_steps) frame_load(t_cur + 2 * g.blocks_per_slice);
+            frame_load(t_cur + 2 * g.blocks_per_slice);      // (unconditional: behind the last tile the offsets are out of range)
         }
         stage_tile();
         if constexpr (!SPREAD) issue_stores(0, NST);
@@ -500,7 +516,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         if constexpr (PRE) {
             if ((wv & 1) == 1 && s + 1 < n_steps) produce_patch(t_cur + g.blocks_per_slice, (s + 1) & 1, (s + 1) & 1);
             C16_TS(3);                         // 3: odd waves' producer
-            if (s + 2 < n_steps) frame_store(s & 1);
+            frame_store(s & 1);                    // (behind the last tile: zeros into a buffer nobody reads)
             C16_TS(4);                         // 4: frame store (waits for the frame loads)
         }
         if (cc == nchunks - 1) {
@@ -587,6 +603,318 @@ namespace evfly {
 namespace {
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_conv16pre (round 5): the fused-first-conv layer (e12: first U-Net conv on the fly + 32 -> 32 conv + ReLU [+ 2x2 max pool]) rebuilt
+// around ONE observation: with two waves per SIMD a wave issues at most one instruction per ~4 cycles, and k_conv16<2, 1, POOL, true>
+// executed ~840 instructions per wave and tile step around its 36 MFMAs (1152 matrix-pipe cycles) -- 7.2 k cycles per step, in
+// phases (produce | multiply | pack + pool | stage) during most of which the matrix pipe idles. Here a step is one stream in which
+// everything that is not an MFMA rides in the MFMAs' issue shadow:
+//   * the finished tile is NOT packed behind its MFMAs: its accumulators stay in registers (two accumulator sets, the step body is
+//     instantiated for both) and ReLU / rounding / pool / lane swaps / stores of tile t go, a sixth at a time, between the MFMAs of
+//     tile t + 1;
+//   * the producer of tile t + 1's patch (first conv on the matrix cores, k_conv16's scheme) is cut into an A stage (taps ->
+//     operand -> MFMA) and a B stage one fragment-loop iteration later (ReLU, rounding, swaps, two 16-B LDS writes), both inside
+//     the fragment loop of every wave (no even / odd split, no phase of its own);
+//   * ReLU is ONE v_pk_max_i16 per rounded pair (the signed-integer order of bf16 bit patterns: negative values and -0 become
+//     +0; a NaN passes unless its sign bit is set -- frames and weights are finite), the bias is the C operand of the
+//     step's first MFMAs (no accumulator initialisation), patch pixels beyond the map are left as they come (they only feed output
+//     pixels that are never stored), every vector-memory instruction of a step is unconditional (out-of-range offsets) so that
+//     hipcc's waits are counted, and a tile is decoded once (packed into one SGPR) instead of three times.
+// Same arithmetic, same rounding points as k_conv16<2, 1, POOL, true>: bit-identical outputs (tests/test_gpu_bf16.py).
+template <bool POOL>
+__global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, const bf16_t *__restrict__ wd) {
+    constexpr int ROWS = 2, TH = NWAVE * ROWS, PH = TH + 2, NPIX = PH * PWD;
+    constexpr int FH = PH + 2, FW = PWD + 2, FPIX = FH * FW;
+    constexpr int NMT = (NPIX + 31) / 32;                       // 32-pixel producer tiles of a patch (20: waves 0-3 take three, 4-7 two)
+    constexpr int PATCH_BYTES = NMT * 32 * 64;                  // (room for the last producer tile's pixels beyond the patch: its lanes write unconditionally)
+    constexpr int FPT = (FPIX + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
+    // LDS: [patch 0][patch 1][weights 18 KiB][bias 32 f][formed frame patches 2 x FPIX f][tap tables]
+    unsigned char *wl = smem + 2 * PATCH_BYTES;
+    float *bl = reinterpret_cast<float *>(wl + 18 * 1024);
+    float *fbuf = bl + 32;
+    unsigned char *taps = smem + 2 * PATCH_BYTES + 18 * 1024 + 128 + 2 * FPIX * 4;      // (2 * FPIX * 4 = 5760: 16-B aligned)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bis = blockIdx.x;                                  // one 32-channel slice: every block walks tiles bis, bis + gridDim.x, ...
+    const int bps = g.blocks_per_slice;
+    {
+        const uint64_t wbase = (uint64_t)(uintptr_t)wd;
+        i32x4 srd = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xffff), 18 * 1024, 0x00020000};
+        srd[0] = __builtin_amdgcn_readfirstlane(srd[0]); srd[1] = __builtin_amdgcn_readfirstlane(srd[1]);
+        for (int pc = wv; pc < 18; pc += NWAVE)
+            dma16((unsigned)(pc * 1024 + lane * 16), srd, __builtin_amdgcn_readfirstlane(lds0 + 2 * PATCH_BYTES + (unsigned)pc * 1024u));
+    }
+    if (tid < 32) bl[tid] = d.bias ? d.bias[tid] : 0.f;
+    const bool masked = d.tap_h > 0;
+    if (masked) {
+        for (int i = tid; i < d.OH + d.OW; i += 512) taps[i] = 0;
+        __syncthreads();
+        const float sh = (float)d.OH / (float)d.tap_h, sw = (float)d.OW / (float)d.tap_w;
+        for (int i = tid; i < d.tap_h + d.tap_w; i += 512) {
+            const bool row = i < d.tap_h;
+            int i0, i1;
+            float l0, l1;
+            bilinear_src_index(row ? i : i - d.tap_h, row ? d.OH : d.OW, row ? d.tap_h : d.tap_w, row ? sh : sw, 0, i0, i1, l0, l1);
+            unsigned char *t = taps + (row ? 0 : d.OH);
+            t[i0] = 1; t[i1] = 1;
+        }
+    }
+    // ---- tiles: decoded once, carried as img | ty << 16 | tx << 24 in one SGPR
+    auto tile_pack = [&](int t) -> unsigned {
+        const int rowq = g.tiles_x == 1 ? t : (int)__umulhi((unsigned)t, g.u_tx);
+        const int tx = t - rowq * g.tiles_x;
+        const int img = g.tiles_y == 1 ? rowq : (int)__umulhi((unsigned)rowq, g.u_ty);
+        const int ty = rowq - img * g.tiles_y;
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)img | ((unsigned)ty << 16) | ((unsigned)tx << 24)));
+    };
+    // ---- frame staging (k_conv16's, through a buffer descriptor: out-of-range lanes and tiles behind the batch read 0)
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.pre_frames), 0,
+        (int)(unsigned)((int64_t)d.NI * (d.H + 2) * (d.W + 2) * 4), 0x00020000);
+    float fval[FPT];
+    int f_yx[FPT];
+#pragma unroll
+    for (int u = 0; u < FPT; ++u) {
+        const int i = tid + u * 512;
+        const int fy = i / FW, fx = i - fy * FW;
+        f_yx[u] = i < FPIX ? (fy | (fx << 16)) : (0x7fff | (0x7fff << 16));
+    }
+    auto frame_load = [&](unsigned tp) __attribute__((always_inline)) {
+        const int img = (int)(tp & 0xffffu), fy0 = (int)((tp >> 16) & 0xffu) * TH, fx0 = (int)(tp >> 24) * TW;
+        const unsigned fbase = (unsigned)(((int64_t)img * (d.H + 2) + fy0) * (d.W + 2) + fx0) * 4u;
+        const int hrem = d.H + 2 - fy0, wrem = d.W + 2 - fx0;
+#pragma unroll
+        for (int u = 0; u < FPT; ++u) {
+            const bool in = (f_yx[u] & 0xffff) < hrem && (f_yx[u] >> 16) < wrem;
+            fval[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fr, in ? (int)(fbase + (unsigned)((f_yx[u] & 0xffff) * (d.W + 2) + (f_yx[u] >> 16)) * 4u) : (int)0xfffffff0u, 0, 0));
+        }
+    };
+    auto frame_store = [&](int fb) __attribute__((always_inline)) {
+        float *f = fbuf + fb * FPIX;
+#pragma unroll
+        for (int u = 0; u < FPT; ++u) {
+            const int i = tid + u * 512;
+            float v = fval[u];
+            if (d.pre_apply_form) {                                     // learner_models.py:476-494 (ops16.hip form_value16)
+                if (fabsf(v) < d.pre_cutoff) v = 0.0f;
+                if (d.pre_form_bev == 2) v = v != 0.0f ? 1.0f : 0.0f;
+                else if (d.pre_form_bev == 1) v = fabsf(v);
+                else v = v > 0.0f ? v : 0.0f;
+            }
+            if (i < FPIX) f[i] = v;
+        }
+    };
+    // ---- producer (k_conv16's first conv on the matrix cores), per lane: A = the 32 channels' taps, bias as C
+    bf16x8 pwa;
+    f32x16 pbias16;
+    {
+        const int ch = lane & 31, kh = lane >> 5;
+        float wv8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int t = 8 * kh + e; wv8[e] = t < 9 ? d.pre_w[t * 32 + ch] : 0.f; }
+        const uint4 wp4 = make_uint4(pack_bf2(wv8[0], wv8[1]), pack_bf2(wv8[2], wv8[3]), pack_bf2(wv8[4], wv8[5]), pack_bf2(wv8[6], wv8[7]));
+        pwa = *reinterpret_cast<const bf16x8 *>(&wp4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pbias16[r] = d.pre_b[(r & 3) + 8 * (r >> 2) + 4 * kh];
+    }
+    constexpr int NSLOT = (NMT + NWAVE - 1) / NWAVE;             // 3
+    int pp_f[NSLOT], pp_d0[NSLOT];         // (the pixel's second chunk: pp_d0 ^ 32)
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int q = (wv + i * NWAVE) * 32 + (lane & 31), qc = q < NPIX ? q : NPIX - 1;
+        const int pr = qc / PWD, pcx = qc - pr * PWD;
+        pp_f[i] = (pr * FW + pcx) * 4;
+        pp_d0[i] = patch_off(q, lane >> 5);
+    }
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto relu2 = [](unsigned x) -> unsigned {                     // ReLU of a rounded pair: v_pk_max_i16 against 0
+        const i16x2 z = {0, 0};
+        const i16x2 r = __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), z);
+        return __builtin_bit_cast(unsigned, r);
+    };
+    auto pmax = [](unsigned x, unsigned y) -> unsigned {
+        const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y));
+        return __builtin_bit_cast(unsigned, r);
+    };
+    // stage A of producer slot i: nine taps of this lane's patch pixel (eight per half, see k_conv16) -> one MFMA
+    auto prod_a = [&](int i, int fb) __attribute__((always_inline)) -> f32x16 {
+        const unsigned char *fp = reinterpret_cast<const unsigned char *>(fbuf + fb * FPIX) + pp_f[i];
+        const int kh = lane >> 5;
+        float v[8];
+        v[0] = *reinterpret_cast<const float *>(fp + (kh ? (2 * FW + 2) * 4 : 0));
+        v[1] = *reinterpret_cast<const float *>(fp + 4); v[2] = *reinterpret_cast<const float *>(fp + 8);
+        v[3] = *reinterpret_cast<const float *>(fp + FW * 4); v[4] = *reinterpret_cast<const float *>(fp + FW * 4 + 4);
+        v[5] = *reinterpret_cast<const float *>(fp + FW * 4 + 8); v[6] = *reinterpret_cast<const float *>(fp + 2 * FW * 4);
+        v[7] = *reinterpret_cast<const float *>(fp + 2 * FW * 4 + 4);
+        const uint4 b4 = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pwa, *reinterpret_cast<const bf16x8 *>(&b4), pbias16, 0, 0, 0);
+    };
+    // stage B: ReLU + rounding, lane swaps, the pixel's two 16-B chunks into the patch
+    auto prod_b = [&](int i, const f32x16 &a, int buf) __attribute__((always_inline)) {
+        unsigned char *dstb = smem + buf * PATCH_BYTES;
+        unsigned pkd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pkd[k] = relu2(pack_bf2(a[2 * k], a[2 * k + 1]));
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            unsigned o[4];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(pkd[(2 * grp) * 2 + w], pkd[(2 * grp + 1) * 2 + w], false, false);
+                o[w] = sw[0]; o[2 + w] = sw[1];
+            }
+            *reinterpret_cast<uint4 *>(dstb + (grp == 0 ? pp_d0[i] : (pp_d0[i] ^ 32))) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    };
+
+    const int n_my = (g.n_tiles - bis + bps - 1) / bps;          // >= 1 (blocks_per_slice <= n_tiles)
+    // ---- prologue: frame patch of tile 0 -> fbuf 0, patch 0 produced; frame patch of tile 1 -> fbuf 1
+    unsigned t_m1 = 0, t_0 = tile_pack(bis), t_1 = tile_pack(bis + bps), t_2 = tile_pack(bis + 2 * bps);      // tiles s - 1, s, s + 1, s + 2
+    frame_load(t_0); frame_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // (the compiler-visible twin: see k_conv16)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i)
+        if (wv + i * NWAVE < NMT) { const f32x16 a = prod_a(i, 0); prod_b(i, a, 0); }
+    frame_load(t_1); frame_store(1);
+    __syncthreads();
+
+    const int fj = lane & 31, fh = lane >> 5;
+    bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y16, 0, (int)(unsigned)((int64_t)d.NI * d.OH * d.OW * d.ldy * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+        POOL ? reinterpret_cast<bf16_t *>(g.y_pool) : y16, 0, POOL ? (int)(unsigned)((int64_t)d.NI * (d.OH / 2) * (d.OW / 2) * d.Nc * 2) : 0, 0x00020000);
+    f32x16 bias16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias16[e] = bl[(e & 3) + 8 * (e >> 2) + 4 * fh];
+
+    // byte offsets of this lane's pixel of tile tp in its two output rows and in the pooled map (OOB: nothing to store)
+    unsigned st_off[ROWS + 1];
+    auto stage = [&](unsigned tp, bool valid) __attribute__((always_inline)) {
+        const int img = (int)(tp & 0xffffu), ty = (int)((tp >> 16) & 0xffu), tx = (int)(tp >> 24);
+        const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
+        const bool col_ok = valid && ox < d.OW && (!masked || taps[d.OH + min(ox, d.OW - 1)]);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int oy = oy0 + r;
+            st_off[r] = !(col_ok && oy < d.OH && (!masked || taps[min(oy, d.OH - 1)])) ? OOB : (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2);
+        }
+        st_off[ROWS] = OOB;
+        if constexpr (POOL) {
+            const int PHo = d.OH / 2, PWo = d.OW / 2;
+            const int py = oy0 >> 1, pxo = ox >> 1;
+            const bool pok = valid && (fj & 1) == 0 && py < PHo && pxo < PWo;
+            st_off[ROWS] = pok ? (unsigned)((((int64_t)img * PHo + py) * PWo + pxo) * d.Nc * 2) : OOB;
+        }
+    };
+    // One sixth of the finished tile's epilogue (piece 0..5): rows' channel group gq = piece / 3 -- piece % 3 == 0: row 0 packed +
+    // stored; 1: row 1 packed + stored, the pool of the group formed; 2: the pool stored. pk0 / pmx carry a group's packed row 0 /
+    // pooled values from one piece to the next.
+    unsigned pk0[4], pmx[4];
+    auto store16 = [&](const unsigned (&p)[4], const __amdgpu_buffer_rsrc_t &rs, unsigned px_off, int gq) __attribute__((always_inline)) {
+        unsigned o[4];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(p[w], p[2 + w], false, false);
+            o[w] = sw[0]; o[2 + w] = sw[1];
+        }
+        const unsigned vo = px_off != OOB ? px_off + (unsigned)(gq * 16 + fh * 8) * 2u : OOB;
+        const u32x4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)vo, 0, 0);
+    };
+    auto epi_piece = [&](int piece, const f32x16 (&a)[ROWS]) __attribute__((always_inline)) {
+        const int gq = piece / 3, ph = piece % 3;
+        if (ph == 2) {
+            if constexpr (POOL) store16(pmx, pr, st_off[ROWS], gq);
+            return;
+        }
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = relu2(pack_bf2(a[ph][8 * gq + 2 * k], a[ph][8 * gq + 2 * k + 1]));
+        store16(p, yr, st_off[ph], gq);
+        if (ph == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk0[k] = p[k];
+        } else if constexpr (POOL) {
+            // 2x2 max pool on the rounded, activated values as unsigned 16-bit integers (k_conv16: NaN-propagating like torch)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned v = pmax(pk0[k], p[k]);
+                pmx[k] = pmax(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));      // lane ^ 1
+            }
+        }
+    };
+
+    // ---- one tile step: aC accumulates tile s, aP holds tile s - 1 (tpP; ok_p: there is one)
+    auto step = [&](f32x16 (&aC)[ROWS], f32x16 (&aP)[ROWS], int s, unsigned tpP, bool ok_p, unsigned tpF) __attribute__((always_inline)) {
+        frame_load(tpF);                                          // frame patch of tile s + 2 (behind the batch: zeros)
+        stage(tpP, ok_p);
+        const unsigned char *pb = smem + (s & 1) * PATCH_BYTES;
+        const int nb = (s + 1) & 1;                               // patch / frame buffer of tile s + 1
+        bf16x8 pxq[2][ROWS + 2], wfq[2][3];
+        auto load_it = [&](int it, bf16x8 (&pxd)[ROWS + 2], bf16x8 (&wfd)[3]) __attribute__((always_inline)) {
+            const int kx = it >> 1, kb = it & 1;
+#pragma unroll
+            for (int y = 0; y < ROWS + 2; ++y) {
+                const int q = (wv * ROWS + y) * PWD + fj + kx;
+                pxd[y] = *reinterpret_cast<const bf16x8 *>(pb + patch_off(q, kb * 2 + fh));
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                wfd[ky] = *reinterpret_cast<const bf16x8 *>(wl + ((ky * 3 + kx) * 2 + kb) * 1024 + lane * 16);
+        };
+        load_it(0, pxq[0], wfq[0]);
+        f32x16 pa;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            if (it + 1 < 6) load_it(it + 1, pxq[(it + 1) & 1], wfq[(it + 1) & 1]);
+            // producer: A of slot 0 / 1 / 2 in iterations 0 / 2 / 4, B one iteration later (slot 2 exists for waves 0-3 only)
+            if (it == 0) pa = prod_a(0, nb);
+            if (it == 2) pa = prod_a(1, nb);
+            if (it == 4 && wv + 2 * NWAVE < NMT) pa = prod_a(2, nb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+                    aC[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[it & 1][ky], pxq[it & 1][r + ky], (it == 0 && ky == 0) ? bias16 : aC[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            epi_piece(it, aP);
+            if (it == 1) prod_b(0, pa, nb);
+            if (it == 3) prod_b(1, pa, nb);
+            if (it == 5 && wv + 2 * NWAVE < NMT) prod_b(2, pa, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        frame_store(s & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    f32x16 acc0[ROWS], acc1[ROWS];
+    for (int s = 0; s < n_my; s += 2) {      // two steps per trip: the accumulator sets swap roles
+        const unsigned t_3 = tile_pack(bis + (s + 3) * bps);
+        step(acc0, acc1, s, t_m1, s > 0, t_2);
+        if (s + 1 < n_my) step(acc1, acc0, s + 1, t_0, true, t_3);
+        t_m1 = t_1; t_0 = t_2; t_1 = t_3; t_2 = tile_pack(bis + (s + 4) * bps);
+    }
+    // ---- the last tile's epilogue (tile n_my - 1: acc0 if n_my is odd)
+    {
+        const unsigned tl = tile_pack(bis + (n_my - 1) * bps);
+        stage(tl, true);
+        if (n_my & 1) {
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) epi_piece(pc, acc0);
+        } else {
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) epi_piece(pc, acc1);
+        }
+    }
+}
+
 template <int ROWS, int NTB, bool POOL, bool PRE, bool DOT = false>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
@@ -603,6 +931,28 @@ int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStrea
     }
     EVFLY_REQUIRE(lds <= kMaxLds, "conv16: %d B of LDS", lds);
     hipLaunchKernelGGL(kern, dim3(g.n_slices * g.blocks_per_slice), dim3(512), lds, st, d, g, wd);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool POOL>
+int launch16pre(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
+    constexpr int TH = 16, NPIX = (TH + 2) * PWD, NMT = (NPIX + 31) / 32, FPIX = (TH + 4) * (PWD + 2);
+    const int lds = 2 * NMT * 32 * 64 + 18 * 1024 + 128 + 2 * FPIX * 4 + (d.tap_h > 0 ? (d.OH + d.OW + 15) / 16 * 16 : 0);
+    EVFLY_REQUIRE(d.tap_h == 0 || (POOL && d.tap_w > 0 && d.tap_h <= d.OH && d.tap_w <= d.OW), "conv16: masked stores go with the fused pool");
+    EVFLY_REQUIRE(d.NI < 65536 && g.tiles_y < 256 && g.tiles_x < 256 && g.n_slices == 1, "conv16pre: tile coordinates do not fit one register");
+    EVFLY_REQUIRE((int64_t)d.NI * (d.H + 2) * (d.W + 2) * 4 < ((int64_t)1 << 31), "conv16pre: frames beyond 2 GB");
+    auto kern = k_conv16pre<POOL>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    EVFLY_REQUIRE(lds <= kMaxLds, "conv16pre: %d B of LDS", lds);
+    hipLaunchKernelGGL(kern, dim3(g.blocks_per_slice), dim3(512), lds, st, d, g, wd);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
@@ -694,6 +1044,10 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
     if (d.pre_frames) {     // fused first conv: C_in = 32, one frame channel, 16-row tiles, one output tile per block
         EVFLY_REQUIRE(d.C == 32 && d.pre_cin == 1 && d.pre_w && d.pre_b && ntb == 1 && rows == 2, "conv16: the fused first-conv producer needs C_in = 32, "
                       "one frame channel and C_out = 32");
+        // round 5: the one-stream form of this layer (k_conv16pre); EVFLY_CONV16_PRE_OLD=1 keeps the phased kernel for A/B runs
+        static const bool old_pre = getenv("EVFLY_CONV16_PRE_OLD") != nullptr;
+        if (!old_pre && d.Nc == 32 && d.NI < 65536 && g.tiles_y < 256 && g.tiles_x < 256)
+            return pool ? launch16pre<true>(d, g, w, st) : launch16pre<false>(d, g, w, st);
         return pool ? launch16d<2, 1, true, true>(d, g, w, st) : launch16d<2, 1, false, true>(d, g, w, st);
     }
     if (d.dot_y) {          // unet_out in the epilogue instead of the 32-channel map (the caller checked conv16_dot_fusable)
