@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     // (the same wait once more in the form hipcc's waitcnt pass reads: the prologue's ordinary loads -- first-conv weights and bias,
     // bias16, dw -- are then known to have landed. Without it their wait sinks to the first use INSIDE the step loop, where the
     // entry path needs vmcnt(0) for them and the loop therefore drains the queue -- stores included -- every step.)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if constexpr (PRE) __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     const int fj = lane & 31, fh = lane >> 5;
@@ -366,9 +366,11 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     bool st_pending = false;
     auto stage_tile = [&]() {
         st_pending = st_tile >= 0;
-        if (!st_pending) {          // (the stores are issued all the same, with out-of-range offsets: a step's vector-memory traffic is then
-#pragma unroll                      //  the same COUNT on every path and hipcc's waits in front of the frame values can be vmcnt(NST))
-            for (int r = 0; r <= ROWS; ++r) st_off[r] = OOB;
+        if (!st_pending) {          // (PRE: the stores are issued all the same, with out-of-range offsets: a step's vector-memory traffic
+            if constexpr (PRE) {    //  is then the same COUNT on every path and hipcc's waits in front of the frame values can be vmcnt(NST))
+#pragma unroll
+                for (int r = 0; r <= ROWS; ++r) st_off[r] = OOB;
+            }
             return;
         }
         int img, ty, tx;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     stage_tile();
     issue_stores(0, NST);
 #ifdef EVFLY_C16_TS
-    if (lane == 0 && blockIdx.x < 256) {
+    if (PRE && lane == 0 && blockIdx.x < 256) {      // (the fused-first-conv layer only: later layers must not overwrite its record)
         ts_acc[7] = (unsigned long long)n_steps;
 #pragma unroll
         for (int i = 0; i < 8; ++i) g_c16_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_acc[i];
@@ -621,6 +623,14 @@ namespace {
 //     pixels that are never stored), every vector-memory instruction of a step is unconditional (out-of-range offsets) so that
 //     hipcc's waits are counted, and a tile is decoded once (packed into one SGPR) instead of three times.
 // Same arithmetic, same rounding points as k_conv16<2, 1, POOL, true>: bit-identical outputs (tests/test_gpu_bf16.py).
+#ifndef EVFLY_C16_PRE_IL
+#define EVFLY_C16_PRE_IL 6
+#endif
+constexpr int kPreInterleave = EVFLY_C16_PRE_IL;
+#ifndef EVFLY_C16_PRE_PRIO
+#define EVFLY_C16_PRE_PRIO 0
+#endif
+constexpr int kPrePrio = EVFLY_C16_PRE_PRIO;        // VALU instructions scheduled behind each MFMA of the fragment loop (0: hipcc's own order)
 template <bool POOL>
 __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, const bf16_t *__restrict__ wd) {
     constexpr int ROWS = 2, TH = NWAVE * ROWS, PH = TH + 2, NPIX = PH * PWD;
@@ -630,11 +640,12 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
     constexpr int FPT = (FPIX + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
-    // LDS: [patch 0][patch 1][weights 18 KiB][bias 32 f][formed frame patches 2 x FPIX f][tap tables]
+    // LDS: [patch 0][patch 1][weights 18 KiB][bias 32 f][formed frame patches 2 x FPIX f][producer constants 2 FW + 4 f][row / column bits]
     unsigned char *wl = smem + 2 * PATCH_BYTES;
     float *bl = reinterpret_cast<float *>(wl + 18 * 1024);
     float *fbuf = bl + 32;
-    unsigned char *taps = smem + 2 * PATCH_BYTES + 18 * 1024 + 128 + 2 * FPIX * 4;      // (2 * FPIX * 4 = 5760: 16-B aligned)
+    float *ctab = fbuf + 2 * FPIX;
+    unsigned char *taps = reinterpret_cast<unsigned char *>(ctab + 2 * FW + 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bis = blockIdx.x;                                  // one 32-channel slice: every block walks tiles bis, bis + gridDim.x, ...
@@ -647,18 +658,31 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
             dma16((unsigned)(pc * 1024 + lane * 16), srd, __builtin_amdgcn_readfirstlane(lds0 + 2 * PATCH_BYTES + (unsigned)pc * 1024u));
     }
     if (tid < 32) bl[tid] = d.bias ? d.bias[tid] : 0.f;
-    const bool masked = d.tap_h > 0;
-    if (masked) {
-        for (int i = tid; i < d.OH + d.OW; i += 512) taps[i] = 0;
+    // Which output pixels are stored: bit (row within the tile) of rowbits[ty], bit (column within the tile) of colbits[tx] -- inside
+    // the map and, with tap_h > 0 (the map's only other reader is the resize to tap_h x tap_w), a tap row / column of that resize
+    // (bilinear_src_index, the resize kernel's own arithmetic). Two uniform 4-byte LDS reads per step instead of per-pixel byte
+    // lookups behind exec-mask branches (first version: three dependent LDS round trips at the top of every step, ~700 cycles).
+    unsigned *rowbits = reinterpret_cast<unsigned *>(taps), *colbits = rowbits + g.tiles_y;
+    {
+        const bool masked = d.tap_h > 0;
+        for (int i = tid; i < g.tiles_y + g.tiles_x; i += 512) rowbits[i] = 0;
         __syncthreads();
-        const float sh = (float)d.OH / (float)d.tap_h, sw = (float)d.OW / (float)d.tap_w;
-        for (int i = tid; i < d.tap_h + d.tap_w; i += 512) {
-            const bool row = i < d.tap_h;
-            int i0, i1;
-            float l0, l1;
-            bilinear_src_index(row ? i : i - d.tap_h, row ? d.OH : d.OW, row ? d.tap_h : d.tap_w, row ? sh : sw, 0, i0, i1, l0, l1);
-            unsigned char *t = taps + (row ? 0 : d.OH);
-            t[i0] = 1; t[i1] = 1;
+        if (!masked) {
+            for (int i = tid; i < d.OH + d.OW; i += 512) {
+                const bool row = i < d.OH;
+                const int p = row ? i : i - d.OH;
+                atomicOr(row ? &rowbits[p / TH] : &colbits[p / TW], 1u << (row ? p % TH : p % TW));
+            }
+        } else {
+            const float sh = (float)d.OH / (float)d.tap_h, sw = (float)d.OW / (float)d.tap_w;      // launch16_bilinear's scales
+            for (int i = tid; i < d.tap_h + d.tap_w; i += 512) {
+                const bool row = i < d.tap_h;
+                int i0, i1;
+                float l0, l1;
+                bilinear_src_index(row ? i : i - d.tap_h, row ? d.OH : d.OW, row ? d.tap_h : d.tap_w, row ? sh : sw, 0, i0, i1, l0, l1);
+                if (row) { atomicOr(&rowbits[i0 / TH], 1u << (i0 % TH)); atomicOr(&rowbits[i1 / TH], 1u << (i1 % TH)); }
+                else { atomicOr(&colbits[i0 / TW], 1u << (i0 % TW)); atomicOr(&colbits[i1 / TW], 1u << (i1 % TW)); }
+            }
         }
     }
     // ---- tiles: decoded once, carried as img | ty << 16 | tx << 24 in one SGPR
@@ -690,34 +714,42 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
             fval[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fr, in ? (int)(fbase + (unsigned)((f_yx[u] & 0xffff) * (d.W + 2) + (f_yx[u] >> 16)) * 4u) : (int)0xfffffff0u, 0, 0));
         }
     };
+    // form_input (learner_models.py:476-494; ops16.hip form_value16) as selects on wave-uniform flags: no branch in the step
+    const float f_cut = d.pre_apply_form ? d.pre_cutoff : 0.f;       // (|v| < 0 never holds: no cutoff without apply_form)
+    const bool f_b2 = d.pre_apply_form && d.pre_form_bev == 2, f_b1 = d.pre_apply_form && d.pre_form_bev == 1, f_b0 = d.pre_apply_form && !f_b2 && !f_b1;
     auto frame_store = [&](int fb) __attribute__((always_inline)) {
         float *f = fbuf + fb * FPIX;
 #pragma unroll
         for (int u = 0; u < FPT; ++u) {
             const int i = tid + u * 512;
             float v = fval[u];
-            if (d.pre_apply_form) {                                     // learner_models.py:476-494 (ops16.hip form_value16)
-                if (fabsf(v) < d.pre_cutoff) v = 0.0f;
-                if (d.pre_form_bev == 2) v = v != 0.0f ? 1.0f : 0.0f;
-                else if (d.pre_form_bev == 1) v = fabsf(v);
-                else v = v > 0.0f ? v : 0.0f;
-            }
-            if (i < FPIX) f[i] = v;
+            v = fabsf(v) < f_cut ? 0.0f : v;
+            const float v2 = v != 0.0f ? 1.0f : 0.0f, v1 = fabsf(v), v0 = v > 0.0f ? v : 0.0f;
+            v = f_b2 ? v2 : f_b1 ? v1 : f_b0 ? v0 : v;
+            if (FPT * 512 == FPIX || i < FPIX) f[i] = v;
         }
     };
-    // ---- producer (k_conv16's first conv on the matrix cores), per lane: A = the 32 channels' taps, bias as C
+    // ---- producer (k_conv16's first conv on the matrix cores). K = 16 slots: taps 0-7 in lanes 0-31, tap 8 + the BIAS in lanes 32-63:
+    // the fp32 bias rides in three k-slots as an exact three-term bf16 split (b = b1 + b2 + b3, each term the bf16 rounding of what is
+    // left) against B = 1.0, so that the MFMA's C operand is the constant 0 -- the 16 registers of a bias accumulator are what the
+    // second set of store offsets and the deeper frame pipeline below live in. The upper half's B values for slots 1..7 come from a
+    // small constant table in LDS (1, 1, 1, 0, 0, 0, 0 at the offsets the tap loads use): the same eight loads for every lane.
     bf16x8 pwa;
-    f32x16 pbias16;
     {
         const int ch = lane & 31, kh = lane >> 5;
         float wv8[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int t = 8 * kh + e; wv8[e] = t < 9 ? d.pre_w[t * 32 + ch] : 0.f; }
+        for (int e = 0; e < 8; ++e) wv8[e] = kh == 0 ? d.pre_w[e * 32 + ch] : 0.f;
+        if (kh) {
+            const float b = d.pre_b[ch];
+            const float b1 = bf_lo(pack_bf2(b, 0.f)), b2 = bf_lo(pack_bf2(b - b1, 0.f)), b3 = bf_lo(pack_bf2((b - b1) - b2, 0.f));
+            wv8[0] = d.pre_w[8 * 32 + ch]; wv8[1] = b1; wv8[2] = b2; wv8[3] = b3;
+        }
         const uint4 wp4 = make_uint4(pack_bf2(wv8[0], wv8[1]), pack_bf2(wv8[2], wv8[3]), pack_bf2(wv8[4], wv8[5]), pack_bf2(wv8[6], wv8[7]));
         pwa = *reinterpret_cast<const bf16x8 *>(&wp4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pbias16[r] = d.pre_b[(r & 3) + 8 * (r >> 2) + 4 * kh];
     }
+    // constant table: float index 1, 2, FW -> 1.0 (slots 1..3 of the upper half), every other index the tap loads touch -> 0
+    for (int i = tid; i < 2 * FW + 4; i += 512) ctab[i] = (i == 1 || i == 2 || i == FW) ? 1.0f : 0.0f;
     constexpr int NSLOT = (NMT + NWAVE - 1) / NWAVE;             // 3
     int pp_f[NSLOT], pp_d0[NSLOT];         // (the pixel's second chunk: pp_d0 ^ 32)
 #pragma unroll
@@ -738,18 +770,21 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
         const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y));
         return __builtin_bit_cast(unsigned, r);
     };
-    // stage A of producer slot i: nine taps of this lane's patch pixel (eight per half, see k_conv16) -> one MFMA
+    const int kh_l = lane >> 5;
+    const unsigned ctab_off = (unsigned)(reinterpret_cast<unsigned char *>(ctab) - smem);
+    // stage A of producer slot i: this lane's eight B values -> one MFMA (C = 0)
     auto prod_a = [&](int i, int fb) __attribute__((always_inline)) -> f32x16 {
         const unsigned char *fp = reinterpret_cast<const unsigned char *>(fbuf + fb * FPIX) + pp_f[i];
-        const int kh = lane >> 5;
+        const unsigned char *fq = kh_l ? smem + ctab_off : fp;      // slots 1..7: taps (lower half) or the constants (upper half)
         float v[8];
-        v[0] = *reinterpret_cast<const float *>(fp + (kh ? (2 * FW + 2) * 4 : 0));
-        v[1] = *reinterpret_cast<const float *>(fp + 4); v[2] = *reinterpret_cast<const float *>(fp + 8);
-        v[3] = *reinterpret_cast<const float *>(fp + FW * 4); v[4] = *reinterpret_cast<const float *>(fp + FW * 4 + 4);
-        v[5] = *reinterpret_cast<const float *>(fp + FW * 4 + 8); v[6] = *reinterpret_cast<const float *>(fp + 2 * FW * 4);
-        v[7] = *reinterpret_cast<const float *>(fp + 2 * FW * 4 + 4);
+        v[0] = *reinterpret_cast<const float *>(fp + (kh_l ? (2 * FW + 2) * 4 : 0));
+        v[1] = *reinterpret_cast<const float *>(fq + 4); v[2] = *reinterpret_cast<const float *>(fq + 8);
+        v[3] = *reinterpret_cast<const float *>(fq + FW * 4); v[4] = *reinterpret_cast<const float *>(fq + FW * 4 + 4);
+        v[5] = *reinterpret_cast<const float *>(fq + FW * 4 + 8); v[6] = *reinterpret_cast<const float *>(fq + 2 * FW * 4);
+        v[7] = *reinterpret_cast<const float *>(fq + 2 * FW * 4 + 4);
         const uint4 b4 = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pwa, *reinterpret_cast<const bf16x8 *>(&b4), pbias16, 0, 0, 0);
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pwa, *reinterpret_cast<const bf16x8 *>(&b4), z, 0, 0, 0);
     };
     // stage B: ReLU + rounding, lane swaps, the pixel's two 16-B chunks into the patch
     auto prod_b = [&](int i, const f32x16 &a, int buf) __attribute__((always_inline)) {
@@ -770,8 +805,8 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
     };
 
     const int n_my = (g.n_tiles - bis + bps - 1) / bps;          // >= 1 (blocks_per_slice <= n_tiles)
-    // ---- prologue: frame patch of tile 0 -> fbuf 0, patch 0 produced; frame patch of tile 1 -> fbuf 1
-    unsigned t_m1 = 0, t_0 = tile_pack(bis), t_1 = tile_pack(bis + bps), t_2 = tile_pack(bis + 2 * bps);      // tiles s - 1, s, s + 1, s + 2
+    // ---- prologue: frame patches of tiles 0 / 1 -> fbuf 0 / 1, patch 0 produced, the frame values of tile 2 in flight
+    unsigned t_0 = tile_pack(bis), t_1 = tile_pack(bis + bps), t_2 = tile_pack(bis + 2 * bps), t_3 = tile_pack(bis + 3 * bps);      // tiles s .. s + 3
     frame_load(t_0); frame_store(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // (the compiler-visible twin: see k_conv16)
@@ -780,12 +815,14 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
     for (int i = 0; i < NSLOT; ++i)
         if (wv + i * NWAVE < NMT) { const f32x16 a = prod_a(i, 0); prod_b(i, a, 0); }
     frame_load(t_1); frame_store(1);
+    frame_load(t_2);
     __syncthreads();
 
     const int fj = lane & 31, fh = lane >> 5;
     bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr unsigned OOB = 0xfffffff0u;
+    // (a store's group offset, 32 B, is added to these by the instruction: an out-of-range marker must not wrap)
+    constexpr unsigned OOB = 0xffffff00u;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y16, 0, (int)(unsigned)((int64_t)d.NI * d.OH * d.OW * d.ldy * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
         POOL ? reinterpret_cast<bf16_t *>(g.y_pool) : y16, 0, POOL ? (int)(unsigned)((int64_t)d.NI * (d.OH / 2) * (d.OW / 2) * d.Nc * 2) : 0, 0x00020000);
@@ -793,67 +830,74 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
 #pragma unroll
     for (int e = 0; e < 16; ++e) bias16[e] = bl[(e & 3) + 8 * (e >> 2) + 4 * fh];
 
-    // byte offsets of this lane's pixel of tile tp in its two output rows and in the pooled map (OOB: nothing to store)
-    unsigned st_off[ROWS + 1];
-    auto stage = [&](unsigned tp, bool valid) __attribute__((always_inline)) {
+    // byte offsets of this lane's 16 B of channel group 0 of its pixel of tile tp: two output rows, the pooled map (OOB: nothing to store)
+    auto stage = [&](unsigned tp, unsigned (&so)[ROWS + 1]) __attribute__((always_inline)) {
         const int img = (int)(tp & 0xffffu), ty = (int)((tp >> 16) & 0xffu), tx = (int)(tp >> 24);
+        const unsigned rb = rowbits[ty], cb = colbits[tx];                                 // (uniform addresses: broadcast reads)
         const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
-        const bool col_ok = valid && ox < d.OW && (!masked || taps[d.OH + min(ox, d.OW - 1)]);
+        const bool col_ok = (cb >> fj) & 1u;
+        const unsigned pix0 = (unsigned)((img * d.OH + oy0) * d.OW + ox);                  // (launcher: NI * OH * OW * ldy * 2 < 2^32)
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int oy = oy0 + r;
-            st_off[r] = !(col_ok && oy < d.OH && (!masked || taps[min(oy, d.OH - 1)])) ? OOB : (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2);
-        }
-        st_off[ROWS] = OOB;
+        for (int r = 0; r < ROWS; ++r)
+            so[r] = (col_ok && ((rb >> (wv * ROWS + r)) & 1u)) ? (pix0 + (unsigned)(r * d.OW)) * (unsigned)(d.ldy * 2) + (unsigned)(fh * 16) : OOB;
+        so[ROWS] = OOB;
         if constexpr (POOL) {
             const int PHo = d.OH / 2, PWo = d.OW / 2;
             const int py = oy0 >> 1, pxo = ox >> 1;
-            const bool pok = valid && (fj & 1) == 0 && py < PHo && pxo < PWo;
-            st_off[ROWS] = pok ? (unsigned)((((int64_t)img * PHo + py) * PWo + pxo) * d.Nc * 2) : OOB;
+            const bool pok = (fj & 1) == 0 && py < PHo && pxo < PWo;
+            so[ROWS] = pok ? (unsigned)((img * PHo + py) * PWo + pxo) * (unsigned)(d.Nc * 2) + (unsigned)(fh * 16) : OOB;
         }
     };
-    // One sixth of the finished tile's epilogue (piece 0..5): rows' channel group gq = piece / 3 -- piece % 3 == 0: row 0 packed +
-    // stored; 1: row 1 packed + stored, the pool of the group formed; 2: the pool stored. pk0 / pmx carry a group's packed row 0 /
-    // pooled values from one piece to the next.
-    unsigned pk0[4], pmx[4];
-    auto store16 = [&](const unsigned (&p)[4], const __amdgpu_buffer_rsrc_t &rs, unsigned px_off, int gq) __attribute__((always_inline)) {
-        unsigned o[4];
+    // One sixth of the finished tile's epilogue (piece 0..5), channel group gq = piece / 3 -- piece % 3 == 0: row 0 rounded, activated,
+    // lane-swapped into its store layout and stored; 1: row 1 likewise, and the group's 2x2 pool formed FROM THE SWAPPED registers
+    // (the swap is the same lane permutation for both rows and keeps a pixel in its 32-lane half: max and swap commute, so the
+    // pooled values are already in store layout); 2: the pool stored. sw0 / pmx carry row 0 / the pool from one piece to the next.
+    unsigned sw0[4], pmx[4];
+    auto epi_piece = [&](int piece, const f32x16 (&a)[ROWS], const unsigned (&so)[ROWS + 1]) __attribute__((always_inline)) {
+        const int gq = piece / 3, ph = piece % 3;
+        if (ph == 2) {
+            if constexpr (POOL) {
+                const u32x4 v = {pmx[0], pmx[1], pmx[2], pmx[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(v, pr, (int)so[ROWS], gq * 32, 0);
+            }
+            return;
+        }
+        unsigned p[4], o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = relu2(pack_bf2(a[ph][8 * gq + 2 * k], a[ph][8 * gq + 2 * k + 1]));
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
             const auto sw = __builtin_amdgcn_permlane32_swap(p[w], p[2 + w], false, false);
             o[w] = sw[0]; o[2 + w] = sw[1];
         }
-        const unsigned vo = px_off != OOB ? px_off + (unsigned)(gq * 16 + fh * 8) * 2u : OOB;
         const u32x4 v = {o[0], o[1], o[2], o[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)vo, 0, 0);
-    };
-    auto epi_piece = [&](int piece, const f32x16 (&a)[ROWS]) __attribute__((always_inline)) {
-        const int gq = piece / 3, ph = piece % 3;
-        if (ph == 2) {
-            if constexpr (POOL) store16(pmx, pr, st_off[ROWS], gq);
-            return;
-        }
-        unsigned p[4];
+        __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)so[ph], gq * 32, 0);
+        if constexpr (POOL) {
+            if (ph == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[k] = relu2(pack_bf2(a[ph][8 * gq + 2 * k], a[ph][8 * gq + 2 * k + 1]));
-        store16(p, yr, st_off[ph], gq);
-        if (ph == 0) {
+                for (int k = 0; k < 4; ++k) sw0[k] = o[k];
+            } else {
+                // 2x2 max pool on the rounded, activated values as unsigned 16-bit integers (k_conv16: NaN-propagating like torch)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pk0[k] = p[k];
-        } else if constexpr (POOL) {
-            // 2x2 max pool on the rounded, activated values as unsigned 16-bit integers (k_conv16: NaN-propagating like torch)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned v = pmax(pk0[k], p[k]);
-                pmx[k] = pmax(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));      // lane ^ 1
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned m = pmax(sw0[k], o[k]);
+                    pmx[k] = pmax(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true));      // lane ^ 1
+                }
             }
         }
     };
 
-    // ---- one tile step: aC accumulates tile s, aP holds tile s - 1 (tpP; ok_p: there is one)
-    auto step = [&](f32x16 (&aC)[ROWS], f32x16 (&aP)[ROWS], int s, unsigned tpP, bool ok_p, unsigned tpF) __attribute__((always_inline)) {
-        frame_load(tpF);                                          // frame patch of tile s + 2 (behind the batch: zeros)
-        stage(tpP, ok_p);
+#ifdef EVFLY_C16_TS
+    unsigned long long ts_acc[8] = {}, ts_last = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_last) :: "memory");
+#endif
+    // ---- one tile step: aC accumulates tile s (tpC; its store offsets -> soC), aP / soP belong to tile s - 1. NOTHING of a step
+    // lies outside the fragment loop: the frame values loaded in step s - 1 (tile s + 2) are formed and written to fbuf[s & 1] in
+    // iteration 0 (that buffer held tile s, which the producers of step s - 1 consumed), the loads of tile s + 3 go out in
+    // iteration 2, the store offsets of tile s are worked out in iteration 4.
+    auto step = [&](f32x16 (&aC)[ROWS], f32x16 (&aP)[ROWS], unsigned (&soC)[ROWS + 1], const unsigned (&soP)[ROWS + 1], int s, unsigned tpC,
+                    unsigned tpF) __attribute__((always_inline)) {
+        C16_TS(3);                                                // 3: barrier wait (from the previous step's C16_TS(1))
         const unsigned char *pb = smem + (s & 1) * PATCH_BYTES;
         const int nb = (s + 1) & 1;                               // patch / frame buffer of tile s + 1
         bf16x8 pxq[2][ROWS + 2], wfq[2][3];
@@ -883,35 +927,56 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
                     aC[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[it & 1][ky], pxq[it & 1][r + ky], (it == 0 && ky == 0) ? bias16 : aC[r], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            epi_piece(it, aP);
+            epi_piece(it, aP, soP);
+            if (it == 0) frame_store(s & 1);
             if (it == 1) prod_b(0, pa, nb);
+            if (it == 2) frame_load(tpF);
             if (it == 3) prod_b(1, pa, nb);
+            if (it == 4) stage(tpC, soC);
             if (it == 5 && wv + 2 * NWAVE < NMT) prod_b(2, pa, nb);
+            // this iteration's other work BETWEEN its MFMAs (an MFMA occupies the pipe for 32 cycles, a wave issues one instruction
+            // per ~4: six MFMAs back to back park the wave for ~190 cycles in which ~40 of its other instructions could have issued)
+            if constexpr (kPreInterleave > 0) {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, kPreInterleave, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        frame_store(s & 1);
+        C16_TS(1);                                                // 1: the step (MFMAs, previous tile's epilogue, producer, frame staging)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
+    // (static wave priorities were measured: s_setprio 1 for the second-dispatched half -- the younger wave of every SIMD, which loses
+    // the issue arbitration -- turns the imbalance round, 2.8 k against 4.2 k cycles, and the step stays as long; kPrePrio = 0)
+    if constexpr (kPrePrio == 1) { if (wv >= 4) __builtin_amdgcn_s_setprio(1); }
+    if constexpr (kPrePrio == 2) { if (wv < 4) __builtin_amdgcn_s_setprio(1); }
     f32x16 acc0[ROWS], acc1[ROWS];
-    for (int s = 0; s < n_my; s += 2) {      // two steps per trip: the accumulator sets swap roles
-        const unsigned t_3 = tile_pack(bis + (s + 3) * bps);
-        step(acc0, acc1, s, t_m1, s > 0, t_2);
-        if (s + 1 < n_my) step(acc1, acc0, s + 1, t_0, true, t_3);
-        t_m1 = t_1; t_0 = t_2; t_1 = t_3; t_2 = tile_pack(bis + (s + 4) * bps);
+    unsigned so0[ROWS + 1], so1[ROWS + 1];
+#pragma unroll
+    for (int r = 0; r <= ROWS; ++r) so1[r] = OOB;                // (step 0 stores "tile -1": nothing)
+    for (int s = 0; s < n_my; s += 2) {      // two steps per trip: the accumulator / offset sets swap roles
+        const unsigned t_4 = tile_pack(bis + (s + 4) * bps);
+        step(acc0, acc1, so0, so1, s, t_0, t_3);
+        if (s + 1 < n_my) step(acc1, acc0, so1, so0, s + 1, t_1, t_4);
+        t_0 = t_2; t_1 = t_3; t_2 = t_4; t_3 = tile_pack(bis + (s + 5) * bps);
     }
-    // ---- the last tile's epilogue (tile n_my - 1: acc0 if n_my is odd)
-    {
-        const unsigned tl = tile_pack(bis + (n_my - 1) * bps);
-        stage(tl, true);
-        if (n_my & 1) {
+#ifdef EVFLY_C16_TS
+    if (lane == 0 && blockIdx.x < 256) {
+        ts_acc[7] = (unsigned long long)n_my;
 #pragma unroll
-            for (int pc = 0; pc < 6; ++pc) epi_piece(pc, acc0);
-        } else {
+        for (int i = 0; i < 8; ++i) g_c16_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_acc[i];
+    }
+#endif
+    // ---- the last tile's epilogue (tile n_my - 1: set 0 if n_my is odd)
+    if (n_my & 1) {
 #pragma unroll
-            for (int pc = 0; pc < 6; ++pc) epi_piece(pc, acc1);
-        }
+        for (int pc = 0; pc < 6; ++pc) epi_piece(pc, acc0, so0);
+    } else {
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) epi_piece(pc, acc1, so1);
     }
 }
 
@@ -938,10 +1003,11 @@ int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStrea
 template <bool POOL>
 int launch16pre(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = 16, NPIX = (TH + 2) * PWD, NMT = (NPIX + 31) / 32, FPIX = (TH + 4) * (PWD + 2);
-    const int lds = 2 * NMT * 32 * 64 + 18 * 1024 + 128 + 2 * FPIX * 4 + (d.tap_h > 0 ? (d.OH + d.OW + 15) / 16 * 16 : 0);
+    const int lds = 2 * NMT * 32 * 64 + 18 * 1024 + 128 + 2 * FPIX * 4 + (2 * (PWD + 2) + 4) * 4 + (g.tiles_y + g.tiles_x) * 4;
     EVFLY_REQUIRE(d.tap_h == 0 || (POOL && d.tap_w > 0 && d.tap_h <= d.OH && d.tap_w <= d.OW), "conv16: masked stores go with the fused pool");
     EVFLY_REQUIRE(d.NI < 65536 && g.tiles_y < 256 && g.tiles_x < 256 && g.n_slices == 1, "conv16pre: tile coordinates do not fit one register");
     EVFLY_REQUIRE((int64_t)d.NI * (d.H + 2) * (d.W + 2) * 4 < ((int64_t)1 << 31), "conv16pre: frames beyond 2 GB");
+    EVFLY_REQUIRE((int64_t)d.NI * d.OH * d.OW < ((int64_t)1 << 31), "conv16pre: pixel index beyond 31 bits");
     auto kern = k_conv16pre<POOL>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;

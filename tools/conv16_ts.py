@@ -28,7 +28,13 @@ t = buf.reshape(256, 8, 8).astype(np.float64)
 steps = t[:, :, 7]
 per = t[:, :, :7] / np.maximum(steps[:, :, None], 1)
 names = ["even producer", "frame loads + stores issued", "fragment loop", "odd producer", "frame store", "pack / pool", "step barrier"]
-for half, tag in ((slice(0, 8, 2), "even waves"), (slice(1, 8, 2), "odd waves")):
+halves = ((slice(0, 8, 2), "even waves"), (slice(1, 8, 2), "odd waves"))
+if not os.environ.get("EVFLY_CONV16_PRE_OLD"):
+    # k_conv16pre (round 5): 0 frame loads + store offsets, 1 fragment loop (MFMAs + previous tile's epilogue + producer), 2 frame
+    # store, 3 barrier wait; waves 0-3 run three producer slots, waves 4-7 two
+    names = ["frame loads + store offsets", "fragment loop (all of it)", "frame store", "barrier wait", "-", "-", "-"]
+    halves = ((slice(0, 4), "waves 0-3"), (slice(4, 8), "waves 4-7"))
+for half, tag in halves:
     p = per[:, half].reshape(-1, 7)
     print(f"{tag}: {p.sum(1).mean():.0f} ticks per step ({steps.mean():.0f} steps per wave)")
     for i, nm in enumerate(names):
