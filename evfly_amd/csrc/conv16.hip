@@ -63,6 +63,13 @@ __device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned lds_add
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(lds_addr) : "memory");
 }
 
+// max of a packed bf16 pair against the packed pair z as signed 16-bit integers (z = 0: ReLU of both; z = 0x80008000: identity)
+__device__ __forceinline__ unsigned relu_pk(unsigned x, unsigned z) {
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    const i16x2 r = __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), __builtin_bit_cast(i16x2, z));
+    return __builtin_bit_cast(unsigned, r);
+}
+
 // swizzled byte offset of 16-B chunk c of patch pixel q (64 B per pixel)
 __device__ __forceinline__ int patch_off(int q, int c) { return q * 64 + ((c ^ ((q >> 2) & 3)) << 4); }
 
@@ -109,18 +116,31 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     }
 
     if (tid < NTB * 32) bl[tid] = (d.bias && n0 + tid < d.Nc) ? d.bias[n0 + tid] : 0.f;        // (published by the prologue barrier)
-    const bool masked = d.tap_h > 0;
-    if (masked) {      // (two passes around a barrier of their own: zero, then every skip row / column marks its two taps)
-        for (int i = tid; i < d.OH + d.OW; i += 512) taps[i] = 0;
+    // Which output pixels are stored: bit (row within the tile) of rowbits[ty], bit (column within the tile) of colbits[tx] -- inside the
+    // map and, with tap_h > 0, a tap row / column of the resize that is the map's only other reader (bilinear_src_index, the resize
+    // kernel's own arithmetic). Two uniform 4-byte LDS reads per tile (round 4: per-pixel byte lookups behind exec-mask branches,
+    // three dependent LDS round trips in stage_tile).
+    unsigned *rowbits = reinterpret_cast<unsigned *>(taps), *colbits = rowbits + g.tiles_y;
+    {
+        const bool masked = d.tap_h > 0;
+        for (int i = tid; i < g.tiles_y + g.tiles_x; i += 512) rowbits[i] = 0;
         __syncthreads();
-        const float sh = (float)d.OH / (float)d.tap_h, sw = (float)d.OW / (float)d.tap_w;      // launch16_bilinear's scales
-        for (int i = tid; i < d.tap_h + d.tap_w; i += 512) {
-            const bool row = i < d.tap_h;
-            int i0, i1;
-            float l0, l1;
-            bilinear_src_index(row ? i : i - d.tap_h, row ? d.OH : d.OW, row ? d.tap_h : d.tap_w, row ? sh : sw, 0, i0, i1, l0, l1);
-            unsigned char *t = taps + (row ? 0 : d.OH);
-            t[i0] = 1; t[i1] = 1;
+        if (!masked) {
+            for (int i = tid; i < d.OH + d.OW; i += 512) {
+                const bool row = i < d.OH;
+                const int p = row ? i : i - d.OH;
+                atomicOr(row ? &rowbits[p / TH] : &colbits[p / TW], 1u << (row ? p % TH : p % TW));
+            }
+        } else {
+            const float sh = (float)d.OH / (float)d.tap_h, sw = (float)d.OW / (float)d.tap_w;      // launch16_bilinear's scales
+            for (int i = tid; i < d.tap_h + d.tap_w; i += 512) {
+                const bool row = i < d.tap_h;
+                int i0, i1;
+                float l0, l1;
+                bilinear_src_index(row ? i : i - d.tap_h, row ? d.OH : d.OW, row ? d.tap_h : d.tap_w, row ? sh : sw, 0, i0, i1, l0, l1);
+                if (row) { atomicOr(&rowbits[i0 / TH], 1u << (i0 % TH)); atomicOr(&rowbits[i1 / TH], 1u << (i1 % TH)); }
+                else { atomicOr(&colbits[i0 / TW], 1u << (i0 % TW)); atomicOr(&colbits[i1 / TW], 1u << (i1 % TW)); }
+            }
         }
     }
 
@@ -376,11 +396,12 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         int img, ty, tx;
         tile_decode(st_tile, img, ty, tx);
         const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
-        const bool col_ok = ox < d.OW && (!masked || taps[d.OH + ox]);
+        const unsigned rb = rowbits[ty], cb = colbits[tx];          // (uniform addresses: broadcast reads)
+        const bool col_ok = (cb >> fj) & 1u;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int oy = oy0 + r;
-            st_off[r] = !(col_ok && oy < d.OH && (!masked || taps[oy])) ? OOB
+            st_off[r] = !(col_ok && ((rb >> (wv * ROWS + r)) & 1u)) ? OOB
                         : DOT ? (fh == 0 ? (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * 4) : OOB)        // (one lane of the pair stores the pixel's value)
                               : (unsigned)((((int64_t)img * d.OH + oy) * d.OW + ox) * d.ldy * 2);
         }
@@ -523,18 +544,19 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
         }
         if (cc == nchunks - 1) {
             // ---- the tile's results, packed straight from the accumulators (staged and stored during the next step)
-            const bool relu = d.act == ACT_RELU;        // (conv16_applicable admits ACT_RELU / ACT_NONE only)
+            const unsigned rz = d.act == ACT_RELU ? 0u : 0x80008000u;        // (conv16_applicable admits ACT_RELU / ACT_NONE only)
 #pragma unroll
             for (int j = 0; j < NTB; ++j)
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
-                        float v0 = acc[r][j][e], v1 = acc[r][j][e + 1];
-                        // ReLU as !(v <= 0) ? v : +0: NaN passes like torch.relu, and -0 becomes +0 so that every activated value is
-                        // +0, positive, +inf or NaN -- the domain the pooling below relies on
-                        if constexpr (!(kAbl16 & 32)) { v0 = (relu && v0 <= 0.f) ? 0.f : v0; v1 = (relu && v1 <= 0.f) ? 0.f : v1; }
-                        pk[r][j][e >> 1] = pack_bf2(v0, v1);
+                        // ReLU on the ROUNDED pair, one v_pk_max_i16 against 0 (no ReLU: against the most negative 16-bit integer): in the
+                        // signed-integer order of bf16 bit patterns every negative value and -0 lie below +0 -- every activated value is
+                        // +0, positive, +inf or NaN, the domain the pooling below relies on; rounding is monotonic and keeps the sign, so
+                        // this is the rounding of the fp32 ReLU. (A NaN with its sign bit set becomes 0 where torch.relu keeps it: the
+                        // frames and weights of this pipeline are finite, DESIGN.md. Round 4: a compare + select per fp32 value.)
+                        pk[r][j][e >> 1] = relu_pk(pack_bf2(acc[r][j][e], acc[r][j][e + 1]), rz);
                     }
             if constexpr (DOT) {
                 const float db = d.dot_b[0];
@@ -983,7 +1005,7 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
 template <int ROWS, int NTB, bool POOL, bool PRE, bool DOT = false>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
-    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + NTB * 128 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0) + (d.tap_h > 0 ? (d.OH + d.OW + 15) / 16 * 16 : 0);
+    const int lds = 2 * NPIECE * 1024 + (d.C >> 5) * 18 * NTB * 1024 + NTB * 128 + (PRE ? 2 * (TH + 4) * (PWD + 2) * 4 : 0) + (g.tiles_y + g.tiles_x) * 4;
     EVFLY_REQUIRE(d.tap_h == 0 || (POOL && !DOT && d.tap_w > 0 && d.tap_h <= d.OH && d.tap_w <= d.OW), "conv16: masked stores go with the fused pool");
     auto kern = k_conv16<ROWS, NTB, POOL, PRE, DOT>;
     static std::atomic<bool> attr_set[64];
