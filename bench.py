@@ -676,6 +676,24 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                                     "note": "bf16 pipeline (BASELINE configs C3 / C5 run in it); informational, not the headline"}
             for mm in (model, model.origunet, model.vitfly_vitlstm):
                 mm.set_compute_dtype("f32")
+        if composite and dtype == "bf16" and not a.pmc_pass:
+            # the bf16 pipeline against the exact-fp32 one on the SAME inputs, 8 sampled streams (the first, evenly spaced, the last): the
+            # velocity deviation a user of this config pays for the precision mode (C2's `alt_precision` is the same figure for C2)
+            pick = sorted(set(int(round(i * (B - 1) / 7)) for i in range(8)))
+            with torch.no_grad():
+                voxelizer.voxelize_windows(ev, Hs, Ws, out="f32", frames=frames, roi=roi)
+                xs = voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W)).view(B, T, 1, H, W)[pick].reshape(len(pick) * T, 1, H, W).contiguous()
+                dv = desvel[:len(pick) * T]
+                v16, _ = model.forward_streams([xs, dv, [None, None], None], len(pick), T)
+                for mm in (model, model.origunet, model.vitfly_vitlstm):
+                    mm.set_compute_dtype("f32")
+                v32, _ = model.forward_streams([xs, dv, [None, None], None], len(pick), T)
+                for mm in (model, model.origunet, model.vitfly_vitlstm):
+                    mm.set_compute_dtype(dtype)
+            out["precision_check"] = {"streams": pick, "max_rel_dev_velocity_vs_f32": float(((v16 - v32).abs().max() / v32.abs().max()).item()),
+                                      "rms_rel_dev_velocity_vs_f32": float(((v16 - v32).pow(2).mean().sqrt() / v32.pow(2).mean().sqrt()).item()),
+                                      "note": f"bf16 pipeline vs the exact-fp32 pipeline, same inputs and weights, {len(pick)} of the {B} streams x {T} windows"}
+            del xs, v16, v32
         if detail and not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, a.cpu_seconds)
         elif not detail and not a.no_cpu_baseline and a.side_cpu_seconds > 0:

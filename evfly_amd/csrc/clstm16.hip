@@ -229,7 +229,8 @@ void clstm16_fragment_host(const unsigned short *wi, int hid, unsigned short *ds
 }
 
 int launch_clstm16_seq(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, hipStream_t st) {
-    EVFLY_REQUIRE(S > 0 && T > 0 && rpi > 0 && (int64_t)S * T * rpi * CL_NG < ((int64_t)1 << 40), "clstm16_seq: bad geometry");
+    // (the kernel addresses zx and hseq through buffer descriptors with 32-bit byte offsets)
+    EVFLY_REQUIRE(S > 0 && T > 0 && rpi > 0 && (int64_t)S * T * rpi * CL_NG * 4 < ((int64_t)1 << 32), "clstm16_seq: %d x %d x %d pre-activation rows exceed the kernel's 4 GB of 32-bit offsets", S, T, rpi);
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));

@@ -157,7 +157,8 @@ void wino_skip_grid(const ConvDesc &d, SkipGrid *g);
 // kernel launches wino_launch(d) issues: 1, or 2 with a split plan
 int wino_launch_count(const ConvDesc &d);
 
-// Winograd F(4x4,3x3) prototype (wino4.hip; EVFLY_WINO4=1 routes evfly_op_conv2d_nhwc to it): plain layers only (no fused pool /
+// Winograd F(4x4,3x3) prototype (tools/proto/wino4.hip, NOT in the product library: tools/scripts/build_w4.sh builds libevfly_w4.so with
+// -DEVFLY_WITH_WINO4, where EVFLY_WINO4=1 routes evfly_op_conv2d_nhwc to it): plain layers only (no fused pool /
 // skip / 1x1 consumer / first conv), C % 8 == 0, Nc % 32 == 0; U = G g G^T in its own layout (wino4_u_floats floats)
 size_t wino4_u_floats(int cout, int cin);
 void wino4_pack_host(const float *w_oihw, int cout, int cin, float *U);

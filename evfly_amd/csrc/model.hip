@@ -83,6 +83,10 @@ struct evfly_model {
     bool full_encoder_outputs = false;
     bool bands_used = false;   // the last forward left "e1".."e4" partial
     bool dot_used = false;     // the last forward fused unet_out into d42: "d4" was not written
+    // ConvLSTM state rows (streams x 104) of the forward's FIRST chunk: the bf16 pipeline picks its recurrence kernel (one launch per chunk
+    // or per-step launches) from it ONCE per forward, so that a stream's depth and state do not depend on which chunk of the batch it
+    // falls in (a smaller tail chunk used to take the other path: a few bf16 ulps apart)
+    int64_t clstm_rows_first = 0;
     struct { const float *w = nullptr, *b = nullptr; float *y = nullptr; bool done = false; } dot;     // request for the next conv()
 
     ~evfly_model() {
@@ -758,7 +762,9 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         float *zx = m->alloc((int64_t)F * rpi * 4 * hid);          // fp32 pre-activations in every pipeline
         // bf16 pipeline: the T steps of a chunk in ONE launch (clstm16.hip: a 1x1 ConvLSTM is an independent LSTM per position) on
         // gate-interleaved pre-activations; otherwise a GEMM + a gate launch per step
-        const bool seq = a16 && m->has("clstm.wh_i") && clstm16_seq_available((int64_t)S * rpi);
+        // (chosen from the forward's first chunk, see clstm_rows_first; the kernel's 32-bit byte offsets bound the chunk: zx < 4 GB)
+        const bool seq = a16 && m->has("clstm.wh_i") && clstm16_seq_available(m->clstm_rows_first > 0 ? m->clstm_rows_first : (int64_t)S * rpi) &&
+                         (int64_t)F * rpi * 4 * hid * 4 < ((int64_t)1 << 32);
         // small chunks: per-step launches, the cell update in the hidden-side GEMM's epilogue (igemm16 OUT_LSTM) on the same interleaved
         // layout -- the step's fp32 pre-activations no longer go through HBM twice and the gate launch is gone
         static const bool no_gate_fusion = getenv("EVFLY_NO_CLSTM16_GATE_FUSION") != nullptr;
@@ -1195,6 +1201,7 @@ extern "C" int evfly_unet_forward(evfly_model *m, const float *frames, int n_str
     EVFLY_REQUIRE((velpred_h == nullptr) == (velpred_c == nullptr), "unet_forward: velpred_h and velpred_c go together");
     const int per = std::max(1, kChunkFrames / T);
     const int64_t fr = (int64_t)m->cfg.input_h * m->cfg.input_w;
+    m->clstm_rows_first = (int64_t)std::min(per, n_streams) * 104;
     for (int s0 = 0; s0 < n_streams; s0 += per) {
         const int S = std::min(per, n_streams - s0);
         auto body = [&]() {
@@ -1272,6 +1279,7 @@ extern "C" int evfly_e2v_forward(evfly_model *m, const float *frames, const floa
     const int per = std::max(1, kChunkFrames / T);
     const int H = m->cfg.input_h, Wd = m->cfg.input_w;
     const int64_t fr = (int64_t)H * Wd;
+    m->clstm_rows_first = (int64_t)std::min(per, n_streams) * 104;
     if (depth_out && n_streams > per) {
         // More than one chunk and the caller takes the depth maps: the depth model runs over all its 320-frame chunks first (depth
         // lands in the caller's buffer), then the velocity model reads it back in chunks four times as large, like evfly_vit_forward
@@ -1478,13 +1486,15 @@ extern "C" int evfly_op_conv2d_nhwc(const float *x, int n, int h, int w, int cin
         d.w = static_cast<const float *>(scr);
     }
     d.ldw = ld; d.Nc = cout; d.res = res; d.ldres = cout; d.act = act; d.y = y; d.ldy = cout; d.dtype = dtype;
+#ifdef EVFLY_WITH_WINO4      // developer library only (tools/scripts/build_w4.sh): the F(4x4,3x3) prototype of tools/proto/wino4.hip, 0.51x the shipped kernel
     static const bool use_w4 = getenv("EVFLY_WINO4") && atoi(getenv("EVFLY_WINO4")) == 1;
-    if (use_w4 && wino4_applicable(d)) {      // F(4x4,3x3) prototype (tools / tests)
+    if (use_w4 && wino4_applicable(d)) {
         void *u = nullptr;
         if (int rc = scratch_get(wino4_u_floats(cout, cin) * 4, &u, as_stream(stream), 2)) return rc;
         if (int rc = wino4_pack_device(w_packed, cout, cin, (int64_t)9 * cin, 1, cin, static_cast<float *>(u), as_stream(stream))) return rc;
         return wino4_launch(d, static_cast<const float *>(u), as_stream(stream));
     }
+#endif
     if (wino_applicable(d) && !(getenv("EVFLY_WINO_OP") && atoi(getenv("EVFLY_WINO_OP")) == 0)) {
         void *u = nullptr;
         if (int rc = scratch_get(wino_u_floats(cout, cin) * 4, &u, as_stream(stream), 2)) return rc;

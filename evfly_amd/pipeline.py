@@ -20,9 +20,12 @@ class StreamPipeline:
         """model: an `OrigUNet_w_VITFLY_ViTLSTM` on the GPU (its two sub-modules build their own native handles)."""
         _lib.lib()
         self.unet, self.vit = model.origunet, model.vitfly_vitlstm
-        self.unet.compute_dtype = self.vit.compute_dtype = model.compute_dtype
+        name = {0: "f32", 1: "bf16", 2: "bf16x3"}[model.compute_dtype]
+        self.unet.set_compute_dtype(name)           # (the setter also thaws a frozen handle: a plain attribute write does not)
+        self.vit.set_compute_dtype(name)
         self.side = torch.cuda.Stream()
         self._done = None
+        self._side_tensors = []
 
     def step(self, frames, desvel, n_streams, T, unet_state=None, vit_state=None, after=None):
         """One batch, laid out [stream][t] like `forward_streams`. D runs on the current stream; P is queued on the side stream
@@ -41,10 +44,26 @@ class StreamPipeline:
             extra = after(vel) if after is not None else None
             self._done = torch.cuda.Event()
             self._done.record()
+        # vel, the LSTM state and after's result were allocated from the SIDE stream's pool of the caching allocator: `wait()` hands them to
+        # the waiting stream (record_stream), otherwise a consumer on that stream could still be reading a block that the allocator has
+        # already given to the next step's velocity model on the side stream
+        self._side_tensors = [t for t in _flatten((vel, st, extra)) if isinstance(t, torch.Tensor) and t.is_cuda]
         del main
         return vel, (depth, upconv, ((h_unet, None), st)), extra
 
     def wait(self):
-        """Make the current stream wait for everything queued on the side stream so far."""
+        """Make the current stream wait for everything queued on the side stream so far; the tensors the last step produced there
+        (vel, the LSTM state, `after`'s result) may then be used -- and dropped -- on the current stream."""
         if self._done is not None:
-            torch.cuda.current_stream().wait_event(self._done)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._done)
+            for t in self._side_tensors:
+                t.record_stream(cur)
+
+
+def _flatten(x):
+    if isinstance(x, (tuple, list)):
+        for y in x:
+            yield from _flatten(y)
+    else:
+        yield x

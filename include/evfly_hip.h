@@ -353,7 +353,8 @@ int evfly_op_grouped_conv_gelu(const void *x, int n, int h, int w, int ce, const
 /* Tail of one Mix-Transformer block in the bf16 pipeline, learner/ViTsubmodules.py:143-146 with MixFFN.forward :98-120 inlined:
  * y = LayerNorm(x + mlp2(GELU(depthwise(mlp1(x))))) in ONE launch, the (n, h*w, e) hidden tensor only in LDS. x, y (n, h*w, c) bf16
  * raw bits; w1 (e, c), b1 (e), dw_w (e, 8, 3, 3), dw_b (e), w2 (c, e), b2 (c), ln_g / ln_b (c) fp32 device tensors as the state
- * dict holds them (rounded to bf16 and packed per call: synchronous). Error if (h, w, c, e) has no fused kernel (c = 128 today). */
+ * dict holds them (rounded to bf16 and packed per call: synchronous). Error if (h, w, c, e) has no fused kernel (c = 128 with one frame per
+ * workgroup and c = 256 with two, the ViT-base stage widths, today). */
 int evfly_op_mixffn_block_bf16(const void *x, int n, int h, int w, int c, int e, const float *w1, const float *b1,
                                const float *dw_w, const float *dw_b, const float *w2, const float *b2, const float *ln_g,
                                const float *ln_b, void *y, void *stream);

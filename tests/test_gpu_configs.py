@@ -11,7 +11,7 @@ from oracle import conditioning as ocond
 from oracle import models as om
 from oracle import voxel as ovox
 
-from _util import ELEM_TOL, cond_frames, rel_err, rel_err_elem
+from _util import BF16_MAP, BF16_VEL, ELEM_TOL, assert_bf16_close, cond_frames, rel_err, rel_err_elem
 
 pytestmark = pytest.mark.gpu
 
@@ -64,6 +64,8 @@ def test_c3_slice_sensor_crop_base_bf16(gpu_device, base_trunk):
     v, (d, _, _) = net.forward_streams([x, desvel.to(gpu_device), [None, None], None], S, T)
     v_ref, d_ref = om.composite_streams(sd, x_ref, desvel, S, T)
     assert rel_err(d.cpu(), d_ref) < 3e-2 and rel_err(v.cpu(), v_ref) < 3e-2       # bf16 operands vs fp32 oracle
+    assert_bf16_close("vel", v, v_ref, BF16_VEL)
+    assert_bf16_close("depth", d, d_ref, BF16_MAP)
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 3e-2)])
@@ -80,6 +82,9 @@ def test_c5_convlstm_seq16(gpu_device, dtype, tol):
     _, (d_ref, up_ref, (st_ref, _)) = om.origunet_forward(sd, x, None)
     assert rel_err(up.cpu(), up_ref) < tol and rel_err(depth.cpu(), d_ref) < tol
     assert rel_err(st[0][0].cpu(), st_ref[0][0]) < tol and rel_err(st[0][1].cpu(), st_ref[0][1]) < tol
+    if dtype == "bf16":
+        for tag, a, b in (("depth", depth, d_ref), ("upconv", up, up_ref), ("h", st[0][0], st_ref[0][0]), ("c", st[0][1], st_ref[0][1])):
+            assert_bf16_close(tag, a, b, BF16_MAP)
 
 
 def test_c4_shard_256_streams_vit_base(gpu_device, base_trunk):
@@ -108,6 +113,44 @@ def test_c4_shard_256_streams_vit_base(gpu_device, base_trunk):
         assert rel_err(v[rows].cpu(), v_ref) < 1e-4 and rel_err(d[rows].cpu(), d_ref) < 1e-4, s
         assert rel_err_elem(v[rows].cpu(), v_ref) < ELEM_TOL and rel_err_elem(d[rows].cpu(), d_ref) < ELEM_TOL, s
     v2, (d2, _, _) = net.forward_streams([x, desvel.to(gpu_device), [None, None], None], S, T)
+    assert torch.equal(v, v2) and torch.equal(d, d2)
+
+
+def test_c3_model_2560_frames_bf16_base(gpu_device, base_trunk):
+    """BASELINE config C3's model at its launch plan: 256 streams x 10 windows = 2560 conditioned frames through the TWO-STREAM pipeline in
+    bf16 with the ViT-base trunk (640-frame chunks, the one-launch ConvLSTM recurrence `k_clstm16_seq`, `k_mixffn16<256, 2>` at full grids),
+    three sampled streams (first chunk, a middle one, the last stream) against the fp32 oracle at the bf16 bars -- the twin of
+    test_c4_shard_256_streams_vit_base. (Frames from syn.make_frames: the 512 M events of the bench are the voxelizer's test, not this one's.)"""
+    import evfly_amd.learner_models as lm
+    from evfly_amd import voxelizer
+    from evfly_amd.pipeline import StreamPipeline
+    S, T = 256, 10
+    net = lm.OrigUNet_w_VITFLY_ViTLSTM(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0],
+                                       input_shape=[1, 1, 260, 346], velpred=0, form_BEV=2, evs_min_cutoff=0.15,
+                                       skip_type="interp", logger=lambda *a: None, vit_trunk=base_trunk)
+    sd = syn.fill_state_dict(net.state_dict())
+    net.load_state_dict(sd)
+    net.set_compute_dtype("bf16")
+    net = net.to(gpu_device).eval()
+    raw = torch.from_numpy(syn.make_frames(777, S * T)).reshape(S * T, 260, 346)
+    x = voxelizer.condition_frames(raw.to(gpu_device))
+    del raw
+    desvel = torch.full((S * T, 1), 4.0)
+    pipe = StreamPipeline(net)
+    with torch.no_grad():
+        v, (d, up, ((h_unet, _), (lh, lc))), _ = pipe.step(x, desvel.to(gpu_device), S, T)
+        pipe.wait()
+        torch.cuda.synchronize()
+    assert v.shape == (S * T, 3) and d.shape == (S * T, 1, 260, 346) and torch.isfinite(v).all() and torch.isfinite(d).all()
+    xc = x.cpu()
+    for s in (0, 131, 255):      # (the base_trunk fixture has switched the oracle to the ViT-base trunk)
+        rows = slice(s * T, (s + 1) * T)
+        v_ref, d_ref = om.composite_streams(sd, xc[rows], desvel[rows], 1, T)
+        assert_bf16_close(f"vel stream {s}", v[rows], v_ref, BF16_VEL)
+        assert_bf16_close(f"depth stream {s}", d[rows], d_ref, BF16_MAP)
+    # the composite call (one stream) gives the same bits as the pipeline at this size too
+    with torch.no_grad():
+        v2, (d2, _, _) = net.forward_streams([x, desvel.to(gpu_device), [None, None], None], S, T)
     assert torch.equal(v, v2) and torch.equal(d, d2)
 
 

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from evfly_amd import synthetic as syn
 from oracle import models as om
 
-from _util import ELEM_TOL, cond_frames, filled_sd, golden, rel_err, rel_err_elem
+from _util import BF16_MAP, BF16_VEL, ELEM_TOL, assert_bf16_close, cond_frames, filled_sd, golden, rel_err, rel_err_elem
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4          # fp32 path (north-star bar: 1e-3)
@@ -450,9 +450,15 @@ def test_composite_bf16_mfma(gpu_device):
     net, sd = _composite(gpu_device, "bf16")
     x = cond_frames(80, 2)
     desvel = torch.full((2, 1), 4.0)
-    v, (d, _, _) = net([x.to(gpu_device), desvel.to(gpu_device), [None, None], None])
-    v_ref, (d_ref, _, _) = om.composite_forward(sd, [x, desvel, [None, None], None])
+    v, (d, up, ((hu, _), _)) = net([x.to(gpu_device), desvel.to(gpu_device), [None, None], None])
+    v_ref, (d_ref, up_ref, ((hr, _), _)) = om.composite_forward(sd, [x, desvel, [None, None], None])
     assert rel_err(d.cpu(), d_ref) < TOL_BF16 and rel_err(v.cpu(), v_ref) < TOL_BF16
+    # round 5: the bf16 bars proper (tests/_util.py): max norm, rms and element-wise, velocity tighter than the maps
+    assert_bf16_close("vel", v, v_ref, BF16_VEL)
+    assert_bf16_close("depth", d, d_ref, BF16_MAP)
+    assert_bf16_close("upconv", up, up_ref, BF16_MAP)
+    assert_bf16_close("h_unet", hu[0][0], hr[0][0], BF16_MAP)
+    assert_bf16_close("c_unet", hu[0][1], hr[0][1], BF16_MAP)
 
 
 def test_composite_bf16x3_split_precision(gpu_device):

@@ -3,6 +3,6 @@
 cd $GRAFT_REPO_ROOT
 REPS=${1:-100}; shift
 LAYERS=${@:-e21 e31 e41 e51 e52 d11 d12 d21 d22 d31 d32 d41}
-python tools/conv_sweep.py $REPS $LAYERS 2>&1 | grep -v amdgpu > /tmp/w4_a.log
-EVFLY_WINO4=1 python tools/conv_sweep.py $REPS $LAYERS 2>&1 | grep -v amdgpu > /tmp/w4_b.log
+EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_w4.so python tools/conv_sweep.py $REPS $LAYERS 2>&1 | grep -v amdgpu > /tmp/w4_a.log
+EVFLY_LIB=$GRAFT_REPO_ROOT/evfly_amd/libevfly_w4.so EVFLY_WINO4=1 python tools/conv_sweep.py $REPS $LAYERS 2>&1 | grep -v amdgpu > /tmp/w4_b.log
 paste <(awk '{print $1, $2, $4, $NF}' /tmp/w4_a.log) <(awk '{print "| F4:", $2, $4, $NF}' /tmp/w4_b.log)
