@@ -137,13 +137,68 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
     const int r1 = min(a.RH, r0 + a.rows_per_band);
     const int cells = (r1 - r0) * a.RW;
     const int words = GENERAL ? 2 * cells : cells;
-    for (int i = threadIdx.x; i < words + 2; i += kVoxThreads) lds[i] = 0u;      // (+ the two words of the wrap check)
+    for (int i = threadIdx.x; i < words + 2 + 64; i += kVoxThreads) lds[i] = 0u;      // (+ the two words of the wrap check, + a scratch word per lane)
     __syncthreads();
     const bool check = !GENERAL && !small;                             // block-uniform
     unsigned accepted = 0;
 
     // 8 events per thread per step: x, y as one 16-B load each, p as one 8-B load
     const int64_t first = lo & ~int64_t(7);
+    if constexpr (!GENERAL) {
+        // Round 5: the 16-bit kernel's event loop without a branch or an exec-mask region. The counters (rocprofv3, profiles/
+        // r5_vox_band_pmc.txt) put the round-4 loop at 38 VALU lane-operations and 20 SALU instructions per event VISIT (every event
+        // is visited by each of the frame's three band blocks): 64-bit index compares, six range tests combined through SGPR
+        // pairs, an exec-mask region around every LDS atomic -- the kernel was VALU-issue-bound at 0.29 of the HBM peak. Here every
+        // range test is a sign bit: v in [0, n) <=> neither v nor (n - 1 - v) is negative, so ONE v_or3 chain over
+        //   row, rows - 1 - row, column, RW - 1 - column, index - lo, hi - 1 - index, W - x, H - y, polarity term
+        // and one compare decide the event; a rejected event adds 0 to a per-lane scratch word behind the band (an unconditional
+        // ds_add, conflict-free), accepted events are counted from the compare's lane mask on the scalar unit.
+        const unsigned nrel = (unsigned)(hi - lo);                        // (< 2^31: `small` or `optimistic`)
+        const int Wm1 = a.W - 1, Hm1 = a.H - 1, yoff = a.rtop + r0, nrm1 = (r1 - r0) - 1, RWm1 = a.RW - 1;
+        const unsigned dummy = (unsigned)(words + 2) + (threadIdx.x & 63u);
+        const bool pm1 = a.pol_mode == EVFLY_POL_PM1;
+        unsigned acc_s = 0;                                                // accepted events of this WAVE (scalar)
+        for (int64_t i0 = first + (int64_t)threadIdx.x * 8; i0 < hi; i0 += (int64_t)kVoxThreads * 8) {
+            uint4 xv, yv;
+            uint2 pv;
+            if (i0 + 8 <= a.n_total) {
+                xv = *reinterpret_cast<const uint4 *>(a.x + i0);
+                yv = *reinterpret_cast<const uint4 *>(a.y + i0);
+                pv = *reinterpret_cast<const uint2 *>(a.p + i0);
+            } else {  // last partial vector of the arrays: never read past n_total
+                unsigned xt[4] = {0, 0, 0, 0}, yt[4] = {0, 0, 0, 0}, pt[2] = {0, 0};
+                for (int k = 0; k < 8 && i0 + k < a.n_total; ++k) {
+                    xt[k >> 1] |= (unsigned)a.x[i0 + k] << ((k & 1) * 16);
+                    yt[k >> 1] |= (unsigned)a.y[i0 + k] << ((k & 1) * 16);
+                    pt[k >> 2] |= (unsigned)(uint8_t)a.p[i0 + k] << ((k & 3) * 8);
+                }
+                xv = make_uint4(xt[0], xt[1], xt[2], xt[3]);
+                yv = make_uint4(yt[0], yt[1], yt[2], yt[3]);
+                pv = make_uint2(pt[0], pt[1]);
+            }
+            const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+            const int rel0 = (int)(i0 - lo);                               // (>= -7; events of the partial vector past n_total: index >= hi)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ex = (int)((k & 1) ? xs[k >> 1] >> 16 : xs[k >> 1] & 0xffffu);
+                const int ey = (int)((k & 1) ? ys[k >> 1] >> 16 : ys[k >> 1] & 0xffffu);
+                const int ep = __builtin_amdgcn_sbfe((int)(k < 4 ? pv.x : pv.y), (k & 3) * 8, 8);
+                // np.histogram2d: the right-most edge is inclusive (x == W counts in column W - 1); bins first, then the crop (run.py:345-350)
+                const int cx = min(ex, Wm1) - a.rleft, cy = min(ey, Hm1) - yoff;
+                const int rel = rel0 + k;
+                // polarity: +-1 convention: p > 0 positive, p < 0 negative, 0 dropped (p * p - 1 < 0 <=> p == 0); 0 / 1 convention: p > 0
+                // positive, p == 0 negative, p < 0 dropped
+                const int pterm = pm1 ? ep * ep - 1 : ep;
+                const int bad = (cy | (nrm1 - cy) | cx) | ((RWm1 - cx) | rel | ((int)(nrel - 1u) - rel)) | ((a.W - ex) | (a.H - ey) | pterm);
+                const bool ok = bad >= 0;
+                const unsigned inc = ep > 0 ? 1u : 0x10000u;
+                const unsigned cell = (unsigned)(__mul24(cy, a.RW) + cx);                   // (24-bit multiply: full rate; rows and widths are far below 2^23)
+                atomicAdd(&lds[ok ? cell : dummy], ok ? inc : 0u);
+                acc_s += (unsigned)__builtin_popcountll(__ballot(ok));
+            }
+        }
+        accepted = (threadIdx.x & 63) == 0 ? acc_s : 0u;                  // (the wrap check sums `accepted` over the block's lanes)
+    } else
     for (int64_t i0 = first + (int64_t)threadIdx.x * 8; i0 < hi; i0 += (int64_t)kVoxThreads * 8) {
         uint4 xv, yv;
         uint2 pv;
@@ -512,10 +567,10 @@ extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t
     for (int general = 0; general < 2; ++general) {
         if (general == 1 ? skip_kernels == 2 : (skip_kernels == 1 && !a.overflow)) continue;      // this kernel owns no frame
         const int bytes_per_row = roi_width * (general ? 8 : 4);
-        const int rows_max = (kMaxLds - 16) / bytes_per_row;
+        const int rows_max = (kMaxLds - 16 - 256) / bytes_per_row;
         a.n_bands = cdiv(roi_height, rows_max);
         a.rows_per_band = cdiv(roi_height, a.n_bands);
-        const int lds_bytes = (int)align_up((size_t)a.rows_per_band * bytes_per_row + 8, 16);
+        const int lds_bytes = (int)align_up((size_t)a.rows_per_band * bytes_per_row + 8 + 256, 16);
         const dim3 grid(groups * kNumXCD * a.n_bands);
         if (general) {
             if (int rc = set_max_lds(k_vox_band<true>, kMaxLds)) return rc;
