@@ -9,7 +9,7 @@ disp = collections.defaultdict(set)
 for r in rows:
     k = r["Kernel_Name"]
     mm = re.search(r"\b(k_[a-z0-9_]+)", k)
-    fam = ("wino_conv3x3" if "k_wino9" in k else "conv16p_deep" if "k_conv16p" in k else
+    fam = ("wino_conv3x3" if "k_wino9" in k else "conv16_direct" if "k_conv16pre" in k else "conv16p_deep" if "k_conv16p" in k else
                ("conv16w_deep" if re.search(r"k_conv16w<[^>]*, *0>", k) else "conv16w_up" if re.search(r"k_conv16w<[^>]*, *1>", k) else "conv16w_gemm") if "k_conv16w" in k else
                "conv16_direct" if "k_conv16" in k else
            "igemm16_conv" if ("k_igemm16" in k and "false>" in k.replace(" ", "")) else "igemm16_gemm" if "k_igemm16" in k else
