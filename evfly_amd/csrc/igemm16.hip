@@ -14,6 +14,7 @@
 #include "igemm.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 
 #include "bf16.h"
@@ -56,8 +57,13 @@ __global__ __launch_bounds__(256) void k_igemm16(ConvDesc d, int n_mt, int n_nt,
     asm volatile("" :: "s"(d.x), "s"(d.w), "s"(d.ldx), "s"(d.ldw), "s"(d.NI), "s"(d.H), "s"(d.W), "s"(d.C), "s"(d.KH), "s"(d.KW), "s"(d.stride),
                  "s"(d.pad), "s"(d.OH), "s"(d.OW), "s"(d.M), "s"(d.Nc), "s"(d.K), "s"(d.zeros), "s"(n_mt), "s"(n_nt), "s"(cpx), "s"(splits));
     const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
-    const int mt = xcd * cpx + slot / n_nt, nt = slot % n_nt;
-    if (mt >= n_mt) return;
+    // cpx > 0: XCD x owns M tiles [x cpx, (x + 1) cpx) (the 3x3 halo rows neighbouring pixel tiles share stay in that XCD's L2);
+    // cpx < 0 (round 5): XCD x owns N tiles [x |cpx|, (x + 1) |cpx|) and every M tile -- for plain GEMMs with few M tiles, where
+    // the M map leaves whole XCDs idle (the ConvLSTM step at 20 streams: 17 M tiles as 3, 3, 3, 3, 3, 2, 0, 0)
+    int mt, nt;
+    if (cpx > 0) { mt = xcd * cpx + slot / n_nt; nt = slot % n_nt; }
+    else { nt = xcd * (-cpx) + slot / n_mt; mt = slot % n_mt; }
+    if (mt >= n_mt || nt >= n_nt) return;
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
 
@@ -401,6 +407,15 @@ int launch_cfg16(const ConvDesc &d, hipStream_t st) {
         if (int rc = scratch_get((size_t)splits * d.M * d.Nc * sizeof(float), &scr, st, 1)) return rc;
         slab = static_cast<float *>(scr);
     }
+    // block -> tile map: whichever of the two XCD maps puts fewer tiles on the busiest XCD (the N map only for plain GEMMs: a
+    // convolution's neighbouring pixel tiles share halo rows through their XCD's L2)
+    const bool plain_gemm = d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1;
+    const int cpn = cdiv(n_nt, kNumXCD);
+    static const bool no_nmap = getenv("EVFLY_IGEMM_NO_NMAP") != nullptr;      // A/B switch
+    if (plain_gemm && !no_nmap && cpn * n_mt < cpx * n_nt) {
+        const int cpx_n = -cpn;
+        hipLaunchKernelGGL(kern, dim3(kNumXCD * cpn * n_mt, splits), dim3(256), lds, st, d, n_mt, n_nt, cpx_n, splits, slab);
+    } else
     hipLaunchKernelGGL(kern, dim3(kNumXCD * cpx * n_nt, splits), dim3(256), lds, st, d, n_mt, n_nt, cpx, splits, slab);
     EVFLY_LAUNCH_CHECK();
     if (splits > 1) {
