@@ -1,4 +1,4 @@
-"""The committed bench lines (profiles/r4_C*_bench.json, produced by `python bench.py [--config ..]` on the MI355X box) carry
+"""The committed bench lines (profiles/r5_C*_bench.json, produced by `python bench.py [--config ..]` on the MI355X box) carry
 every field of the bench contract; guards against a refactor of bench.py dropping one."""
 import json
 import os
@@ -11,7 +11,7 @@ def _line(name):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    b = _line("r4_C2_bench.json")
+    b = _line("r5_C2_bench.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "step_mfma_util", "stage_rates"):
         assert k in b, k
@@ -41,7 +41,7 @@ def test_committed_bench_line_has_the_contract_fields():
 
 def test_default_line_carries_the_other_baseline_configs():
     """The driver runs `python bench.py` (C2): BASELINE.json's C5 / C3 / C4 ride on the same line as compact objects."""
-    oc = _line("r4_C2_bench.json")["other_configs"]
+    oc = _line("r5_C2_bench.json")["other_configs"]
     assert set(oc) == {"C5", "C3", "C4"}
     for name, dtype, frames in (("C5", "bf16", 320), ("C3", "bf16", 2560), ("C4", "f32", 1280)):
         o = oc[name]
@@ -54,7 +54,7 @@ def test_default_line_carries_the_other_baseline_configs():
 
 def test_committed_lines_of_the_other_baseline_configs():
     """BASELINE.json configs[2..4] have a driver-form line each (C3 bf16 ViT-base at 480x640, C4 shard, C5 ConvLSTM seq-16)."""
-    c3, c4, c5 = _line("r4_C3_bench.json"), _line("r4_C4_bench.json"), _line("r4_C5_bench.json")
+    c3, c4, c5 = _line("r5_C3_bench.json"), _line("r5_C4_bench.json"), _line("r5_C5_bench.json")
     assert c3["dtype"] == "bf16" and c3["config"]["sensor"] == [480, 640] and c3["config"]["vit_trunk"] == "base" and c3["config"]["streams_per_gpu"] == 256
     assert abs(c3["value"] - 2560 * 1e3 / c3["ms_per_step"]) < 1e-2 * c3["value"]
     assert c4["config"]["streams_per_gpu"] == 256 and c4["config"]["windows"] == 5 and c4["config"]["vit_trunk"] == "base"
@@ -69,7 +69,7 @@ def test_bench_source_keeps_the_contract_keys():
               '"data"', '"config"', '"roofline"', '"cpu_baseline"', "--gpus", "--steps", "--warmup", "dist.barrier()",
               '"frac_useful"', '"frac_algorithmic"', '"step_mfma_util"', '"stage_rates"', '"threads_1"', '"threads_nproc"', "--config",
               "pin_memory()", '"other_configs"', '"voxelize_bytes_moved"', '"voxelize_with_pass1_ms"', '"step_ms"',
-              '"ms_per_step_by_rank"', '"all_gather_us"'):
+              '"ms_per_step_by_rank"', '"all_gather_us"', '"steps_executed"', "--pmc-pass", '"precision_check"', '"c4"'):
         assert k in src, k
 
 
@@ -139,3 +139,26 @@ def test_pmc_summary_tool_refuses_partial_steps():
     assert doc["kernels"]["wino_conv3x3"]["launches_per_step"] == 28 and doc["steps_profiled"] == 3
     with pytest.raises(SystemExit):
         m.summarise(rows(196), rows(196), 3)
+
+
+def test_round5_line_traffic_and_side_objects():
+    """Round 5: `roofline.traffic` comes from a --pmc-pass summary whose bookkeeping bench.py verified (whole launches per step, the
+    conv family's count equal to the run's): within [0.95, 1.10] of the algorithmic bytes for the fp32 Winograd family (the review
+    found 2.36 x in round 4's line, an artefact of a wrong step count); the compact objects of the other BASELINE configs are
+    self-contained (CPU baseline, single-stream latency, precision check)."""
+    b = _line("r5_C2_bench.json")
+    r = b["roofline"]
+    assert r["traffic"] and 0.95 <= r["traffic"] / r["algorithmic"]["bytes_per_launch"] <= 1.10, r["traffic_note"]
+    assert "r5_C2_pmc_traffic.json" in r["traffic_note"] and b["steps_executed"] >= b["steps"] + b["warmup"]
+    t = json.load(open(os.path.join(REPO, "profiles", "r5_C2_pmc_traffic.json")))
+    assert all(float(v["launches_per_step"]).is_integer() for v in t["kernels"].values()) and t["kernels"]["wino_conv3x3"]["launches_per_step"] == 28
+    oc = b["other_configs"]
+    for name in ("C5", "C3", "C4"):
+        assert oc[name]["cpu_baseline"]["value"] > 0 and oc[name]["cpu_baseline"]["kind"] == "port"
+    assert oc["C5"]["convlstm"]["single_stream_sequence_ms"] > 0
+    pc = oc["C3"]["precision_check"]
+    assert len(pc["streams"]) == 8 and 0 < pc["max_rel_dev_velocity_vs_f32"] < 2e-2
+    # the bf16 configs' own lines carry their PMC traffic too (tap-masked stores: below the algorithmic full-map bytes)
+    for name in ("r5_C5_bench.json", "r5_C3_bench.json"):
+        rr = _line(name)["roofline"]
+        assert rr["traffic"] and 0.6 <= rr["traffic"] / rr["algorithmic"]["bytes_per_launch"] <= 1.1, rr["traffic_note"]
