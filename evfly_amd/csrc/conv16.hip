@@ -1002,6 +1002,265 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_conv16r (round 5): the 3x3 layers with C_in = 32 (K = 288) with their WEIGHTS IN REGISTERS, one wave per SIMD. Every k_conv16 variant
+// runs eight waves of <= 256 registers, two per SIMD, and spends 7 ds_read_b128 per 6 MFMAs (one 32-channel output tile) or 10 per 12
+// (two): the matrix pipe, the LDS and the waves' instruction issue are each 40-55 % busy and two waves per SIMD cannot overlap them
+// further. gfx950's register file is 512 registers per lane and SIMD: ONE wave may own all of it. Here a block is
+// four waves, each with four output rows of the 16 x 32 tile (ROWS = 4): the layer's 18 NTB weight fragments live in 72 NTB registers for
+// the block's whole life (no weights in LDS at all), a (kx, k-half) iteration reads six pixel fragments for 12 NTB MFMAs (0.5 / 0.25
+// LDS reads per MFMA instead of 1.17 / 0.83), and with 144 NTB MFMAs of 32 cycles per step a wave has ~7 issue slots per MFMA for
+// everything else: the previous tile's stores, the next patch's DMA, and -- in the step's last iteration, where the rows finish one
+// after the other -- the packing of row r under the MFMAs of row r + 1. Persistent blocks, patches double-buffered by LDS-DMA, the
+// accumulator-direct epilogue of k_conv16 (bias as the first MFMAs' C operand, packed integer ReLU, lane swaps, 16-B stores). Same
+// arithmetic and rounding points as k_conv16: bit-identical outputs.
+// MEASURED (C5, 320 frames, same box): e21 0.308 -> 0.299 ms -- 3 %, not the 2 x the instruction arithmetic promised, and neither the
+// MFMA / VALU interleave hints nor moving the patch requests and the store-offset arithmetic into the MFMA stream changed it. The reason
+// is not in the kernel: e21 reads 1.4 MB (+ halo, from L2) and writes 2.7 MB per frame, 1.44 GB per 320 frames -- 0.30 ms IS 4.8 TB/s,
+// 0.60 of the HBM peak and ~0.8 of what a mixed read / write stream reaches on this chip. The layer was memory-bound all along
+// (`roofline.per_layer_bound` counts it among the six HBM-bound layers); the kernel stays because it is the faster one and the design
+// (weights in registers, one wave per SIMD) is the one a compute-bound C_in = 32 layer would want.
+#ifndef EVFLY_C16R_IL
+#define EVFLY_C16R_IL 1
+#endif
+constexpr bool kRInterleave = EVFLY_C16R_IL != 0;
+template <int NTB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv16r(ConvDesc d, Conv16Geom g, const bf16_t *__restrict__ wd) {
+    constexpr int NW = 4, ROWS = 4, TH = NW * ROWS, PH = TH + 2, NPIX = PH * PWD;
+    constexpr int NPIECE = (NPIX * 64 + 1023) / 1024, PPW = (NPIECE + NW - 1) / NW, PATCH_BYTES = NPIECE * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
+    // LDS: [patch 0][patch 1][bias NTB * 32 f][row / column bits]
+    float *bl = reinterpret_cast<float *>(smem + 2 * PATCH_BYTES);
+    unsigned *rowbits = reinterpret_cast<unsigned *>(bl + NTB * 32), *colbits = rowbits + g.tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.x / g.blocks_per_slice, bis = blockIdx.x - slice * g.blocks_per_slice;
+    const int n0 = slice * NTB * 32;
+
+    // ---- the slice's weights -> registers (conv16_pack_host's consumption order: [tap][k-half][n-tile][lane][8])
+    bf16x8 wreg[9][2][NTB];
+    {
+        const uint4 *wp = reinterpret_cast<const uint4 *>(wd + (size_t)slice * 18 * NTB * 512) + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) {
+                    const uint4 v = wp[((t * 2 + kb) * NTB + j) * 64];
+                    wreg[t][kb][j] = *reinterpret_cast<const bf16x8 *>(&v);
+                }
+    }
+    if (tid < NTB * 32) bl[tid] = (d.bias && n0 + tid < d.Nc) ? d.bias[n0 + tid] : 0.f;
+    {   // stored pixels as per-tile row / column bit masks (k_conv16's)
+        const bool masked = d.tap_h > 0;
+        for (int i = tid; i < g.tiles_y + g.tiles_x; i += 256) rowbits[i] = 0;
+        __syncthreads();
+        if (!masked) {
+            for (int i = tid; i < d.OH + d.OW; i += 256) {
+                const bool row = i < d.OH;
+                const int p = row ? i : i - d.OH;
+                atomicOr(row ? &rowbits[p / TH] : &colbits[p / TW], 1u << (row ? p % TH : p % TW));
+            }
+        } else {
+            const float sh = (float)d.OH / (float)d.tap_h, sw = (float)d.OW / (float)d.tap_w;
+            for (int i = tid; i < d.tap_h + d.tap_w; i += 256) {
+                const bool row = i < d.tap_h;
+                int i0, i1;
+                float l0, l1;
+                bilinear_src_index(row ? i : i - d.tap_h, row ? d.OH : d.OW, row ? d.tap_h : d.tap_w, row ? sh : sw, 0, i0, i1, l0, l1);
+                if (row) { atomicOr(&rowbits[i0 / TH], 1u << (i0 % TH)); atomicOr(&rowbits[i1 / TH], 1u << (i1 % TH)); }
+                else { atomicOr(&colbits[i0 / TW], 1u << (i0 % TW)); atomicOr(&colbits[i1 / TW], 1u << (i1 % TW)); }
+            }
+        }
+    }
+    // ---- patch DMA geometry (k_conv16's, four waves)
+    unsigned poff[PPW], prc[PPW];
+    const unsigned rowb = (unsigned)d.W * (unsigned)d.ldx * 2u;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wv + i * NW;
+        const int q = pc * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((q >> 2) & 3);
+        const int pr = q / PWD, pcx = q - pr * PWD;
+        const bool in = pc < NPIECE && q < NPIX;
+        poff[i] = in ? (unsigned)pr * rowb + (unsigned)pcx * (unsigned)d.ldx * 2u + (unsigned)c * 16u : 0x7ffffff0u;
+        prc[i] = in ? ((unsigned)pr | ((unsigned)pcx << 8)) : 0xffffu;
+    }
+    auto tile_decode = [&](int t, int &img, int &ty, int &tx) {
+        const int rowq = g.tiles_x == 1 ? t : (int)__umulhi((unsigned)t, g.u_tx);
+        tx = t - rowq * g.tiles_x;
+        img = g.tiles_y == 1 ? rowq : (int)__umulhi((unsigned)rowq, g.u_ty);
+        ty = rowq - img * g.tiles_y;
+    };
+    // the next patch's DMA: `patch_setup` (tile -> descriptor, edge flags; scalar work) and one `patch_piece` per request, so that the step
+    // can place the requests one by one between its MFMAs
+    i32x4 p_srd;
+    int p_hrem = 0, p_wrem = 0;
+    bool p_interior = true;
+    unsigned p_dst = 0;
+    auto patch_setup = [&](int t, int buf) {
+        int img, ty, tx;
+        tile_decode(t, img, ty, tx);
+        const int iy0 = ty * TH, ix0 = tx * TW;
+        const uint64_t xb = (uint64_t)(uintptr_t)d.x + ((uint64_t)(unsigned)img * (unsigned)d.H + (unsigned)iy0) * rowb + (uint64_t)(unsigned)ix0 * (unsigned)d.ldx * 2u;
+        p_srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        p_srd[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffff));
+        p_srd[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)PH * rowb));
+        p_srd[3] = 0x00020000;
+        p_hrem = d.H - iy0; p_wrem = d.W - ix0;
+        p_interior = PH <= p_hrem && PWD <= p_wrem;
+        p_dst = lds0 + (unsigned)buf * PATCH_BYTES;
+    };
+    auto patch_piece = [&](int i) {          // (compile-time i)
+        const int pc = wv + i * NW;
+        // waves past the last piece issue an out-of-range request into the buffer's last KiB (zeros nobody reads... the slot IS piece
+        // NPIECE - 1's: redirect to an offset that reads zeros only if that piece is theirs) -- keep the COUNT of requests per wave fixed
+        unsigned vo = pc < NPIECE ? poff[i] : 0x7ffffff0u;
+        if (!p_interior) vo = ((int)(prc[i] & 0xffu) < p_hrem && (int)(prc[i] >> 8) < p_wrem) ? vo : 0x7ffffff0u;
+        if (pc < NPIECE) dma16(vo, p_srd, __builtin_amdgcn_readfirstlane(p_dst + (unsigned)pc * 1024u));
+    };
+    auto issue_patch = [&](int t, int buf) {
+        patch_setup(t, buf);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) patch_piece(i);
+    };
+    constexpr int NDMA = (NPIECE + NW - 1) / NW;                 // DMA instructions a wave issues per patch (waves past the last piece: fewer)
+    const int n_dma = __builtin_amdgcn_readfirstlane((NPIECE - wv + NW - 1) / NW);
+
+    const int n_my = bis < g.n_tiles ? (g.n_tiles - bis + g.blocks_per_slice - 1) / g.blocks_per_slice : 0;
+    if (n_my > 0) issue_patch(bis, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // (the compiler-visible twin: the weight loads above have landed)
+    __syncthreads();
+
+    const int fj = lane & 31, fh = lane >> 5;
+    bf16_t *y16 = reinterpret_cast<bf16_t *>(d.y);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB = 0xffffff00u;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y16, 0, (int)(unsigned)((int64_t)d.NI * d.OH * d.OW * d.ldy * 2), 0x00020000);
+    f32x16 bias16[NTB];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias16[j][e] = bl[j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
+    const unsigned rz = d.act == ACT_RELU ? 0u : 0x80008000u;
+
+    unsigned st_off[ROWS];
+    constexpr int NST = ROWS * NTB * 2;
+    auto stage = [&](int t) {            // byte offsets of this lane's 16 B of (row r, n-tile 0, group 0) of tile t (OOB: not stored)
+        int img, ty, tx;
+        tile_decode(t, img, ty, tx);
+        const unsigned rb = rowbits[ty], cb = colbits[tx];
+        const int oy0 = ty * TH + wv * ROWS, ox = tx * TW + fj;
+        const bool col_ok = (cb >> fj) & 1u;
+        const unsigned pix0 = (unsigned)((img * d.OH + oy0) * d.OW + ox);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            st_off[r] = (col_ok && ((rb >> (wv * ROWS + r)) & 1u)) ? (pix0 + (unsigned)(r * d.OW)) * (unsigned)(d.ldy * 2) + (unsigned)(n0 + fh * 8) * 2u : OOB;
+    };
+    // a finished row: ReLU + rounding on the pairs, lane swaps, its 2 NTB 16-byte stores (issued under the MFMAs of the rows behind it)
+    auto finish_row = [&](int r, const f32x16 (&a)[ROWS][NTB]) {
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+            unsigned p[8];
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) p[e >> 1] = relu_pk(pack_bf2(a[r][j][e], a[r][j][e + 1]), rz);
+            const unsigned off = (n0 + j * 32 < d.Nc) ? st_off[r] : OOB;      // (an n-tile past the layer's channels is never stored)
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                unsigned o[4];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(p[(2 * grp) * 2 + w], p[(2 * grp + 1) * 2 + w], false, false);
+                    o[w] = sw[0]; o[2 + w] = sw[1];
+                }
+                const u32x4 v = {o[0], o[1], o[2], o[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)off, (j * 32 + grp * 16) * 2, 0);
+            }
+        }
+    };
+
+    f32x16 acc[ROWS][NTB];
+    int t_cur = bis;
+    for (int s = 0; s < n_my; ++s) {
+        // (this tile's store offsets and the next tile's patch requests are issued INSIDE the MFMA stream, iterations 1 and 2: with one
+        // wave per SIMD, work in front of the first MFMA runs with the matrix pipe idle)
+        patch_setup(s + 1 < n_my ? t_cur + g.blocks_per_slice : t_cur, (s + 1) & 1);      // (behind the last tile: the same patch again, unused)
+        const unsigned char *pb = smem + (s & 1) * PATCH_BYTES;
+        bf16x8 pxq[2][ROWS + 2];
+        auto load_it = [&](int it, bf16x8 (&pxd)[ROWS + 2]) {
+            const int kx = it >> 1, kb = it & 1;
+#pragma unroll
+            for (int y = 0; y < ROWS + 2; ++y) {
+                const int q = (wv * ROWS + y) * PWD + fj + kx;
+                pxd[y] = *reinterpret_cast<const bf16x8 *>(pb + patch_off(q, kb * 2 + fh));
+            }
+        };
+        load_it(0, pxq[0]);
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int kx = it >> 1, kb = it & 1;
+            if (it + 1 < 6) load_it(it + 1, pxq[(it + 1) & 1]);
+            if (it < 5) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) {
+                            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ky * 3 + kx][kb][j], pxq[it & 1][r + ky], (it == 0 && ky == 0) ? bias16[j] : acc[r][j], 0, 0, 0);
+                            const int m = (ky * ROWS + r) * NTB + j;
+                            if (it == 1 && (m & 1) == 1 && (m >> 1) < PPW) {      // one patch request behind every second MFMA
+                                __builtin_amdgcn_sched_barrier(0);
+                                patch_piece(m >> 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                if (it == 2) stage(t_cur);
+                // ONE wave per SIMD: whatever is not an MFMA has to sit BETWEEN the MFMAs in program order (an MFMA holds the pipe for 32
+                // cycles, the wave issues ~7 other instructions meanwhile; a block of them behind 24 MFMAs would run with the pipe idle):
+                // the next iteration's fragment reads and their address arithmetic, two per four MFMAs
+                if constexpr (kRInterleave) {
+#pragma unroll
+                    for (int m = 0; m < 3 * NTB; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+            } else {
+                // last iteration: row-major, so that row r is final while the rows behind it are still being multiplied: its packing and its
+                // stores ride under their MFMAs
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j)
+                            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ky * 3 + kx][kb][j], pxq[it & 1][r + ky], acc[r][j], 0, 0, 0);
+                    if (r > 0) finish_row(r - 1, acc);
+                    if constexpr (kRInterleave) {      // the finished row's packing and stores between this row's MFMAs
+#pragma unroll
+                        for (int m = 0; m < 3 * NTB; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                finish_row(ROWS - 1, acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next patch has landed (this wave's pieces: older than the NST stores issued behind them), every wave is done with this one
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        t_cur += g.blocks_per_slice;
+    }
+    (void)NDMA; (void)n_dma;
+}
+
 template <int ROWS, int NTB, bool POOL, bool PRE, bool DOT = false>
 int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
     constexpr int TH = NWAVE * ROWS, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
@@ -1018,6 +1277,25 @@ int launch16d(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStrea
     }
     EVFLY_REQUIRE(lds <= kMaxLds, "conv16: %d B of LDS", lds);
     hipLaunchKernelGGL(kern, dim3(g.n_slices * g.blocks_per_slice), dim3(512), lds, st, d, g, wd);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NTB>
+int launch16r(const ConvDesc &d, const Conv16Geom &g, const bf16_t *wd, hipStream_t st) {
+    constexpr int TH = 16, NPIX = (TH + 2) * PWD, NPIECE = (NPIX * 64 + 1023) / 1024;
+    const int lds = 2 * NPIECE * 1024 + NTB * 128 + (g.tiles_y + g.tiles_x) * 4;
+    auto kern = k_conv16r<NTB>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    EVFLY_REQUIRE(lds <= kMaxLds, "conv16r: %d B of LDS", lds);
+    hipLaunchKernelGGL(kern, dim3(g.n_slices * g.blocks_per_slice), dim3(256), lds, st, d, g, wd);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
@@ -1142,6 +1420,11 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
         EVFLY_REQUIRE(conv16_dot_fusable(d) && !pool, "conv16: this layer cannot take the 1x1 consumer");
         return rows == 2 ? launch16d<2, 1, false, false, true>(d, g, w, st) : launch16d<1, 1, false, false, true>(d, g, w, st);
     }
+    // round 5: C_in = 32 without pool / first conv / 1x1 consumer (e21): weights in registers, one wave per SIMD (k_conv16r);
+    // EVFLY_NO_CONV16R=1 keeps k_conv16 for A/B runs
+    static const bool no_r = getenv("EVFLY_NO_CONV16R") != nullptr;
+    if (!no_r && d.C == 32 && !pool && rows == 2 && d.OH >= 16 && (int64_t)d.NI * d.OH * d.OW < ((int64_t)1 << 31))
+        return ntb == 2 ? launch16r<2>(d, g, w, st) : launch16r<1>(d, g, w, st);
     if (rows == 2) {
         if (ntb == 2) return pool ? launch16d<2, 2, true, false>(d, g, w, st) : launch16d<2, 2, false, false>(d, g, w, st);
         return pool ? launch16d<2, 1, true, false>(d, g, w, st) : launch16d<2, 1, false, false>(d, g, w, st);
