@@ -428,6 +428,12 @@ int launch_cfg16(const ConvDesc &d, hipStream_t st) {
 
 template <bool PLAIN>
 int launch_by_n16(const ConvDesc &d, hipStream_t st) {
+    // the ConvLSTM step at small chunks (C5: 2080 rows x 2048 columns, K = 512) is latency-shaped: 128 x 128 tiles are one tile per CU, each
+    // an eight-step K loop whose every step waits for its own LDS-DMA; 64 x 128 tiles put two to three co-resident blocks on a CU, whose
+    // waits cover each other (EVFLY_IGEMM16_LSTM_BM=128 restores the large tile)
+    static const int lstm_bm = getenv("EVFLY_IGEMM16_LSTM_BM") ? atoi(getenv("EVFLY_IGEMM16_LSTM_BM")) : 64;
+    if (PLAIN && d.out_mode == OUT_LSTM && d.Nc % 128 == 0 && lstm_bm != 128 && cdiv(d.M, 128) * (d.Nc / 128) <= 2 * kNumCU)
+        return lstm_bm == 32 ? launch_cfg16<32, 128, 1, 4, PLAIN>(d, st) : launch_cfg16<64, 128, 2, 2, PLAIN>(d, st);
     if (d.Nc % 128 == 0) return launch_cfg16<128, 128, 2, 2, PLAIN>(d, st);
     if (d.Nc > 32) return launch_cfg16<256, 64, 4, 1, PLAIN>(d, st);
     return launch_cfg16<256, 32, 4, 1, PLAIN>(d, st);
