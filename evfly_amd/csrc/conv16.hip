@@ -1391,10 +1391,13 @@ bool conv16_dot_fusable(const ConvDesc &d) {
 int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t st) {
     EVFLY_REQUIRE(conv16_applicable(d), "conv16: layer not eligible");
     const int ntb = conv16_ntb(d.Nc);
-    // tile height: 16 rows (two per wave; needed for the fused pool) unless 8-row tiles waste fewer rows
+    // tile height: 16 rows (two per wave; needed for the fused pool) unless 8-row tiles waste MUCH fewer rows: a 16-row step amortises the
+    // per-step barrier / DMA wait over twice the MFMAs (round 5, same box: d41 (70 rows) 0.193 -> 0.177 ms, d42 (68) 0.102 -> 0.093 with 16-row
+    // tiles although they compute 80 rows; d32 (36 rows -> 48) 0.095 -> 0.101): 16 rows while the extra waste stays below 15 % of the map
     const bool pool = y_pool != nullptr;
     const int waste16 = cdiv(d.OH, 16) * 16 - d.OH, waste8 = cdiv(d.OH, 8) * 8 - d.OH;
-    const int rows = (pool || d.pre_frames || waste16 <= waste8 + 2) ? 2 : 1;
+    static const int force_rows = getenv("EVFLY_CONV16_ROWS") ? atoi(getenv("EVFLY_CONV16_ROWS")) : 0;      // tuning switch
+    const int rows = force_rows == 1 && !pool && !d.pre_frames ? 1 : force_rows == 2 ? 2 : (pool || d.pre_frames || 20 * (waste16 - waste8) <= 3 * d.OH) ? 2 : 1;
     EVFLY_REQUIRE(!pool || d.act == ACT_RELU, "conv16: the fused 2x2 max pool needs the ReLU epilogue (its integer max relies on non-negative values)");
     Conv16Geom g{};
     const int TH = 8 * rows;
