@@ -1018,8 +1018,9 @@ __global__ __launch_bounds__(512) void k_conv16pre(ConvDesc d, Conv16Geom g, con
 // MFMA / VALU interleave hints nor moving the patch requests and the store-offset arithmetic into the MFMA stream changed it. The reason
 // is not in the kernel: e21 reads 1.4 MB (+ halo, from L2) and writes 2.7 MB per frame, 1.44 GB per 320 frames -- 0.30 ms IS 4.8 TB/s,
 // 0.60 of the HBM peak and ~0.8 of what a mixed read / write stream reaches on this chip. The layer was memory-bound all along
-// (`roofline.per_layer_bound` counts it among the six HBM-bound layers); the kernel stays because it is the faster one and the design
-// (weights in registers, one wave per SIMD) is the one a compute-bound C_in = 32 layer would want.
+// (`roofline.per_layer_bound` counts it among the six HBM-bound layers). With its stores ablated the kernel takes 0.22 ms -- exactly what
+// k_conv16 takes without stores (0.226, round 4): one wave per SIMD with half the LDS reads per MFMA reaches the same ~1.15 PFLOP/s as two
+// waves per SIMD do, so the design is NOT the lever for e12 either. The kernel stays because it is (marginally) the faster one.
 #ifndef EVFLY_C16R_IL
 #define EVFLY_C16R_IL 1
 #endif
