@@ -85,6 +85,12 @@ def _assert_bf16_close(got, ref):
     (5, 12, 70, 64, 32, 3, 1, 0, 1, False),
     (300, 10, 36, 32, 32, 3, 1, 0, 1, False),    # more tiles than persistent blocks: every block walks several tiles
     (2, 72, 152, 64, 32, 3, 1, 0, 1, False),     # d41's geometry
+    # C_in = 32 with 16-row tiles: k_conv16r (weights in registers, one wave per SIMD, four rows per wave) -- one and two 32-channel
+    # tiles per block, a partial last slice (96 = 64 + 32 channels), no activation, ragged right / bottom edges, more tiles than blocks
+    (4, 34, 70, 32, 32, 3, 1, 0, 1, False),
+    (3, 50, 45, 32, 96, 3, 1, 0, 0, False),
+    (6, 18, 100, 32, 64, 3, 1, 0, 1, False),
+    (90, 66, 40, 32, 64, 3, 1, 0, 1, False),
     # large-M problems (thousands of tiles, ragged last M tile, every XCD slot many times over)
     (70, 60, 81, 128, 128, 3, 1, 0, 1, False),   # e32's geometry at 70 frames
     (200, 27, 37, 128, 256, 3, 1, 1, 0, True),   # padding + residual
