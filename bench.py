@@ -649,7 +649,7 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         if not composite:
             # C5: the serial part of the ConvLSTM -- T dependent (hidden-side GEMM + gate kernel) pairs per chunk --
             # and the latency of ONE stream's 16-frame sequence
-            serial = sum(p["ms"] for p in prof if p["name"] in ("convlstm_h_gemm", "convlstm_gates"))
+            serial = sum(p["ms"] for p in prof if p["name"] in ("convlstm_h_gemm", "convlstm_gates", "convlstm_seq"))
             xg = sum(p["ms"] for p in prof if p["name"] == "convlstm_x_gemm")
             one_ms = None
             if not a.no_stage_rates:
@@ -660,7 +660,8 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                                "batched_input_gemm_ms_per_step": round(xg, 3),
                                "single_stream_sequence_ms": round(one_ms, 3) if one_ms else None,
                                "single_stream_frames_per_s": round(T / (one_ms * 1e-3), 1) if one_ms else None,
-                               "note": f"serial = the {T} dependent (h-GEMM, gates) launch pairs of one {B}-stream chunk; single_stream = one stream's "
+                               "note": f"serial = the {T} dependent recurrence steps of one {B}-stream chunk (from ~1 k state rows: ONE launch, k_clstm16_coop, weights "
+                                       f"resident in groups of 16 CUs, a group barrier per step; below: a GEMM launch per step with the cell update in its epilogue); single_stream = one stream's "
                                        f"{T}-frame sequence through the U-Net alone (latency-bound: {T} frames do not fill the chip)"}
         mf = sum(p["flops"] for p in prof if p["flops"])
         out["mfma_flops_per_frame"] = mf / (B * T)

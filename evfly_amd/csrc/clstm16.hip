@@ -201,7 +201,273 @@ __global__ __launch_bounds__(512) void k_clstm16_seq(const float *__restrict__ z
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same recurrence with the hidden-side weights RESIDENT and the gate columns split over the CUs of a group (round 5).
+// k_clstm16_seq streams all 2 MB of W_h through every CU every step (43-57 us per step whatever the row count), and the per-step
+// launches pay a launch, a K loop that waits for its own DMA eight times and a tail per step (19-21 us). Here the 256 blocks form 16
+// groups of 16: a group owns a block of state rows, member j of a group owns cells [32 j, 32 j + 32) = gate columns [128 j, 128 j + 128)
+// of them. A wave keeps the 32 x 512 weight tile of its 32 gate columns in REGISTERS for the whole sequence (128 VGPRs, A operand),
+// c in registers (4 per 64-row tile), and per step only h(t - 1) of the group's rows comes in: 64-row tiles by LDS-DMA, double
+// buffered, one row (1 KiB, contiguous in HBM) per DMA instruction, its 64 units XOR-swizzled with (row & 15) so that the B-fragment
+// reads (32 rows x one unit) are conflict-free. h(t) goes out once, into the h sequence the decoder reads anyway -- that IS the
+// exchange buffer. The hand-off is the placement-independent one of the CDNA guide: write-through (sc1) stores, EVERY storing wave
+// drains (s_waitcnt vmcnt(0)), a block barrier, one relaxed agent-scope arrival per block on the group's counter of the step, one lane
+// polls it (relaxed, agent scope), a block barrier, and the consumers read with sc1 loads (L2 or memory, never the CU's L1: the lines were
+// written by other CUs a moment ago, each is requested once per step, so the L1 has nothing to give and no buffer_inv is needed -- the
+// acquire cost 1.7 us per step plus a stalled vector-memory pipe behind it: -DEVFLY_CO_ACQ=1, C5 0.282 -> 0.256 ms per 16 steps).
+// Nothing depends on where a block runs; the b % 8 arithmetic below only keeps a group's traffic inside one XCD's L2 when the
+// dispatcher places blocks the way it has been observed to. Counters: one word per (group, step), zeroed by a memset node in front of
+// every launch. Same fragment order, same gate arithmetic as the kernel above and as igemm16's OUT_LSTM epilogue: the same bits
+// (tests/test_gpu_bf16.py::test_convlstm_cooperative_kernel_equals_the_other_paths_bitwise, ..._keeps_two_copies_of_h under a side-stream load).
+// A block that waits ~4 s for its group (a member that never became resident) sets *err and traps: a loud failure, not a hang.
+// Measured (s_memtime timeline, tools/clstm_ts.py): 16 us per step at C5's 2 080 rows (per-step launches: 20-21), 36 us at the 6 656 rows of
+// C3's chunk (k_clstm16_seq: 58). What a step costs: the h tiles and the fp32 pre-activations arrive at the CU's ~15-22 B/clk (96 KB per
+// 64-row tile), the DMA requests stall the issuing waves for most of that, the gates are ~1 k VALU cycles per wave and tile next to 1 k of
+// MFMA, and the hand-off (drain, arrival, poll, first tile's DMA) is ~3 us per step with nothing to hide it under.
+// phase timeline (developer build: -DEVFLY_CO_TS; tools/clstm_ts.py): every wave sums the s_memtime ticks of 0 pre-activation loads issued, 1 wait for the
+// tile's DMA + barrier, 2 next tile's DMA issued + MFMAs, 3 gates + stores, 4 drain + arrive, 5 poll, 6 acquire + barrier, 7 first DMA of the step issued
+#ifdef EVFLY_CO_TS
+__device__ unsigned long long g_co_ts[256 * 8 * 8];
+#define CO_TS(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts_acc[i] += t_ - ts_last; ts_last = t_; } while (0)
+#else
+#define CO_TS(i) do { } while (0)
+#endif
+#ifndef EVFLY_CO_ACQ
+#define EVFLY_CO_ACQ 0      // A/B builds: 1 = an agent-scope acquire behind the poll (not needed with sc1 loads of sc1-stored lines)
+#endif
+constexpr int CO_SC1 = 16;                          // aux bit of the buffer intrinsics: sc1
+constexpr int CO_G = 16, CO_NGRP = 16;              // members per group (column split), groups (row split): 256 blocks, one per CU
+constexpr int CO_TR = 64;                           // state rows per tile: waves 0-3 rows 0-31, waves 4-7 rows 32-63
+constexpr int CO_NT = 7;                            // tiles per group at most (c of a tile: 4 registers per lane)
+constexpr int CO_BUF = CO_TR * CL_HID * 2;          // one h tile: 64 KB
+typedef __attribute__((address_space(1))) unsigned co_gu32;
+
+// wait until at most n vector-memory operations are outstanding (n wave-uniform; the counter is an immediate)
+__device__ __forceinline__ void gm_wait(int n) {
+    switch (__builtin_amdgcn_readfirstlane(n)) {
+#define CO_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        CO_W(1) CO_W(2) CO_W(4) CO_W(5) CO_W(8) CO_W(9) CO_W(10) CO_W(14)
+#undef CO_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+__device__ __forceinline__ void co_dma(unsigned voff, cl_i32x4 srd, unsigned soff, unsigned lds_addr) {
+    // sc1: served by the L2 (or memory), never by this CU's L1 -- the lines were written write-through by other CUs a moment ago, every line is
+    // requested exactly once per step, so the L1 has nothing to give, and no acquire (buffer_inv sc1: ~1.7 us of a stalled vector-memory pipe per
+    // step) is needed in front of the loads
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen sc1 lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+}
+
+__global__ __launch_bounds__(512) void k_clstm16_coop(const float *__restrict__ zx, const bf16_t *__restrict__ whi, int S, int T, int rpi, unsigned u_rpi,
+                                                      int rows_per_group, float *__restrict__ h, float *__restrict__ c, bf16_t *__restrict__ h16,
+                                                      bf16_t *__restrict__ hseq, int fresh, unsigned *__restrict__ cnt, unsigned *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char csm[];      // [2 buffers][64 rows][64 units, swizzled][16 B]
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)csm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, half = lane >> 5;
+    const int rows = S * rpi;
+    // group and member: blocks b, b + 8, b + 16 ... run on one XCD (observed placement, used for L2 locality only)
+    const int b = blockIdx.x, grp = (b & 7) * 2 + (b >> 7), mem = (b >> 3) & 15;
+    const int g0 = grp * rows_per_group, g1 = min(rows, g0 + rows_per_group);
+    if (g0 >= g1) return;                                                 // (the whole group leaves: nobody waits for it)
+    const int ntl = (g1 - g0 + CO_TR - 1) / CO_TR;
+    const int ct = wave & 3, rh = wave >> 2, ctile = mem * 4 + ct;        // the wave's 32 gate columns = 8 cells, its half of a tile's rows
+
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(hseq, 0, (int)(unsigned)((int64_t)S * T * rpi * CL_HID * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(h, 0, rows * CL_HID * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(c, 0, rows * CL_HID * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t h16r = __builtin_amdgcn_make_buffer_rsrc(h16, 0, rows * CL_HID * 2, 0x00020000);
+    const uint64_t qb = (uint64_t)(uintptr_t)hseq, hb16 = (uint64_t)(uintptr_t)h16;      // (the same two descriptors as SGPR quadruples for the DMA asm)
+    const cl_i32x4 qrv = {(int)(unsigned)qb, (int)((unsigned)(qb >> 32) & 0xffff), (int)(unsigned)((int64_t)S * T * rpi * CL_HID * 2), 0x00020000};
+    const cl_i32x4 h16v = {(int)(unsigned)hb16, (int)((unsigned)(hb16 >> 32) & 0xffff), rows * CL_HID * 2, 0x00020000};
+
+    // ---- resident weights: fragment kb of the wave's column tile (whi is in fragment order: 1 KiB of consecutive bytes per request)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(whi), 0, CL_NG * CL_HID * 2, 0x00020000);
+    cl_s16x8 wreg[CL_KB];
+#pragma unroll
+    for (int kb = 0; kb < CL_KB; ++kb)
+        wreg[kb] = __builtin_bit_cast(cl_s16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, (ctile * CL_KB + kb) * 1024, 0));
+    // ---- c of the lane's cells (cell0 + 2 q + half) of its row in every tile
+    float cst[CO_NT][4];
+#pragma unroll
+    for (int k = 0; k < CO_NT; ++k) {
+        const int sr = g0 + k * CO_TR + rh * 32 + n;
+        const unsigned vs = (!fresh && k < ntl && sr < g1) ? (unsigned)sr * (unsigned)(CL_HID * 4) + (unsigned)half * 4u : OOB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cst[k][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, (int)vs, ctile * 32 + q * 8, 0));
+    }
+    // ---- B fragments: row rt of the tile, unit 2 kb + half in slot (unit ^ (rt & 15)): the eight low parts, then 256 B per 8 k steps
+    const int rt = rh * 32 + n;
+    unsigned lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lo[j] = (unsigned)(rt * 1024 + ((((2 * j + half) ^ rt) & 15) << 4));
+    // ---- DMA: piece i of a wave = tile row 8 wave + i; lane l fills slot l = unit l ^ (row & 15)
+    auto dma_tile = [&](int k, int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, sr = g0 + k * CO_TR + r;
+            const unsigned st = __umulhi((unsigned)sr, u_rpi);                              // stream of the state row
+            // t = 0: the bf16 copy of the incoming state; else row (stream, t - 1, pixel) of the h sequence
+            const unsigned srow = t == 0 ? (unsigned)sr : (unsigned)sr + st * (unsigned)((T - 1) * rpi) + (unsigned)((t - 1) * rpi);
+            const unsigned vo = sr < g1 ? (unsigned)((lane ^ (r & 15)) << 4) : OOB;
+            // (under SGPR pressure hipcc carries the loop counter in a VGPR and would hand the asm vector registers for its "s" operands)
+            const cl_i32x4 sel = t == 0 ? h16v : qrv;
+            const cl_i32x4 srd = {__builtin_amdgcn_readfirstlane(sel[0]), __builtin_amdgcn_readfirstlane(sel[1]), __builtin_amdgcn_readfirstlane(sel[2]), 0x00020000};
+            co_dma(vo, srd, (unsigned)__builtin_amdgcn_readfirstlane((int)(srow * (unsigned)(CL_HID * 2))),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(buf * CO_BUF + r * 1024))));
+        }
+    };
+    co_gu32 *gcnt = (co_gu32 *)(cnt + grp * T);
+#ifdef EVFLY_CO_TS
+    unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_last) :: "memory");
+#endif
+
+    // the pre-activations of a tile are requested one tile ahead, each 16-B vector into the register its predecessor has just left (counted asm
+    // loads: hipcc, which does not see the DMA requests in the queue, would wait for half of the next tile's pieces in front of the gates)
+    cl_f32x4 zq[4];
+    auto zq_addr = [&](int k, unsigned &seq0, bool &ok, int &sr) {
+        sr = g0 + k * CO_TR + rt;
+        ok = sr < g1;
+        const unsigned st = __umulhi((unsigned)sr, u_rpi);
+        seq0 = (unsigned)sr + st * (unsigned)((T - 1) * rpi);            // row of (stream, t = 0, pixel) in zx / hseq
+    };
+    const cl_i32x4 zrv = {(int)(unsigned)(uint64_t)(uintptr_t)zx, (int)((unsigned)((uint64_t)(uintptr_t)zx >> 32) & 0xffff),
+                          (int)(unsigned)((int64_t)S * T * rpi * CL_NG * 4), 0x00020000};
+    auto zq_load = [&](cl_f32x4 &dst, unsigned vz, int t, int q) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(t * rpi * (CL_NG * 4) + ctile * 128 + q * 32);
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vz), "s"(zrv), "s"(so) : "memory");
+    };
+    for (int tv = 0; tv < T; ++tv) {
+        // (under SGPR pressure hipcc keeps the loop counters in VGPRs and turns every uniform branch on them into an exec-mask region)
+        const int t = __builtin_amdgcn_readfirstlane(tv);
+        const bool last = t == T - 1;
+        const bool use_h = !(fresh && t == 0);                           // fresh streams: h(-1) = 0 contributes nothing to step 0
+        if (use_h) dma_tile(0, t, 0);
+        CO_TS(7);
+        {
+            unsigned seq0; bool ok; int sr;
+            zq_addr(0, seq0, ok, sr);
+            const unsigned vz = ok ? seq0 * (unsigned)(CL_NG * 4) + (unsigned)half * 16u : OOB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zq_load(zq[q], vz, t, q);
+        }
+#pragma unroll 1
+        for (int kv = 0; kv < ntl; ++kv) {
+            const int k = __builtin_amdgcn_readfirstlane(kv);
+            unsigned seq0, seq0n; bool ok, okn; int sr, srn;
+            zq_addr(k, seq0, ok, sr);
+            zq_addr(k + 1, seq0n, okn, srn);
+            const bool more = k + 1 < ntl;
+            const unsigned vzn = okn ? seq0n * (unsigned)(CL_NG * 4) + (unsigned)half * 16u : OOB;
+            cl_f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            CO_TS(0);
+            if (use_h) {
+                // this wave's pieces of tile k have landed: younger in the queue are the four pre-activation loads and, from the second tile on,
+                // the stores of the tile before (one, or ten in the last step)
+                gm_wait(k == 0 ? 4 : last ? 14 : 5);
+                __syncthreads();                                          // every wave's pieces; and everybody is done with the other buffer
+                CO_TS(1);
+                if (more) dma_tile(k + 1, t, (k + 1) & 1);
+                const unsigned char *hb = csm + (k & 1) * CO_BUF;
+#pragma unroll
+                for (int kb = 0; kb < CL_KB; ++kb) {
+                    const cl_s16x8 bf = *reinterpret_cast<const cl_s16x8 *>(hb + lo[kb & 7] + (kb >> 3) * 256);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kb], bf, acc, 0, 0, 0);
+                }
+            }
+            CO_TS(2);
+            // the tile's pre-activations have landed: younger are the next tile's pieces and (k > 0) the h stores behind the loads
+            {
+                const int nd = (use_h && more) ? 8 : 0;
+                const int n = k == 0 ? nd : nd + (last ? 2 : 1);
+                gm_wait(n);
+                asm volatile("" : "+v"(zq[0]), "+v"(zq[1]), "+v"(zq[2]), "+v"(zq[3]));
+            }
+            // D register 4 q + g of a lane = gate g of cell cell0 + 2 q + half, state row rt of the tile
+            float hn[4];
+            const unsigned vsl = ok ? (unsigned)sr * (unsigned)(CL_HID * 4) + (unsigned)half * 4u : OOB;
+            // (the tile loop stays rolled -- unrolled, hipcc hoists every tile's addresses out of the time loop and spills 55 registers -- so the
+            // tile's c, a register, is picked by a uniform branch)
+            float cold[4], cnew[4];
+#pragma unroll
+            for (int kk = 0; kk < CO_NT; ++kk)
+                if (kk == k) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cold[q] = cst[kk][q];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float zi = acc[4 * q] + zq[q][0], zf = acc[4 * q + 1] + zq[q][1];
+                const float zo = acc[4 * q + 2] + zq[q][2], zg = acc[4 * q + 3] + zq[q][3];
+                const float cn = cl_sigmoid(zf) * cold[q] + cl_sigmoid(zi) * cl_tanh(zg);         // convlstm.py:50
+                cnew[q] = cn;
+                hn[q] = cl_sigmoid(zo) * cl_tanh(cn);                                              // :51
+                if (last) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn[q]), hr, (int)vsl, ctile * 32 + q * 8, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cn), cr, (int)vsl, ctile * 32 + q * 8, 0);
+                }
+                if (more) zq_load(zq[q], vzn, t, q);
+            }
+#pragma unroll
+            for (int kk = 0; kk < CO_NT; ++kk)
+                if (kk == k) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cst[kk][q] = cnew[q];
+                }
+            unsigned u = pack_bf2(hn[0], hn[1]), v = pack_bf2(hn[2], hn[3]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, v, false, false);
+            u = sw[0]; v = sw[1];
+            typedef unsigned cl_u32x2 __attribute__((ext_vector_type(2)));
+            const cl_u32x2 o8v = {__builtin_amdgcn_perm(v, u, 0x05040100u), __builtin_amdgcn_perm(v, u, 0x07060302u)};
+            const unsigned vq = ok ? seq0 * (unsigned)(CL_HID * 2) + (unsigned)half * 8u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b64(o8v, qr, (int)vq, t * rpi * (CL_HID * 2) + ctile * 16, /*sc1: write-through*/ CO_SC1);
+            if (last) {
+                const unsigned v16 = ok ? (unsigned)sr * (unsigned)(CL_HID * 2) + (unsigned)half * 8u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(o8v, h16r, (int)v16, ctile * 16, 0);
+            }
+            CO_TS(3);
+        }
+        if (last) break;
+        // ---- the group's hand-off of h(t): every storing wave drains, one arrival per block, one poller, one acquire
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CO_TS(4);
+        if (tid == 0) {
+            __hip_atomic_fetch_add(gcnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(gcnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)CO_G) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) { __hip_atomic_store((co_gu32 *)err, 1u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_trap(); }
+            }
+            CO_TS(5);
+#if EVFLY_CO_ACQ
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        }
+        __syncthreads();
+        CO_TS(6);
+    }
+#ifdef EVFLY_CO_TS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) g_co_ts[(blockIdx.x * 8 + wave) * 8 + i] = ts_acc[i];
+#endif
+}
+
 }  // namespace
+#ifdef EVFLY_CO_TS
+}  // namespace evfly
+extern "C" int evfly_debug_clstm_ts(unsigned long long *out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evfly::g_co_ts), n * sizeof(unsigned long long));
+}
+namespace evfly {
+#endif
 
 // Each workgroup streams the whole 2 MB of hidden-side weights through its CU every step, and a CU takes ~22 B/clk from L2 (the same
 // per-CU limit conv16w.hip's LDS-DMA runs into): 43 us per step whatever the row count. With few row blocks (C5: 20 streams = 33 blocks)
@@ -226,6 +492,46 @@ void clstm16_fragment_host(const unsigned short *wi, int hid, unsigned short *ds
         for (int k = 0; k < kb; ++k)
             for (int l = 0; l < 64; ++l)
                 std::memcpy(dst + (((size_t)t * kb + k) * 64 + l) * 8, wi + (size_t)(t * 32 + (l & 31)) * hid + k * 16 + (l >> 5) * 8, 16);
+}
+
+// the cooperative form: from ~1 k state rows (below that the per-step launches' 128 x 64 tiles already sit in a few CUs' reach) up to what 16
+// groups x 7 tiles hold; T >= 2 (with one step there is nothing to hand over, and the last step's h16 store would race the first step's reads)
+bool clstm16_coop_available(int64_t state_rows, int T) {
+    static const bool off = getenv("EVFLY_NO_CLSTM16_COOP") != nullptr;      // A/B switch
+    static const int64_t min_rows = getenv("EVFLY_CLSTM16_COOP_MIN_ROWS") ? atoll(getenv("EVFLY_CLSTM16_COOP_MIN_ROWS")) : 1024;
+    // every block waits for the fifteen others of its group: the grid (256 blocks, one per CU by its LDS) has to fit the chip at once
+    static const bool fits = [] {
+        int dev = 0, cus = 0;
+        return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= CO_G * CO_NGRP;
+    }();
+    return !off && fits && T >= 2 && state_rows >= min_rows && state_rows <= (int64_t)CO_NGRP * CO_NT * CO_TR;
+}
+size_t clstm16_coop_scratch_words(int T) { return (size_t)CO_NGRP * T + 16; }
+
+// scratch: clstm16_coop_scratch_words(T) 32-bit words (the groups' arrival counters per step + the timeout word), zeroed here on every call
+int launch_clstm16_coop(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, void *scratch,
+                        hipStream_t st) {
+    const int64_t rows = (int64_t)S * rpi;
+    EVFLY_REQUIRE(S > 0 && T >= 2 && rpi > 0 && rpi < 65536 && rows < 65536 && rows <= (int64_t)CO_NGRP * CO_NT * CO_TR &&
+                  (int64_t)S * T * rpi * CL_NG * 4 < ((int64_t)1 << 32), "clstm16_coop: %d x %d x %d rows outside the kernel's range", S, T, rpi);
+    EVFLY_REQUIRE(kNumCU >= CO_G * CO_NGRP, "clstm16_coop: the grid has to be resident at once");
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    EVFLY_HIP(hipGetDevice(&dev));
+    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_clstm16_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CO_BUF));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    const int rpg = (int)((cdiv((int)rows, CO_NGRP) + 31) / 32 * 32);
+    const unsigned u_rpi = rpi <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)rpi + 1);
+    EVFLY_REQUIRE(rpi > 1, "clstm16_coop: rows per image");
+    EVFLY_HIP(hipMemsetAsync(scratch, 0, clstm16_coop_scratch_words(T) * 4, st));
+    unsigned *words = static_cast<unsigned *>(scratch);
+    hipLaunchKernelGGL(k_clstm16_coop, dim3(CO_G * CO_NGRP), dim3(512), 2 * CO_BUF, st, zx, static_cast<const bf16_t *>(whi), S, T, rpi, u_rpi, rpg, h, c,
+                       static_cast<bf16_t *>(h16), static_cast<bf16_t *>(hseq), fresh ? 1 : 0, words, words + (size_t)CO_NGRP * T);
+    EVFLY_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_clstm16_seq(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, hipStream_t st) {

@@ -763,13 +763,17 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         // bf16 pipeline: the T steps of a chunk in ONE launch (clstm16.hip: a 1x1 ConvLSTM is an independent LSTM per position) on
         // gate-interleaved pre-activations; otherwise a GEMM + a gate launch per step
         // (chosen from the forward's first chunk, see clstm_rows_first; the kernel's 32-bit byte offsets bound the chunk: zx < 4 GB)
-        const bool seq = a16 && m->has("clstm.wh_i") && clstm16_seq_available(m->clstm_rows_first > 0 ? m->clstm_rows_first : (int64_t)S * rpi) &&
-                         (int64_t)F * rpi * 4 * hid * 4 < ((int64_t)1 << 32);
+        const int64_t rows_first = m->clstm_rows_first > 0 ? m->clstm_rows_first : (int64_t)S * rpi;
+        // up to 7 168 state rows per chunk (C5: 2 080, C3: 6 656): the cooperative form -- weights resident in the registers of groups of 16 CUs,
+        // h handed over through the h sequence once per step (k_clstm16_coop); more rows: a workgroup per 64 rows, weights streamed
+        const bool coop = a16 && m->has("clstm.wh_i") && clstm16_coop_available(rows_first, T) && clstm16_coop_available((int64_t)S * rpi, T) &&
+                          (int64_t)F * rpi * 4 * hid * 4 < ((int64_t)1 << 32);
+        const bool seq = !coop && a16 && m->has("clstm.wh_i") && clstm16_seq_available(rows_first) && (int64_t)F * rpi * 4 * hid * 4 < ((int64_t)1 << 32);
         // small chunks: per-step launches, the cell update in the hidden-side GEMM's epilogue (igemm16 OUT_LSTM) on the same interleaved
         // layout -- the step's fp32 pre-activations no longer go through HBM twice and the gate launch is gone
         static const bool no_gate_fusion = getenv("EVFLY_NO_CLSTM16_GATE_FUSION") != nullptr;
-        const bool gfuse = a16 && !seq && m->has("clstm.wh_ir") && !no_gate_fusion;
-        const bool il = seq || gfuse;                              // interleaved pre-activations
+        const bool gfuse = a16 && !seq && !coop && m->has("clstm.wh_ir") && !no_gate_fusion;
+        const bool il = coop || seq || gfuse;                              // interleaved pre-activations
         {   // input-side 1x1 conv for every frame at once
             ConvDesc d; d.x = y5; d.ldx = hid; d.NI = F * rpi; d.C = hid; d.w = m->W(il ? "clstm.wx_i" : "clstm.wx"); d.ldw = hid;
             conv_finish(d); d.Nc = 4 * hid; d.y = zx; d.ldy = 4 * hid; d.dtype = c.compute_dtype; d.in_bf16 = a16;
@@ -791,11 +795,15 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         // reads h(t - 1) as its A operand also writes h(t), and a block that starts late -- a grid of more blocks than the chip holds, or
         // a chip shared with another stream's kernels -- must not find rows its neighbours have already replaced
         float *h16 = a16 ? m->alloc_act((int64_t)S * rpi * hid) : nullptr;
-        float *h16_alt = a16 && !seq ? m->alloc_act((int64_t)S * rpi * hid) : nullptr;
+        float *h16_alt = a16 && !seq && !coop ? m->alloc_act((int64_t)S * rpi * hid) : nullptr;
         if (a16 && !m->planning) {
             if (int rc = launch_f32_to_bf16(hs, (int64_t)S * rpi * hid, h16, st)) return rc;
         }
-        if (seq)
+        if (coop) {
+            float *ws = m->alloc((int64_t)clstm16_coop_scratch_words(T));
+            RUN(m, "convlstm_seq", 2.0 * S * rpi * 4.0 * hid * hid * (h_state ? T : T - 1), (double)F * rpi * hid * (16.0 + 2.0 + 2.0) + 2.0 * 4.0 * hid * hid,
+                launch_clstm16_coop(zx, m->W("clstm.wh_i"), S, T, rpi, hs, cs, h16, hseq, !h_state, ws, st));
+        } else if (seq)
             RUN(m, "convlstm_seq", 2.0 * S * rpi * 4.0 * hid * hid * (h_state ? T : T - 1), (double)F * rpi * hid * (16.0 + 2.0) + 2.0 * 4.0 * hid * hid,
                 launch_clstm16_seq(zx, m->W("clstm.wh_i"), S, T, rpi, hs, cs, h16, hseq, !h_state, st));
         else

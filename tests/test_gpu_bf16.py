@@ -287,9 +287,10 @@ def test_convlstm_fused_paths_equal_per_step_launches(gpu_device, tmp_path):
         return torch.load(out)
 
     ref = child("steps", EVFLY_NO_CLSTM16_GATE_FUSION="1", EVFLY_NO_CLSTM16_SEQ="1")
-    seq = child("seq", EVFLY_CLSTM16_SEQ_MIN_ROWS="0")
+    seq = child("seq", EVFLY_CLSTM16_SEQ_MIN_ROWS="0", EVFLY_NO_CLSTM16_COOP="1")
+    coop = child("coop", EVFLY_CLSTM16_COOP_MIN_ROWS="0")
     fused, _, _ = _clstm_seq_outputs()
-    for got in (seq, fused):
+    for got in (seq, coop, fused):
         for k in ("h1", "c1", "h2", "c2"):
             assert torch.isfinite(got[k]).all()
             assert rel_err(got[k], ref[k]) < 1e-2, (k, rel_err(got[k], ref[k]))
@@ -298,6 +299,59 @@ def test_convlstm_fused_paths_equal_per_step_launches(gpu_device, tmp_path):
     # the two fused paths run the same arithmetic in the same order: same bits
     for k in ("h1", "c1", "h2", "c2", "up1", "up2"):
         assert torch.equal(seq[k], fused[k]), k
+        assert torch.equal(coop[k], fused[k]), k
+
+
+CLSTM_SHAPES = ((20, 16), (64, 10), (7, 3))
+
+
+def _clstm_shapes_outputs():
+    """The bf16 U-Net over (streams, windows) batches that exercise the ConvLSTM paths' tilings -- 2 080 state rows (C5: three 64-row tiles per
+    group of the cooperative kernel, the last one half full, three of sixteen groups idle), 6 656 (C3's chunk: six and a half tiles in every
+    group), 728 (one tile, the last group ragged) -- fresh, then with the carried state: ConvLSTM states and depth maps."""
+    net, _ = _unet("cuda")
+    out = {}
+    for S, T in CLSTM_SHAPES:
+        x = cond_frames(31 + S, 8).repeat((S * T + 7) // 8, 1, 1, 1)[:S * T]
+        x = (x * torch.linspace(0.4, 1.0, S * T).view(-1, 1, 1, 1)).cuda()
+        with torch.no_grad():
+            d1, _, st1 = net.forward_streams(x, None, S, T)
+            d2, _, st2 = net.forward_streams(x.flip(0).contiguous(), st1, S, T)
+        out[(S, T)] = {"d1": d1.float().cpu(), "d2": d2.float().cpu(), "h1": st1[0][0].float().cpu(), "c1": st1[0][1].float().cpu(),
+                       "h2": st2[0][0].float().cpu(), "c2": st2[0][1].float().cpu()}
+    return out
+
+
+def test_convlstm_cooperative_kernel_equals_the_other_paths_bitwise(gpu_device, tmp_path):
+    """k_clstm16_coop (round 5: hidden-side weights resident in the registers of groups of 16 CUs, h handed from CU to CU through the h
+    sequence once per step with write-through stores, an arrival counter per group and step, and L1-bypassing loads) against the two paths
+    it replaces: the one-launch kernel that streams the weights (EVFLY_NO_CLSTM16_COOP=1, EVFLY_CLSTM16_SEQ_MIN_ROWS=0) and the GEMM launch
+    per step with the cell update in its epilogue (EVFLY_NO_CLSTM16_COOP=1, EVFLY_NO_CLSTM16_SEQ=1). All three accumulate the hidden-side
+    product in the same fragment order and run the same gate arithmetic: the same bits, states and depth maps, fresh and carried state, at
+    the tilings of C5 and of C3's chunk and at a ragged one. A stale or torn hand-off shows as differing rows."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def child(tag, **env):
+        out = str(tmp_path / (tag + ".pt"))
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import torch, test_gpu_bf16 as t\n"
+                "torch.save(t._clstm_shapes_outputs(), %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+        return torch.load(out)
+
+    steps = child("steps", EVFLY_NO_CLSTM16_COOP="1", EVFLY_NO_CLSTM16_SEQ="1")
+    seq = child("seq", EVFLY_NO_CLSTM16_COOP="1", EVFLY_CLSTM16_SEQ_MIN_ROWS="0")
+    coop = child("coop", EVFLY_CLSTM16_COOP_MIN_ROWS="0")
+    for shape in CLSTM_SHAPES:
+        for k in ("h1", "c1", "h2", "c2", "d1", "d2"):
+            assert torch.isfinite(coop[shape][k]).all(), (shape, k)
+            for other, name in ((seq, "seq"), (steps, "steps")):
+                bad = (coop[shape][k] != other[shape][k])
+                assert not bad.any(), (shape, k, name, int(bad.sum()), bad.nonzero()[:5].tolist())
 
 
 def test_convlstm_gate_fused_gemm_keeps_two_copies_of_h(gpu_device):
@@ -308,7 +362,25 @@ def test_convlstm_gate_fused_gemm_keeps_two_copies_of_h(gpu_device):
     alone on the chip the blocks of a row block start and finish together and nothing shows). Here: 32 streams x 10 windows (3 328
     state rows: the per-step path) alone, then three times while the ViT-base velocity model works on 1 280 frames on a side stream --
     depth maps and states bit-identical. (`tools/scripts/build_variant.sh inplace model.hip -DEVFLY_CLSTM_INPLACE_H16` builds the
-    one-copy form this test fails on.)"""
+    one-copy form this test fails on.) Since round 5 a batch of this size takes the cooperative kernel (k_clstm16_coop) by default -- this
+    process then checks ITS hand-off of h between CUs under an uneven load, blocks that become resident late included -- and the per-step
+    path is what `test_convlstm_per_step_path_under_side_stream_load` runs this body on (EVFLY_NO_CLSTM16_COOP=1, read once per process)."""
+    _two_copies_body(gpu_device)
+
+
+def test_convlstm_per_step_path_under_side_stream_load(gpu_device):
+    """The body of the test above in a process where the cooperative kernel is switched off (3 328 state rows: the per-step launches)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_bf16 as t\nt._two_copies_body('cuda')\nprint('ok')\n") % (repo, os.path.join(repo, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_NO_CLSTM16_COOP="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+
+
+def _two_copies_body(gpu_device):
     import evfly_amd.vitfly_models as vm
     net, _ = _unet(gpu_device)
     vit = vm.LSTMNetVIT(**vm.BASE)
