@@ -718,6 +718,8 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     float *up_fused = nullptr;                                                      // unet_out's map when d42's kernel wrote it
     const bool run_decoder = !(c.is_deployment && !(c.velpred == 1 || c.velpred == 11));
     float *cats[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // by decoder level 1..4
+    bool skip_done[5] = {false, false, false, false, false};              // the level's skip is already in its concat buffer (bf16: pool + skip kernel)
+    static const bool no_pool_skip = getenv("EVFLY_NO_POOL_SKIP_FUSION") != nullptr;      // A/B switch
     SkipGrid skip_region[5];                                               // block regions of the fused producer (rh0 == 0: not fused)
     if (run_decoder && c.skip_type == EVFLY_SKIP_INTERP && !no_skip_fuse)
         for (int l = 1; l <= 4; ++l) cats[l] = m->alloc_act((int64_t)F * small[l - 1][0] * small[l - 1][1] * 2 * (512 >> l));
@@ -730,6 +732,14 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
     for (int l = 0; l < 5; ++l) {
         if (l > 0) {
             float *p = pooled;
+            // bf16 pipeline, levels 3 / 4 (their conv kernels fuse neither the pool nor the 'interp' skip): both in one pass over the map, the
+            // skip written into the decoder's concat buffer now instead of a ConvLSTM later
+            const int sdl = 4 - (l - 1);
+            if (!pool_done && a16 && !no_pool_skip && cats[sdl]) {
+                RUN(m, "maxpool", 0, 2.0 * F * (H * W * C * 1.25 + small[sdl - 1][0] * small[sdl - 1][1] * C),
+                    launch16_pool_bilinear(cur, F, H, W, C, p, cats[sdl], small[sdl - 1][0], small[sdl - 1][1], 2 * C, st));
+                skip_done[sdl] = true;
+            } else
             if (!pool_done && a16) RUN(m, "maxpool", 0, 2.0 * F * H * W * C * 1.25, launch16_maxpool2x2(cur, F, H, W, C, p, st));
             else if (!pool_done) RUN(m, "maxpool", 0, 4.0 * F * H * W * C * 1.25, launch_maxpool2x2(cur, F, H, W, C, p, st));
             cur = p; H /= 2; W /= 2;
@@ -869,7 +879,8 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         const int ccat = c.skip_type == EVFLY_SKIP_NONE ? co : 2 * co;
         float *cat = cats[l] ? cats[l] : m->alloc_act((int64_t)F * uh * uw * ccat);
         float *up_dst = m->eoff(cat, ccat - co);
-        if (c.skip_type == EVFLY_SKIP_INTERP && a16)
+        if (c.skip_type == EVFLY_SKIP_INTERP && a16 && skip_done[l]) {
+        } else if (c.skip_type == EVFLY_SKIP_INTERP && a16)
             RUN(m, "skip_bilinear", 0, 2.0 * F * uh * uw * co * 5, launch16_bilinear(enc.y, F, enc.H, enc.W, enc.C, enc.C, cat, uh, uw, ccat, 0, st));
         else if (c.skip_type == EVFLY_SKIP_CROP && a16)
             RUN(m, "skip_crop", 0, 2.0 * F * uh * uw * co * 2,

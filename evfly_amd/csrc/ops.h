@@ -87,6 +87,8 @@ int launch_lstm(const float *xg0 /*(S*T, 512)*/, int n_streams, int T, LstmWeigh
 int launch16_e11(const float *frames, int n, int H, int W, int cin, int form_bev, int apply_form, float cutoff, const float *w_packed,
                  const float *bias, void *y, hipStream_t st);
 int launch16_maxpool2x2(const void *x, int n, int H, int W, int C, void *y, hipStream_t st);
+// the pool and the 'interp' skip of the same map in one pass over it (ops16.hip)
+int launch16_pool_bilinear(const void *x, int n, int H, int W, int C, void *yp, void *ys, int Ho, int Wo, int64_t ldy, hipStream_t st);
 int launch16_bilinear(const void *x, int n, int Hi, int Wi, int C, int64_t ldx, void *y, int Ho, int Wo, int64_t ldy, int align_corners,
                       hipStream_t st);
 int launch16_crop(const void *x, int n, int Hi, int Wi, int C, int top, int left, void *y, int Ho, int Wo, int64_t ldy, hipStream_t st);

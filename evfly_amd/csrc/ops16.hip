@@ -122,6 +122,60 @@ __global__ __launch_bounds__(256) void k16_bilinear(const bf16_t *__restrict__ x
     }
 }
 
+// The 2x2 max pool of a map AND the 'interp' skip resampled from it in one pass (levels 3 and 4 of the bf16 U-Net, whose conv kernels fuse
+// neither): a block owns a strip of `sr` source rows of one image; first the pooled rows of the strip, then every skip row whose upper tap row
+// lies in the strip -- the taps are the lines the block has just pulled through its L2 / the Infinity Cache, so the map crosses HBM once
+// instead of twice (the resize used to run in the decoder, a ConvLSTM later). Same arithmetic per output as k16_maxpool2x2 / k16_bilinear.
+__global__ __launch_bounds__(512) void k16_pool_bilinear(const bf16_t *__restrict__ x, int n, int H, int W, int C8, bf16_t *__restrict__ yp,
+                                                          bf16_t *__restrict__ ys, int Ho, int Wo, int64_t ldy, float sh, float sw, int sr, int nstrips) {
+    const int OH = H / 2, OW = W / 2, C = C8 * 8;
+    for (int b = blockIdx.x; b < n * nstrips; b += gridDim.x) {
+        const int img = b / nstrips, s = b - img * nstrips;
+        const int ya = s * sr, yb = s == nstrips - 1 ? H : ya + sr;
+        // ---- pooled rows [ya / 2, min(OH, yb / 2))
+        const int p0 = ya / 2, p1 = min(OH, yb / 2);
+        for (int i = threadIdx.x; i < (p1 - p0) * OW * C8; i += 512) {
+            const int c = i % C8;
+            int p = i / C8;
+            const int ox = p % OW, oy = p0 + p / OW;
+            const bf16_t *src = x + ((((int64_t)img * H + 2 * oy) * W + 2 * ox) * C8 + c) * 8;
+            float a[8], bb[8], cc[8], d[8], o[8];
+            Elem<bf16_t>::load(src, a); Elem<bf16_t>::load(src + C8 * 8, bb);
+            Elem<bf16_t>::load(src + (int64_t)W * C8 * 8, cc); Elem<bf16_t>::load(src + (int64_t)W * C8 * 8 + C8 * 8, d);
+#define MX(p, q) ((p) > (q) || (p) != (p) ? (p) : (q))
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = MX(MX(a[e], bb[e]), MX(cc[e], d[e]));
+#undef MX
+            Elem<bf16_t>::store(yp + ((((int64_t)img * OH + oy) * OW + ox) * C8 + c) * 8, o);
+        }
+        // ---- skip rows whose upper tap row is in [ya, yb) (the tap rows grow with the skip row: a short candidate range, each tested)
+        const int o_lo = max(0, (int)((float)ya / sh) - 2), o_hi = min(Ho - 1, (int)((float)yb / sh) + 2);
+        for (int oy = o_lo; oy <= o_hi; ++oy) {
+            int y0, y1;
+            float hy0, hy1;
+            bilinear_src_index(oy, H, Ho, sh, 0, y0, y1, hy0, hy1);
+            if (y0 < ya || y0 >= yb) continue;
+            const bf16_t *b0 = x + ((int64_t)img * H + y0) * W * C, *b1 = x + ((int64_t)img * H + y1) * W * C;
+            bf16_t *orow = ys + ((int64_t)img * Ho + oy) * Wo * ldy;
+            for (int i = threadIdx.x; i < Wo * C8; i += 512) {
+                const int ox = i / C8, c = (i - ox * C8) * 8;
+                int x0, x1;
+                float wx0, wx1;
+                bilinear_src_index(ox, W, Wo, sw, 0, x0, x1, wx0, wx1);
+                float p00[8], p01[8], p10[8], p11[8], o[8];
+                Elem<bf16_t>::load(b0 + (int64_t)x0 * C + c, p00); Elem<bf16_t>::load(b0 + (int64_t)x1 * C + c, p01);
+                Elem<bf16_t>::load(b1 + (int64_t)x0 * C + c, p10); Elem<bf16_t>::load(b1 + (int64_t)x1 * C + c, p11);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t0 = p00[e] * wx0 + p01[e] * wx1, t1 = p10[e] * wx0 + p11[e] * wx1;
+                    o[e] = t0 * hy0 + t1 * hy1;
+                }
+                Elem<bf16_t>::store(orow + (int64_t)ox * ldy + c, o);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k16_crop(const uint4 *__restrict__ x, int n, int Hi, int Wi, int C8, int top, int left,
                                                  uint4 *__restrict__ y, int Ho, int Wo, int64_t ldy8) {
     const int64_t total = (int64_t)n * Ho * Wo * C8;
@@ -441,6 +495,19 @@ int launch16_maxpool2x2(const void *x, int n, int H, int W, int C, void *y, hipS
     EVFLY_REQUIRE(C % 8 == 0, "maxpool16: C %% 8");
     const int64_t work = (int64_t)n * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(k16_maxpool2x2, dim3(grid16(work, 256)), dim3(256), 0, st, static_cast<const bf16_t *>(x), n, H, W, C / 8, static_cast<bf16_t *>(y));
+    EVFLY_LAUNCH_CHECK();
+    return 0;
+}
+
+// x (n, H, W, C) dense; yp (n, H / 2, W / 2, C) dense; ys (n, Ho, Wo, ldy): F.interpolate(x, (Ho, Wo), bilinear, align_corners=False)
+int launch16_pool_bilinear(const void *x, int n, int H, int W, int C, void *yp, void *ys, int Ho, int Wo, int64_t ldy, hipStream_t st) {
+    EVFLY_REQUIRE(C % 8 == 0 && ldy % 8 == 0 && H >= 2 && W >= 2 && Ho >= 1 && Wo >= 1 && Ho <= H, "pool_bilinear16: geometry");
+    static const int sr_env = getenv("EVFLY_POOL_SKIP_ROWS") ? atoi(getenv("EVFLY_POOL_SKIP_ROWS")) : 0;
+    const int sr = sr_env > 0 ? (sr_env + 1) / 2 * 2 : 2;       // (measured 2 / 4 / 8 / 12 source rows per block: pool + skip 0.595 / 0.61 / 0.63 / 0.68 ms per C5 step)
+    const int nstrips = std::max(1, H / sr);                     // (the last strip takes the remainder)
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)n * nstrips, 1 << 20);
+    hipLaunchKernelGGL(k16_pool_bilinear, dim3(grid), dim3(512), 0, st, static_cast<const bf16_t *>(x), n, H, W, C / 8, static_cast<bf16_t *>(yp),
+                       static_cast<bf16_t *>(ys), Ho, Wo, ldy, (float)H / (float)Ho, (float)W / (float)Wo, sr, nstrips);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

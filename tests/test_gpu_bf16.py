@@ -236,6 +236,41 @@ def test_skip_tap_stores_equal_full_maps(gpu_device, tmp_path):
         net.hip().tap("e1")
 
 
+def test_pool_skip_kernel_equals_pool_and_resize_launches(gpu_device, tmp_path):
+    """Levels 3 / 4 of the bf16 U-Net: k16_pool_bilinear (round 5: the 2x2 max pool of e32 / e42 and the 'interp' skip resampled from the same
+    map in one pass, the skip written at encoder time) against the pool launch + the decoder's resize launch (EVFLY_NO_POOL_SKIP_FUSION=1, read
+    once per process: subprocess): the same arithmetic per output, the same bits -- depth and up-conv maps, two batch sizes, the arena
+    dirtied in between (a skip row the fused kernel failed to write would show what the previous forward left in the concat buffer)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "ps.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, test_gpu_bf16 as t\n"
+            "torch.save(t._pool_skip_outputs(), %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_NO_POOL_SKIP_FUSION="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+    ref = torch.load(out)
+    got = _pool_skip_outputs()
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), (k, int((got[k] != ref[k]).sum()))
+
+
+def _pool_skip_outputs():
+    net, _ = _unet("cuda")
+    out = {}
+    for nfr, seed in ((5, 74), (23, 75)):
+        x = cond_frames(seed, 8).repeat((nfr + 7) // 8, 1, 1, 1)[:nfr].cuda()
+        d, (_, up, _) = net([x.clone(), None, None])
+        out["depth%d" % nfr] = d.float().cpu()
+        out["up%d" % nfr] = up.float().cpu()
+        for tap in ("d1", "d2"):                              # the decoder levels that read the two skips
+            out[tap + "_%d" % nfr] = net.hip().tap(tap).float().cpu()
+        net([torch.flip(x, dims=[0, 2]).contiguous() * 3.0, None, None])      # other values in every arena buffer
+    return out
+
+
 def test_unet_bf16_stateful_split_equals_one_call(gpu_device):
     """ConvLSTM state hand-off in the bf16 pipeline: frames [0..3) then [3..5) with the carried fp32 state against five frames
     in one call. Same kernels and rounding points (the bf16 copy of h is re-derived from the fp32 state), but the two call
