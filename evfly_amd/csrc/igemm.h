@@ -17,7 +17,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
 }
-enum OutMode { OUT_ROWS = 0, OUT_UPCONV2X2 = 1, OUT_LSTM = 2 };
+enum OutMode { OUT_ROWS = 0, OUT_UPCONV2X2 = 1, OUT_LSTM = 2, OUT_ATTN = 3 };
 
 struct ConvDesc {
     const float *x = nullptr;   // input pixels, row (pixel) stride ldx floats, channels [0, C)
@@ -48,6 +48,11 @@ struct ConvDesc {
     float *lstm_c = nullptr, *lstm_h = nullptr;
     void *lstm_h16 = nullptr, *lstm_hseq = nullptr;
     int64_t lstm_seq_img_rows = 0;
+    // OUT_ATTN (igemm16 only; EfficientSelfAttention, ViTsubmodules.py:74-80): the GEMM is the query projection of (frames x attn_n) token rows, head dim 32;
+    // the epilogue runs the attention of every (token, head) of its tile against the frame's attn_nkv reduced keys / values (attn_kv: [frame][nkv][2 Nc] bf16,
+    // keys then values) and writes the attention output (bf16) instead of q -- k16_attention's arithmetic on the ROUNDED q, i.e. the same bits as the two launches
+    const void *attn_kv = nullptr;
+    int attn_nkv = 0, attn_n = 0;
     int dtype = EVFLY_DTYPE_F32;
     // bf16 pipeline (dtype == EVFLY_DTYPE_BF16 with in_bf16): x, w point at bf16 elements (strides ldx / ldw stay in
     // ELEMENTS; w is [Nc][ldw] bf16 rounded at pack time, ldw a multiple of 64) and go HBM/L2 -> LDS -> MFMA operands

@@ -43,7 +43,7 @@ __device__ __forceinline__ void act8(float (&v)[8], int act) {
     for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], act);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PLAIN>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PLAIN, bool ATTN = false>
 __global__ __launch_bounds__(256) void k_igemm16(ConvDesc d, int n_mt, int n_nt, int cpx, int splits, float *slab) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -249,8 +249,78 @@ __global__ __launch_bounds__(256) void k_igemm16(ConvDesc d, int n_mt, int n_nt,
         const int bi = upconv ? n % d.up_cout : n;
         bj[j] = (d.bias && n < d.Nc) ? d.bias[bi] : 0.f;
     }
-    // the fp32 tile (+ bias) transposed through LDS: every lane then handles 8 adjacent columns of one row
     float *ot = reinterpret_cast<float *>(smem_raw);          // [BM][BN]; every wave passed the last barrier of the K loop
+    if constexpr (ATTN) {      // (its own instantiation: in the common one the attention's registers cost every GEMM an occupancy step)
+        // q tile (+ bias) into LDS with its 16-B column units XOR-swizzled by the row (a thread below reads the 32 columns of ONE row: unswizzled,
+        // the 16 lanes of a read phase hit two bank groups), then one thread per (token, head): k16_attention's arithmetic on the rounded q
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = wn * WN + j * 32 + frow;
+                    ot[row * BN + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3))] = acc[i][j][r] + bj[j];
+                }
+            }
+        __syncthreads();
+        constexpr int NH = BN / 32;
+        const float dim_head = sqrtf(32.0f);
+        const bf16_t *kvb = reinterpret_cast<const bf16_t *>(d.attn_kv);
+        bf16_t *yo = reinterpret_cast<bf16_t *>(d.y);
+        const int nkv = d.attn_nkv, C = d.Nc;
+        for (int idx = tid; idx < BM * NH; idx += 256) {
+            const int row = idx / NH, hq = idx - row * NH;
+            const int64_t m = m0 + row;
+            const int n = n0 + hq * 32;
+            if (m >= d.M || n >= d.Nc) continue;
+            const int f = (int)(m / d.attn_n);
+            float qv[32];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 v = *reinterpret_cast<const float4 *>(ot + row * BN + (((hq * 8 + k) ^ (row & 7)) << 2));
+                const unsigned p0 = pack_bf2(v.x, v.y), p1 = pack_bf2(v.z, v.w);      // (the unfused path stores q as bf16 and reads it back)
+                qv[4 * k] = bf_lo(p0); qv[4 * k + 1] = bf_hi(p0); qv[4 * k + 2] = bf_lo(p1); qv[4 * k + 3] = bf_hi(p1);
+            }
+            float sc[16];
+            float mx = -INFINITY;
+            for (int j = 0; j < nkv; ++j) {
+                const bf16_t *kp = kvb + ((int64_t)f * nkv + j) * 2 * C + n;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float kk[8];
+                    Elem<bf16_t>::load(kp + k * 8, kk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s = fmaf(qv[k * 8 + e], kk[e], s);
+                }
+                s = s / dim_head;
+                sc[j] = s;
+                mx = fmaxf(mx, s);
+            }
+            float den = 0.f;
+            for (int j = 0; j < nkv; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+            float o[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) o[e] = 0.f;
+            for (int j = 0; j < nkv; ++j) {
+                const float pj = sc[j] / den;
+                const bf16_t *vp = kvb + ((int64_t)f * nkv + j) * 2 * C + C + n;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float vv[8];
+                    Elem<bf16_t>::load(vp + k * 8, vv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[k * 8 + e] = fmaf(pj, vv[e], o[k * 8 + e]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Elem<bf16_t>::store(yo + m * d.ldy + n + k * 8, *reinterpret_cast<float(*)[8]>(o + k * 8));
+        }
+        return;
+    }
+    // the fp32 tile (+ bias) transposed through LDS: every lane then handles 8 adjacent columns of one row
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -384,12 +454,12 @@ __global__ __launch_bounds__(256) void k_splitk_reduce16(ConvDesc d, int splits,
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PLAIN>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PLAIN, bool ATTN = false>
 int launch_cfg16(const ConvDesc &d, hipStream_t st) {
     const int n_mt = cdiv(d.M, BM), n_nt = cdiv(d.Nc, BN);
     const int cpx = cdiv(n_mt, kNumXCD);
     const int lds = 2 * (BM + BN) * ROWF * 4;
-    auto kern = k_igemm16<BM, BN, WAVES_M, WAVES_N, PLAIN>;
+    auto kern = k_igemm16<BM, BN, WAVES_M, WAVES_N, PLAIN, ATTN>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
@@ -434,6 +504,13 @@ int launch_by_n16(const ConvDesc &d, hipStream_t st) {
     static const int lstm_bm = getenv("EVFLY_IGEMM16_LSTM_BM") ? atoi(getenv("EVFLY_IGEMM16_LSTM_BM")) : 64;
     if (PLAIN && d.out_mode == OUT_LSTM && d.Nc % 128 == 0 && lstm_bm != 128 && cdiv(d.M, 128) * (d.Nc / 128) <= 2 * kNumCU)
         return lstm_bm == 32 ? launch_cfg16<32, 128, 1, 4, PLAIN>(d, st) : launch_cfg16<64, 128, 2, 2, PLAIN>(d, st);
+    if constexpr (PLAIN) {
+        if (d.out_mode == OUT_ATTN) {
+            EVFLY_REQUIRE(d.Nc % 128 == 0, "igemm16: the attention epilogue is built for the 128-column tile (Nc=%d)", d.Nc);
+            return launch_cfg16<128, 128, 2, 2, true, true>(d, st);
+        }
+    }
+    EVFLY_REQUIRE(d.out_mode != OUT_ATTN, "igemm16: the attention epilogue needs a plain GEMM");
     if (d.Nc % 128 == 0) return launch_cfg16<128, 128, 2, 2, PLAIN>(d, st);
     if (d.Nc > 32) return launch_cfg16<256, 64, 4, 1, PLAIN>(d, st);
     return launch_cfg16<256, 32, 4, 1, PLAIN>(d, st);
@@ -451,6 +528,9 @@ int igemm16_launch(const ConvDesc &d_in, hipStream_t st) {
     EVFLY_REQUIRE(((uintptr_t)d.w) % 16 == 0 && ((uintptr_t)d.x) % 16 == 0 && d.ldx % 8 == 0, "igemm16: operands not 16-byte aligned");
     EVFLY_REQUIRE(d.M < (int64_t)1 << 31, "igemm16: more than 2^31 output pixels in one launch");
     EVFLY_REQUIRE(d.out_mode != OUT_UPCONV2X2 || (d.up_cout > 0 && d.Nc == 4 * d.up_cout && !d.res && d.act == ACT_NONE), "igemm16: bad upconv epilogue");
+    EVFLY_REQUIRE(d.out_mode != OUT_ATTN || (d.out_bf16 && d.in_bf16 && d.Nc % 32 == 0 && !d.res && d.act == ACT_NONE && d.attn_kv && d.attn_nkv >= 1 && d.attn_nkv <= 16 &&
+                                             d.attn_n > 0 && d.KH == 1 && d.KW == 1 && (d.ldy & 7) == 0 && (((uintptr_t)d.y) & 15) == 0 && (((uintptr_t)d.attn_kv) & 15) == 0),
+                  "igemm16: bad attention epilogue");
     EVFLY_REQUIRE(d.out_mode != OUT_LSTM || (d.Nc % 128 == 0 && d.res && !d.res_bf16 && d.res_rpi > 0 && d.lstm_c && d.lstm_h16 && !d.bias &&
                                             d.ldres % 4 == 0 && ((uintptr_t)d.res) % 16 == 0), "igemm16: bad ConvLSTM epilogue");
     const bool plain = d.KH == 1 && d.KW == 1 && d.pad == 0 && d.stride == 1;

@@ -1057,11 +1057,23 @@ static int vit_stage(evfly_model *m, int s, const float *x, int n, int H, int W,
         if (int rc = layernorm(red, (int64_t)n * nkv, NL + "ln1.g", NL + "ln1.beta", redn)) return rc;
         float *kv = m->alloc_act((int64_t)n * nkv * 2 * C);
         if (int rc = linear(m, "vit_linear", NL + "kv", redn, (int64_t)n * nkv, C, C, 2 * C, ACT_NONE, nullptr, 0, kv, 2 * C, io)) return rc;
+        float *att = m->alloc_act(rows * C);
+        // bf16 pipeline, ViT-base widths: the attention in the query projection's epilogue (igemm16 OUT_ATTN: a thread per (token, head) of the tile, the
+        // attention kernel's arithmetic on the rounded q) -- q is neither written nor read back, one launch less; same bits
+        static const bool no_attn_fuse = getenv("EVFLY_NO_ATTN_FUSION") != nullptr;      // A/B switch
+        if (a16 && !no_attn_fuse && C % 128 == 0 && C / heads == 32 && nkv <= 16) {
+            ConvDesc d; d.x = xcur; d.ldx = C; d.NI = (int)rows; d.H = 1; d.W = 1; d.C = C; d.in_bf16 = d.out_bf16 = 1;
+            d.w = m->W(NL + "q.w"); d.ldw = m->planning ? round_up(C, 64) : m->wld[NL + "q"]; d.bias = m->W(NL + "q.b");
+            conv_finish(d); d.Nc = C; d.y = att; d.ldy = C; d.dtype = c.compute_dtype;
+            d.out_mode = OUT_ATTN; d.attn_kv = kv; d.attn_nkv = nkv; d.attn_n = h * w;
+            if (!m->planning && !d.w) return fail(-4, "weights '%s' were not loaded", (NL + "q").c_str());
+            RUN(m, ("vit_linear/" + NL + "q").c_str(), igemm_flops(d) + 4.0 * rows * C * nkv, 2.0 * (2.0 * rows * C + (double)C * C), igemm_launch(d, st));
+        } else {
         float *q = m->alloc_act(rows * C);
         if (int rc = linear(m, "vit_linear", NL + "q", xcur, rows, C, C, C, ACT_NONE, nullptr, 0, q, C, io)) return rc;
-        float *att = m->alloc_act(rows * C);
         if (a16) RUN(m, "vit_attention", 4.0 * rows * C * nkv, 2 * eb * rows * C, launch16_attention(q, kv, n, h * w, nkv, C, heads, att, st));
         else RUN(m, "vit_attention", 4.0 * rows * C * nkv, 8.0 * rows * C, launch_attention(q, kv, n, h * w, nkv, C, heads, att, st));
+        }
         float *x1 = m->alloc_act(rows * C);   // x = x + attn(x)   (:144)
         if (int rc = linear(m, "vit_linear", NL + "fin", att, rows, C, C, C, ACT_NONE, xcur, C, x1, C, a16 ? (IO16 | RES16) : 0)) return rc;
         // --- MixFFN (:98-120)

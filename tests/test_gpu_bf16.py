@@ -471,6 +471,28 @@ def test_vit_bf16_pipeline(gpu_device, trunk):
         om.use_trunk()
 
 
+def test_attention_in_query_projection_equals_the_two_launches(gpu_device, tmp_path):
+    """ViT-base trunk, bf16 pipeline: EfficientSelfAttention's attention in the epilogue of the query projection (igemm16 OUT_ATTN, round 5: one thread per
+    (token, head) of the finished q tile runs the attention kernel's arithmetic on the ROUNDED q; q is never written) against the projection launch + the
+    attention launch (EVFLY_NO_ATTN_FUSION=1, read once per process: subprocess): the same bits -- velocities and both stage outputs, 5 and 37 frames
+    (a ragged last M tile, tiles that straddle frames: a token's keys are its own frame's)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "attn.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, test_gpu_bf16 as t\n"
+            "torch.save([t._vit_base_taps(5, 11)[0], t._vit_base_taps(37, 12)[0]], %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, EVFLY_NO_ATTN_FUSION="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+    ref = torch.load(out)
+    for got, want in zip((_vit_base_taps(5, 11)[0], _vit_base_taps(37, 12)[0]), ref):
+        for k in ("v", "s1", "s2"):
+            assert torch.isfinite(got[k]).all()
+            assert torch.equal(got[k], want[k]), (k, int((got[k] != want[k]).sum()), float((got[k] - want[k]).abs().max()))
+
+
 def _vit_base_taps(n_frames=5, seed=11):
     """LSTMNetVIT with the ViT-base trunk in the bf16 pipeline on a seeded batch: velocities and the two stage outputs."""
     import evfly_amd.vitfly_models as vm
