@@ -337,13 +337,14 @@ def test_convlstm_fused_paths_equal_per_step_launches(gpu_device, tmp_path):
         assert torch.equal(coop[k], fused[k]), k
 
 
-CLSTM_SHAPES = ((20, 16), (64, 10), (7, 3))
+CLSTM_SHAPES = ((20, 16), (64, 10), (7, 3), (10, 2), (69, 2))
 
 
 def _clstm_shapes_outputs():
     """The bf16 U-Net over (streams, windows) batches that exercise the ConvLSTM paths' tilings -- 2 080 state rows (C5: three 64-row tiles per
     group of the cooperative kernel, the last one half full, three of sixteen groups idle), 6 656 (C3's chunk: six and a half tiles in every
-    group), 728 (one tile, the last group ragged) -- fresh, then with the carried state: ConvLSTM states and depth maps."""
+    group), 728 (one tile, the last group ragged), 1 040 rows x two steps (one hand-off), 7 176 rows (just past what the cooperative kernel takes: the
+    streamed-weights kernel) -- fresh, then with the carried state: ConvLSTM states and depth maps."""
     net, _ = _unet("cuda")
     out = {}
     for S, T in CLSTM_SHAPES:
