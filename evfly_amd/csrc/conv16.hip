@@ -609,7 +609,10 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     stage_tile();
     issue_stores(0, NST);
 #ifdef EVFLY_C16_TS
-    if (PRE && lane == 0 && blockIdx.x < 256) {      // (the fused-first-conv layer only: later layers must not overwrite its record)
+#ifndef EVFLY_C16_TS_SEL
+#define EVFLY_C16_TS_SEL PRE      // which instantiation records (developer builds: e.g. -DEVFLY_C16_TS_SEL="(POOL&&NTB==2&&!PRE)" for e22)
+#endif
+    if ((EVFLY_C16_TS_SEL) && lane == 0 && blockIdx.x < 256) {      // (one layer only: later layers must not overwrite its record)
         ts_acc[7] = (unsigned long long)n_steps;
 #pragma unroll
         for (int i = 0; i < 8; ++i) g_c16_ts[((size_t)blockIdx.x * 8 + wv) * 8 + i] = ts_acc[i];

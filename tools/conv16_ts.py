@@ -29,7 +29,12 @@ steps = t[:, :, 7]
 per = t[:, :, :7] / np.maximum(steps[:, :, None], 1)
 names = ["even producer", "frame loads + stores issued", "fragment loop", "odd producer", "frame store", "pack / pool", "step barrier"]
 halves = ((slice(0, 8, 2), "even waves"), (slice(1, 8, 2), "odd waves"))
-if not os.environ.get("EVFLY_CONV16_PRE_OLD"):
+if os.environ.get("C16_TS_GENERIC"):
+    # a non-PRE k_conv16 instantiation selected with -DEVFLY_C16_TS_SEL=...: 1 next patch's DMA issued (+ previous tile's stores), 2 fragment loop, 5 pack / pool,
+    # 6 wait for the patch + step barrier
+    names = ["-", "next patch's DMA + previous tile's stores issued", "fragment loop", "-", "-", "pack / pool", "wait for the patch + barrier"]
+    halves = ((slice(0, 8), "all waves"),)
+elif not os.environ.get("EVFLY_CONV16_PRE_OLD"):
     # k_conv16pre (round 5): 0 frame loads + store offsets, 1 fragment loop (MFMAs + previous tile's epilogue + producer), 2 frame
     # store, 3 barrier wait; waves 0-3 run three producer slots, waves 4-7 two
     names = ["frame loads + store offsets", "fragment loop (all of it)", "frame store", "barrier wait", "-", "-", "-"]
