@@ -244,7 +244,7 @@ constexpr int CO_BUF = CO_TR * CL_HID * 2;          // one h tile: 64 KB
 typedef __attribute__((address_space(1))) unsigned co_gu32;
 
 // wait until at most n vector-memory operations are outstanding (n wave-uniform; the counter is an immediate)
-__device__ __forceinline__ void gm_wait(int n) {
+__device__ __forceinline__ void co_wait(int n) {
     switch (__builtin_amdgcn_readfirstlane(n)) {
 #define CO_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
         CO_W(1) CO_W(2) CO_W(4) CO_W(5) CO_W(8) CO_W(9) CO_W(10) CO_W(14)
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(512) void k_clstm16_coop(const float *__restrict__ 
             if (use_h) {
                 // this wave's pieces of tile k have landed: younger in the queue are the four pre-activation loads and, from the second tile on,
                 // the stores of the tile before (one, or ten in the last step)
-                gm_wait(k == 0 ? 4 : last ? 14 : 5);
+                co_wait(k == 0 ? 4 : last ? 14 : 5);
                 __syncthreads();                                          // every wave's pieces; and everybody is done with the other buffer
                 CO_TS(1);
                 if (more) dma_tile(k + 1, t, (k + 1) & 1);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512) void k_clstm16_coop(const float *__restrict__ 
             {
                 const int nd = (use_h && more) ? 8 : 0;
                 const int n = k == 0 ? nd : nd + (last ? 2 : 1);
-                gm_wait(n);
+                co_wait(n);
                 asm volatile("" : "+v"(zq[0]), "+v"(zq[1]), "+v"(zq[2]), "+v"(zq[3]));
             }
             // D register 4 q + g of a lane = gate g of cell cell0 + 2 q + half, state row rt of the tile
