@@ -382,6 +382,16 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     // C5 step: e12 0.91 -> 0.86 ms, e21 0.379 -> 0.348, e31 0.265 -> 0.259 -- but e22 (two chunks, pool: 12 stores) 0.575 -> 0.68 and the
     // one-tile variants unchanged, so only the fused-first-conv variant and the two-tile variants without pool spread
     constexpr bool SPREAD = PRE || (NTB == 2 && !POOL);
+    // IMMEDIATE (the variants that do not spread): the finished tile's stores go out right behind its pack, in front of the step-closing wait -- the
+    // wave is about to sit ~1.5 k cycles at that wait and barrier anyway, where the burst at the top of the NEXT step held every wave of the block
+    // ~2 k cycles in the store issue with the matrix pipe idle (tools/conv16_ts.py: e22 2.8 k of 8.3 k cycles per step). The patch DMA of the step
+    // is older than these stores: the closing wait is vmcnt(NST). (Keeping the packed tile live through the next fragment loop instead -- the
+    // spread form, or one wave of a SIMD storing late -- spills in the 256-register e22 variant: 0.53 -> 0.58-0.77 ms.)
+#ifndef EVFLY_C16_IMMEDIATE
+#define EVFLY_C16_IMMEDIATE 1
+#endif
+    constexpr bool IMMEDIATE = !SPREAD && !PRE && EVFLY_C16_IMMEDIATE;
+    bool stored_now = false;
     unsigned st_off[ROWS + 1];           // staged byte offsets of this lane's pixel in the output rows / the pooled map (OOB: none)
     bool st_pending = false;
     auto stage_tile = [&]() {
@@ -417,11 +427,12 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
     // store k of the staged tile: k = (row * NTB + n-tile) * 2 + group for the output map, NST_Y + n-tile * 2 + group for the pool.
     // Lanes l / l + 32 hold channel quads {0-3 | 4-7}, {8-11 | 12-15}, ... of the SAME pixel: the swaps of group g hand lane l channels
     // 16 g .. 16 g + 7 and lane l + 32 channels 16 g + 8 .. 16 g + 15 (16 B each)
-    auto issue_stores = [&](int k0, int k1) {          // (compile-time range after unrolling)
+    auto issue_stores = [&](int k0, int k1, int jsel = -1) {          // (compile-time range / n-tile after unrolling; jsel < 0: every n-tile)
         if (!PRE && !st_pending) return;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             if (k < k0 || k >= k1) continue;
+            if (!DOT && jsel >= 0 && (((k >= NST_Y ? k - NST_Y : k) >> 1) % NTB) != jsel) continue;
             if constexpr (DOT) {      // store k = row k's value
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dq[k < ROWS ? k : 0]), dr, (int)st_off[k < ROWS ? k : 0], 0, 0);
                 continue;
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             frame_load(t_cur + 2 * g.blocks_per_slice);      // (unconditional: behind the last tile the offsets are out of range)
         }
         stage_tile();
-        if constexpr (!SPREAD) issue_stores(0, NST);
+        if constexpr (!SPREAD && !IMMEDIATE) issue_stores(0, NST);
         if constexpr (!PRE) {                  // (SPREAD: the DMA first -- the step-closing wait is for it, the stores behind it are counted)
             int t_nx = t_cur, c_nx = cc + 1;
             if (c_nx == nchunks) { c_nx = 0; t_nx += g.blocks_per_slice; }
@@ -543,10 +554,17 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
             C16_TS(4);                         // 4: frame store (waits for the frame loads)
         }
         if (cc == nchunks - 1) {
-            // ---- the tile's results, packed straight from the accumulators (staged and stored during the next step)
+            // ---- the tile's results, packed straight from the accumulators; stored during the next step, or (IMMEDIATE) right here, one n-tile at
+            // a time so that only one n-tile's packed rows and pool are live beside the accumulators of the other (the 256-register e22 variant)
             const unsigned rz = d.act == ACT_RELU ? 0u : 0x80008000u;        // (conv16_applicable admits ACT_RELU / ACT_NONE only)
+            if constexpr (IMMEDIATE) { st_tile = t_cur; stage_tile(); stored_now = st_pending; }
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            auto pmax = [](unsigned x, unsigned y) {
+                const u16x2 r = __builtin_elementwise_max(*reinterpret_cast<const u16x2 *>(&x), *reinterpret_cast<const u16x2 *>(&y));
+                return *reinterpret_cast<const unsigned *>(&r);
+            };
 #pragma unroll
-            for (int j = 0; j < NTB; ++j)
+            for (int j = 0; j < NTB; ++j) {
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
 #pragma unroll
@@ -558,49 +576,45 @@ __global__ __launch_bounds__(512) void k_conv16(ConvDesc d, Conv16Geom g, const 
                         // frames and weights of this pipeline are finite, DESIGN.md. Round 4: a compare + select per fp32 value.)
                         pk[r][j][e >> 1] = relu_pk(pack_bf2(acc[r][j][e], acc[r][j][e + 1]), rz);
                     }
-            if constexpr (DOT) {
-                const float db = d.dot_b[0];
+                if constexpr (DOT) {
+                    const float db = d.dot_b[0];
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    float sd = 0.f;
+                    for (int r = 0; r < ROWS; ++r) {
+                        float sd = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 16; e += 2) {      // the ROUNDED outputs, like the stand-alone kernel reads them from the bf16 map
-                        sd = fmaf(bf_lo(pk[r][0][e >> 1]), dw[e], sd);
-                        sd = fmaf(bf_hi(pk[r][0][e >> 1]), dw[e + 1], sd);
+                        for (int e = 0; e < 16; e += 2) {      // the ROUNDED outputs, like the stand-alone kernel reads them from the bf16 map
+                            sd = fmaf(bf_lo(pk[r][0][e >> 1]), dw[e], sd);
+                            sd = fmaf(bf_hi(pk[r][0][e >> 1]), dw[e + 1], sd);
+                        }
+                        dq[r] = (sd + __shfl_xor(sd, 32)) + db;
                     }
-                    dq[r] = (sd + __shfl_xor(sd, 32)) + db;
                 }
-            }
-            if constexpr (POOL && ROWS == 2) {
-                // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes (one DPP
-                // quad permute per packed pair: no LDS round trip). The max of bf16-rounded values is the rounded max (rounding is
-                // monotonic): pool the packed results, and do it as UNSIGNED 16-bit integers -- on {+0, positive, +inf, NaN} the bit
-                // patterns order like the values, with every NaN (0x7f81.. / 0xff81..) above +inf: one v_pk_max_u16 per pair is the
-                // NaN-propagating max of torch's max_pool2d (the launcher fuses the pool only behind a ReLU). (Round 3 spelled the
-                // NaN cases as nested float selects around ds_bpermute shuffles: sixteen divergent branch regions with an LDS wait
-                // each, ~2.5 k cycles per tile.)
-                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-                auto pmax = [](unsigned x, unsigned y) {
-                    const u16x2 r = __builtin_elementwise_max(*reinterpret_cast<const u16x2 *>(&x), *reinterpret_cast<const u16x2 *>(&y));
-                    return *reinterpret_cast<const unsigned *>(&r);
-                };
-#pragma unroll
-                for (int j = 0; j < NTB; ++j)
+                if constexpr (POOL && ROWS == 2) {
+                    // 2x2 max pool of the activated tile: rows (oy0, oy0 + 1) in this wave, columns (ox, ox ^ 1) in adjacent lanes (one DPP
+                    // quad permute per packed pair: no LDS round trip). The max of bf16-rounded values is the rounded max (rounding is
+                    // monotonic): pool the packed results, and do it as UNSIGNED 16-bit integers -- on {+0, positive, +inf, NaN} the bit
+                    // patterns order like the values, with every NaN (0x7f81.. / 0xff81..) above +inf: one v_pk_max_u16 per pair is the
+                    // NaN-propagating max of torch's max_pool2d (the launcher fuses the pool only behind a ReLU). (Round 3 spelled the
+                    // NaN cases as nested float selects around ds_bpermute shuffles: sixteen divergent branch regions with an LDS wait
+                    // each, ~2.5 k cycles per tile.)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const unsigned v = pmax(pk[0][j][e], pk[1][j][e]);
                         pm[j][e] = pmax(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));       // lane ^ 1: quad_perm [1, 0, 3, 2]
                     }
+                }
+                if constexpr (IMMEDIATE) issue_stores(0, NST, j);
             }
-            st_tile = t_cur;
+            if constexpr (!IMMEDIATE) st_tile = t_cur;
         }
         // the next patch has landed (this wave's pieces) and every wave is done reading this one
         C16_TS(5);                             // 5: pack / pool
         if constexpr (!PRE) {
             // the next patch has landed: its DMA pieces are older than the NST stores issued behind them in this step (vmcnt retires
             // in order), which stay in flight across the barrier and drain under the next step
-            if (SPREAD && st_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            if ((SPREAD && st_pending) || (IMMEDIATE && stored_now)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stored_now = false;
         }
         __syncthreads();
         C16_TS(6);                             // 6: step barrier
