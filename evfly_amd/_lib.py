@@ -88,6 +88,7 @@ SIGNATURES = {
     "evfly_op_convlstm_gates": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p]),
     "evfly_convlstm_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "evfly_convlstm_forward": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "evfly_convlstm_standby_runs": (c_i64, []),
     "evfly_op_conv2d_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
                                         c_p, c_p, c_p]),
 }

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "bf16.h"
 
@@ -55,10 +56,17 @@ __device__ __forceinline__ float cl_tanh(float v) { return fmaf(2.0f, __builtin_
 
 // zx: (S * T * rpi, 2048) fp32 input-side pre-activations, gate-interleaved columns, row (stream * T + t) * rpi + pixel; whi: the (2048, 512)
 // bf16 matrix with gate-interleaved rows in fragment order (clstm16_fragment_host); h, c: (S * rpi, 512) fp32 state, updated in place; h16: bf16 copy of the final h; hseq: (S * T * rpi, 512) bf16
+__device__ unsigned long long g_standby_runs;      // chunks recomputed by a stand-by launch (evfly_convlstm_standby_runs)
+
 __global__ __launch_bounds__(512) void k_clstm16_seq(const float *__restrict__ zx, const bf16_t *__restrict__ whi, int S, int T, int rpi,
                                                      float *__restrict__ h, float *__restrict__ c, bf16_t *__restrict__ h16,
-                                                     bf16_t *__restrict__ hseq, int fresh) {
+                                                     bf16_t *__restrict__ hseq, int fresh, const float *__restrict__ h_in, const float *__restrict__ c_in,
+                                                     const unsigned *__restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char csm[];      // [2 buffers][64 planes][64 rows][16 B]
+    // gate: this launch is the stand-by of a cooperative launch in front of it (launch_clstm16_coop) and runs only if that one gave up (its
+    // error word is set); h_in / c_in: the incoming state (the stand-by reads the copy saved before the cooperative launch replaced it)
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (gate && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_standby_runs, 1ull);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, half = lane >> 5;
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(512) void k_clstm16_seq(const float *__restrict__ z
 
     // ---- h_{-1} into buffer 0 (bf16 planes); fresh streams start from zeros (an out-of-range offset loads zeros)
     {
-        const __amdgpu_buffer_rsrc_t hr0 = __builtin_amdgcn_make_buffer_rsrc(h, 0, S * rpi * CL_HID * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t hr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(h_in), 0, S * rpi * CL_HID * 4, 0x00020000);
 #pragma unroll 1
         for (int i = tid; i < CL_BM * (CL_HID / 8); i += 512) {
             const int row = i & (CL_BM - 1), u = i / CL_BM;
@@ -99,13 +107,16 @@ __global__ __launch_bounds__(512) void k_clstm16_seq(const float *__restrict__ z
         v16[rt] = ok ? (unsigned)r * (unsigned)(CL_HID * 2) + (unsigned)half * 8u : OOB;
     }
     float cst[CL_NSL][CL_RT][4];
+    {
+        const __amdgpu_buffer_rsrc_t cr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c_in), 0, rows * CL_HID * 4, 0x00020000);
 #pragma unroll
-    for (int sl = 0; sl < CL_NSL; ++sl)
+        for (int sl = 0; sl < CL_NSL; ++sl)
 #pragma unroll
-        for (int rt = 0; rt < CL_RT; ++rt)
+            for (int rt = 0; rt < CL_RT; ++rt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                cst[sl][rt][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, (int)(fresh ? OOB : vs[rt]), wave * 32 + sl * 256 + q * 8, 0));
+                for (int q = 0; q < 4; ++q)
+                    cst[sl][rt][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr0, (int)(fresh ? OOB : vs[rt]), wave * 32 + sl * 256 + q * 8, 0));
+    }
 
     // ---- the ring of weight fragments: fragment i = (slice i / 32, k step i % 32) of this wave's 32 gate columns, the same 256 every step
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(whi), 0, CL_NG * CL_HID * 2, 0x00020000);
@@ -262,8 +273,9 @@ __device__ __forceinline__ void co_dma(unsigned voff, cl_i32x4 srd, unsigned sof
 
 __global__ __launch_bounds__(512) void k_clstm16_coop(const float *__restrict__ zx, const bf16_t *__restrict__ whi, int S, int T, int rpi, unsigned u_rpi,
                                                       int rows_per_group, float *__restrict__ h, float *__restrict__ c, bf16_t *__restrict__ h16,
-                                                      bf16_t *__restrict__ hseq, int fresh, unsigned *__restrict__ cnt, unsigned *__restrict__ err) {
+                                                      bf16_t *__restrict__ hseq, int fresh, unsigned *__restrict__ cnt, unsigned *__restrict__ err, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char csm[];      // [2 buffers][64 rows][64 units, swizzled][16 B]
+    __shared__ unsigned s_giveup;                                            // the poller's verdict for the block's other waves
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)csm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -441,17 +453,28 @@ __global__ __launch_bounds__(512) void k_clstm16_coop(const float *__restrict__ 
         CO_TS(4);
         if (tid == 0) {
             __hip_atomic_fetch_add(gcnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
+            unsigned spins = 0, giveup = 0;
             while (__hip_atomic_load(gcnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)CO_G) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) { __hip_atomic_store((co_gu32 *)err, 1u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_trap(); }
+                // Fail soft. Nothing guarantees that the group's sixteen blocks are resident together (another cooperative launch on a second
+                // stream, a CU-masked queue, a foreign kernel that holds CUs for seconds): a block that has polled `spin_limit` times -- or sees
+                // that another block has -- sets the error word and the whole block LEAVES; the launcher's stand-by (the gated k_clstm16_seq
+                // queued behind this launch) then recomputes the chunk from the saved incoming state. A trap would take the context down.
+                ++spins;
+                if (spins > spin_limit || ((spins & 1023u) == 0u && __hip_atomic_load((co_gu32 *)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store((co_gu32 *)err, 1u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    giveup = 1;
+                    break;
+                }
             }
+            s_giveup = giveup;
             CO_TS(5);
 #if EVFLY_CO_ACQ
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
         }
         __syncthreads();
+        if (s_giveup) break;             // (uniform: every wave reads the poller's word behind the barrier; nothing of this block is in flight but register loads)
         CO_TS(6);
     }
 #ifdef EVFLY_CO_TS
@@ -494,47 +517,72 @@ void clstm16_fragment_host(const unsigned short *wi, int hid, unsigned short *ds
                 std::memcpy(dst + (((size_t)t * kb + k) * 64 + l) * 8, wi + (size_t)(t * 32 + (l & 31)) * hid + k * 16 + (l >> 5) * 8, 16);
 }
 
+int launch_clstm16_seq_from(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh,
+                            const float *h_in, const float *c_in, const unsigned *gate, hipStream_t st);
+
 // the cooperative form: from ~1 k state rows (below that the per-step launches' 128 x 64 tiles already sit in a few CUs' reach) up to what 16
-// groups x 7 tiles hold; T >= 2 (with one step there is nothing to hand over, and the last step's h16 store would race the first step's reads)
+// groups x 7 tiles hold; T >= 2 (with one step there is nothing to hand over, and the last step's h16 store would race the first step's reads).
+// Every block waits for the fifteen others of its group, so the grid (256 blocks, one per CU by its LDS) should be resident at once: asked PER
+// DEVICE (CU count and the occupancy query for this kernel at its LDS size). That is necessary, not sufficient -- a second cooperative launch
+// on another stream or a foreign kernel can still hold CUs -- which is why the kernel gives up softly and the launcher queues a stand-by.
+static bool coop_fits_device() {
+    static std::mutex mu;
+    static int fits[64];                 // per device: 0 unknown, 1 fits, -1 does not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (fits[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= CO_G * CO_NGRP;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_clstm16_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CO_BUF) == hipSuccess;
+        ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_clstm16_coop, 512, 2 * CO_BUF) == hipSuccess && per_cu >= 1;
+        fits[dev] = ok ? 1 : -1;
+    }
+    return fits[dev] == 1;
+}
 bool clstm16_coop_available(int64_t state_rows, int T) {
     static const bool off = getenv("EVFLY_NO_CLSTM16_COOP") != nullptr;      // A/B switch
     static const int64_t min_rows = getenv("EVFLY_CLSTM16_COOP_MIN_ROWS") ? atoll(getenv("EVFLY_CLSTM16_COOP_MIN_ROWS")) : 1024;
-    // every block waits for the fifteen others of its group: the grid (256 blocks, one per CU by its LDS) has to fit the chip at once
-    static const bool fits = [] {
-        int dev = 0, cus = 0;
-        return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= CO_G * CO_NGRP;
-    }();
-    return !off && fits && T >= 2 && state_rows >= min_rows && state_rows <= (int64_t)CO_NGRP * CO_NT * CO_TR;
+    return !off && T >= 2 && state_rows >= min_rows && state_rows <= (int64_t)CO_NGRP * CO_NT * CO_TR && coop_fits_device();
 }
 size_t clstm16_coop_scratch_words(int T) { return (size_t)CO_NGRP * T + 16; }
 
-// scratch: clstm16_coop_scratch_words(T) 32-bit words (the groups' arrival counters per step + the timeout word), zeroed here on every call
+// scratch: clstm16_coop_scratch_words(T) 32-bit words (the groups' arrival counters per step + the give-up word), zeroed here on every call.
+// state_save: 2 x (S * rpi * 512) floats when the streams carry state in (!fresh), else unused. The launch is followed by its STAND-BY: the
+// one-workgroup-per-64-rows kernel (bit-identical results, tests/test_gpu_bf16.py) gated on the give-up word -- every block of it reads the
+// word and leaves when it is zero (a few microseconds per chunk), otherwise it recomputes the whole chunk from the incoming state. No host
+// round trip, so the pair can sit inside a captured graph and on a pipelined stream.
 int launch_clstm16_coop(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, void *scratch,
-                        hipStream_t st) {
+                        float *state_save, hipStream_t st) {
     const int64_t rows = (int64_t)S * rpi;
     EVFLY_REQUIRE(S > 0 && T >= 2 && rpi > 0 && rpi < 65536 && rows < 65536 && rows <= (int64_t)CO_NGRP * CO_NT * CO_TR &&
                   (int64_t)S * T * rpi * CL_NG * 4 < ((int64_t)1 << 32), "clstm16_coop: %d x %d x %d rows outside the kernel's range", S, T, rpi);
-    EVFLY_REQUIRE(kNumCU >= CO_G * CO_NGRP, "clstm16_coop: the grid has to be resident at once");
-    static std::atomic<bool> attr_set[64];
-    int dev = 0;
-    EVFLY_HIP(hipGetDevice(&dev));
-    EVFLY_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        EVFLY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_clstm16_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CO_BUF));
-        attr_set[dev].store(true, std::memory_order_release);
-    }
+    EVFLY_REQUIRE(coop_fits_device(), "clstm16_coop: the grid has to be resident at once on this device");
+    EVFLY_REQUIRE(fresh || state_save, "clstm16_coop: carried state needs the save area of the stand-by");
+    // polls before a block gives up: ~1 us each, i.e. about a second (a hand-off takes microseconds; a side stream's kernels can delay a
+    // block's START by milliseconds). EVFLY_CLSTM16_COOP_SPINS=1 forces the give-up path (tests).
+    static const unsigned spin_limit = getenv("EVFLY_CLSTM16_COOP_SPINS") ? (unsigned)atoll(getenv("EVFLY_CLSTM16_COOP_SPINS")) : (1u << 20);
     const int rpg = (int)((cdiv((int)rows, CO_NGRP) + 31) / 32 * 32);
     const unsigned u_rpi = rpi <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)rpi + 1);
     EVFLY_REQUIRE(rpi > 1, "clstm16_coop: rows per image");
     EVFLY_HIP(hipMemsetAsync(scratch, 0, clstm16_coop_scratch_words(T) * 4, st));
+    const float *h_in = h, *c_in = c;
+    if (!fresh) {
+        EVFLY_HIP(hipMemcpyAsync(state_save, h, (size_t)rows * CL_HID * 4, hipMemcpyDeviceToDevice, st));
+        EVFLY_HIP(hipMemcpyAsync(state_save + rows * CL_HID, c, (size_t)rows * CL_HID * 4, hipMemcpyDeviceToDevice, st));
+        h_in = state_save; c_in = state_save + rows * CL_HID;
+    }
     unsigned *words = static_cast<unsigned *>(scratch);
+    unsigned *err = words + (size_t)CO_NGRP * T;
     hipLaunchKernelGGL(k_clstm16_coop, dim3(CO_G * CO_NGRP), dim3(512), 2 * CO_BUF, st, zx, static_cast<const bf16_t *>(whi), S, T, rpi, u_rpi, rpg, h, c,
-                       static_cast<bf16_t *>(h16), static_cast<bf16_t *>(hseq), fresh ? 1 : 0, words, words + (size_t)CO_NGRP * T);
+                       static_cast<bf16_t *>(h16), static_cast<bf16_t *>(hseq), fresh ? 1 : 0, words, err, spin_limit);
     EVFLY_LAUNCH_CHECK();
-    return 0;
+    return launch_clstm16_seq_from(zx, whi, S, T, rpi, h, c, h16, hseq, fresh, h_in, c_in, err, st);
 }
 
-int launch_clstm16_seq(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, hipStream_t st) {
+// h_in / c_in: where the incoming state is read (h / c unless a stand-by reads a saved copy); gate: null, or the word that has to be non-zero
+int launch_clstm16_seq_from(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh,
+                            const float *h_in, const float *c_in, const unsigned *gate, hipStream_t st) {
     // (the kernel addresses zx and hseq through buffer descriptors with 32-bit byte offsets)
     EVFLY_REQUIRE(S > 0 && T > 0 && rpi > 0 && (int64_t)S * T * rpi * CL_NG * 4 < ((int64_t)1 << 32), "clstm16_seq: %d x %d x %d pre-activation rows exceed the kernel's 4 GB of 32-bit offsets", S, T, rpi);
     static std::atomic<bool> attr_set[64];
@@ -546,9 +594,21 @@ int launch_clstm16_seq(const float *zx, const void *whi, int S, int T, int rpi, 
         attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_clstm16_seq, dim3(cdiv(S * rpi, CL_BM)), dim3(512), 2 * CL_HBUF, st, zx, static_cast<const bf16_t *>(whi), S, T, rpi, h, c,
-                       static_cast<bf16_t *>(h16), static_cast<bf16_t *>(hseq), fresh ? 1 : 0);
+                       static_cast<bf16_t *>(h16), static_cast<bf16_t *>(hseq), fresh ? 1 : 0, h_in, c_in, gate);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }
 
+int launch_clstm16_seq(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, hipStream_t st) {
+    return launch_clstm16_seq_from(zx, whi, S, T, rpi, h, c, h16, hseq, fresh, h, c, nullptr, st);
+}
+
+int64_t clstm16_standby_runs() {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_standby_runs), sizeof(v)) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
 }  // namespace evfly
+
+extern "C" int64_t evfly_convlstm_standby_runs(void) { return evfly::clstm16_standby_runs(); }

@@ -776,7 +776,9 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         const int64_t rows_first = m->clstm_rows_first > 0 ? m->clstm_rows_first : (int64_t)S * rpi;
         // up to 7 168 state rows per chunk (C5: 2 080, C3: 6 656): the cooperative form -- weights resident in the registers of groups of 16 CUs,
         // h handed over through the h sequence once per step (k_clstm16_coop); more rows: a workgroup per 64 rows, weights streamed
-        const bool coop = a16 && m->has("clstm.wh_i") && clstm16_coop_available(rows_first, T) && clstm16_coop_available((int64_t)S * rpi, T) &&
+        // (one path per forward: a tail chunk of fewer rows than the kernel's lower bound stays on it -- groups without rows leave at once --, so a
+        // stream's result does not depend on which chunk it falls into beyond the three kernels' tested bit-equality)
+        const bool coop = a16 && m->has("clstm.wh_i") && clstm16_coop_available(rows_first, T) && (int64_t)S * rpi <= rows_first &&
                           (int64_t)F * rpi * 4 * hid * 4 < ((int64_t)1 << 32);
         const bool seq = !coop && a16 && m->has("clstm.wh_i") && clstm16_seq_available(rows_first) && (int64_t)F * rpi * 4 * hid * 4 < ((int64_t)1 << 32);
         // small chunks: per-step launches, the cell update in the hidden-side GEMM's epilogue (igemm16 OUT_LSTM) on the same interleaved
@@ -811,8 +813,9 @@ static int unet_chunk(evfly_model *m, const float *frames, int S, int T, float *
         }
         if (coop) {
             float *ws = m->alloc((int64_t)clstm16_coop_scratch_words(T));
+            float *save = h_state ? m->alloc((int64_t)2 * S * rpi * hid) : nullptr;      // the stand-by's copy of the incoming state
             RUN(m, "convlstm_seq", 2.0 * S * rpi * 4.0 * hid * hid * (h_state ? T : T - 1), (double)F * rpi * hid * (16.0 + 2.0 + 2.0) + 2.0 * 4.0 * hid * hid,
-                launch_clstm16_coop(zx, m->W("clstm.wh_i"), S, T, rpi, hs, cs, h16, hseq, !h_state, ws, st));
+                launch_clstm16_coop(zx, m->W("clstm.wh_i"), S, T, rpi, hs, cs, h16, hseq, !h_state, ws, save, st));
         } else if (seq)
             RUN(m, "convlstm_seq", 2.0 * S * rpi * 4.0 * hid * hid * (h_state ? T : T - 1), (double)F * rpi * hid * (16.0 + 2.0) + 2.0 * 4.0 * hid * hid,
                 launch_clstm16_seq(zx, m->W("clstm.wh_i"), S, T, rpi, hs, cs, h16, hseq, !h_state, st));

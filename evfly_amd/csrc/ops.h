@@ -64,11 +64,12 @@ void clstm16_interleave_host(const unsigned short *w_src, int hid, int ld, unsig
 void clstm16_fragment_host(const unsigned short *wi, int hid, unsigned short *dst);
 int launch_clstm16_seq(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, hipStream_t st);
 // the same recurrence with resident weights and the gate columns split over groups of 16 CUs (h handed over through the h sequence, one
-// group barrier per step); scratch: clstm16_coop_scratch_words(T) 32-bit words
+// group barrier per step); scratch: clstm16_coop_scratch_words(T) 32-bit words; state_save: 2 x S * rpi * 512 floats when the streams carry
+// state in (the launch is followed by its stand-by, k_clstm16_seq gated on the kernel's give-up word: fail-soft, no host round trip)
 bool clstm16_coop_available(int64_t state_rows, int T);
 size_t clstm16_coop_scratch_words(int T);
 int launch_clstm16_coop(const float *zx, const void *whi, int S, int T, int rpi, float *h, float *c, void *h16, void *hseq, bool fresh, void *scratch,
-                        hipStream_t st);
+                        float *state_save, hipStream_t st);
 int launch_pixel_shuffle2(const float *x, int n, int H, int W, int C, float *y, int64_t ldy, hipStream_t st);
 // x517 assembly (vitfly_models.py:144): cols [512] = desvel/10, [513..516] = quat (or 1,0,0,0), rest of the pad 0
 int launch_meta_fill(float *x517, int64_t rows, int ld, const float *desvel, const float *quat, hipStream_t st);

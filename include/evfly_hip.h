@@ -380,6 +380,12 @@ int evfly_convlstm_forward(const float *x, int b, int t, int h, int w, int cin, 
                            int hid, int kh, int kw, float *h_state, float *c_state, float *out, void *workspace,
                            int64_t workspace_bytes, void *stream);
 
+/* Diagnostic for the bf16 pipeline's one-launch ConvLSTM recurrence (convlstm.py:157-170 over a chunk's T steps): the cooperative kernel
+ * waits for group-mates on other CUs and gives up softly when they do not show (CUs held by another stream or process); the gated
+ * stand-by launch behind it then recomputes the chunk (same bits). Returns how many chunks of this process ran on the stand-by so far on
+ * the current device (a synchronising read; 0 in a healthy deployment), or -1 on a HIP error. */
+int64_t evfly_convlstm_standby_runs(void);
+
 /* The same operator in the bf16 pipeline (compute_dtype EVFLY_DTYPE_BF16): x, res, y are bf16 NHWC tensors (raw
  * bits in uint16_t), cin % 32 == 0; w_packed / bias stay fp32 (the weights are rounded to bf16 once, like
  * evfly_model_finalize does); fp32 accumulation, one rounding of the result. */

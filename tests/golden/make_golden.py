@@ -156,6 +156,28 @@ def g4():
     save("g4_mixstage", y1=y1.numpy(), y2=y2.numpy())
 
 
+# ------------------------------------------------------------------ G15: Mix-Transformer stages at the "ViT-base" widths
+def g15():
+    """The reference's own (fully parametric, ViTsubmodules.py:122-131) MixTransformerEncoderLayer at the widths / heads / depths
+    BASELINE configs C3 / C4 run (evfly_amd.vitfly_models.BASE: 128 / 256 channels, 4 / 8 heads, 4 + 4 layers, reductions 8 / 4):
+    pins the head split and the 4-layer chain that G4 (heads 1 / 2, 2 layers) cannot see. Stage 2 runs on stage 1's OUTPUT (the
+    trunk's chain, vitfly_models.py:136-137) and on an independent input."""
+    rs = np.random.RandomState(150)
+    x1 = torch.from_numpy(rs.rand(2, 1, 60, 90).astype(np.float32))
+    st1 = ref_vs.MixTransformerEncoderLayer(1, 128, patch_size=7, stride=4, padding=3, n_layers=4, reduction_ratio=8,
+                                            num_heads=4, expansion_factor=8).eval()
+    st1.load_state_dict(syn.fill_state_dict(st1, "vitfly_vitlstm.encoder_blocks.0."))
+    st2 = ref_vs.MixTransformerEncoderLayer(128, 256, patch_size=3, stride=2, padding=1, n_layers=4, reduction_ratio=4,
+                                            num_heads=8, expansion_factor=8).eval()
+    st2.load_state_dict(syn.fill_state_dict(st2, "vitfly_vitlstm.encoder_blocks.1."))
+    with torch.no_grad():
+        y1 = st1(x1)
+        y12 = st2(y1)
+        x2 = torch.from_numpy(rs.standard_normal((2, 128, 15, 23)).astype(np.float32))
+        y2 = st2(x2)
+    save("g15_mixstage_base", y1=y1.numpy(), y12=y12.numpy(), y2=y2.numpy())
+
+
 # ------------------------------------------------------------------ G5: LSTMNetVIT / ViT
 def g5():
     rs = np.random.RandomState(50)
@@ -498,7 +520,7 @@ def g0():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g0", "g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     with torch.no_grad():
         for g in which:
             globals()[g]()

@@ -355,6 +355,9 @@ def _clstm_shapes_outputs():
             d2, _, st2 = net.forward_streams(x.flip(0).contiguous(), st1, S, T)
         out[(S, T)] = {"d1": d1.float().cpu(), "d2": d2.float().cpu(), "h1": st1[0][0].float().cpu(), "c1": st1[0][1].float().cpu(),
                        "h2": st2[0][0].float().cpu(), "c2": st2[0][1].float().cpu()}
+    from evfly_amd import _lib
+    torch.cuda.synchronize()
+    out["standby_runs"] = int(_lib.lib().evfly_convlstm_standby_runs())
     return out
 
 
@@ -382,12 +385,42 @@ def test_convlstm_cooperative_kernel_equals_the_other_paths_bitwise(gpu_device, 
     steps = child("steps", EVFLY_NO_CLSTM16_COOP="1", EVFLY_NO_CLSTM16_SEQ="1")
     seq = child("seq", EVFLY_NO_CLSTM16_COOP="1", EVFLY_CLSTM16_SEQ_MIN_ROWS="0")
     coop = child("coop", EVFLY_CLSTM16_COOP_MIN_ROWS="0")
+    assert int(coop["standby_runs"]) == 0, "the cooperative kernel gave up on an idle chip"
     for shape in CLSTM_SHAPES:
         for k in ("h1", "c1", "h2", "c2", "d1", "d2"):
             assert torch.isfinite(coop[shape][k]).all(), (shape, k)
             for other, name in ((seq, "seq"), (steps, "steps")):
                 bad = (coop[shape][k] != other[shape][k])
                 assert not bad.any(), (shape, k, name, int(bad.sum()), bad.nonzero()[:5].tolist())
+
+
+def test_convlstm_cooperative_kernel_gives_up_softly(gpu_device, tmp_path):
+    """The cooperative kernel's blocks wait for group-mates that nothing guarantees to be resident. EVFLY_CLSTM16_COOP_SPINS=0 makes every
+    wait that is not satisfied at its first poll give up: the blocks set the give-up word and LEAVE (no trap, the context survives), and the
+    gated stand-by launch queued behind every cooperative launch recomputes the chunk from the saved incoming state -- fresh and carried
+    state, three tilings: the bits of the undisturbed cooperative run, and `evfly_convlstm_standby_runs` counts the chunks."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def child(tag, **env):
+        out = str(tmp_path / (tag + ".pt"))
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import torch, test_gpu_bf16 as t\n"
+                "torch.save(t._clstm_shapes_outputs(), %r)\nprint('ok')\n") % (repo, os.path.join(repo, "tests"), out)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+        return torch.load(out)
+
+    coop = child("coop", EVFLY_CLSTM16_COOP_MIN_ROWS="0")
+    soft = child("soft", EVFLY_CLSTM16_COOP_MIN_ROWS="0", EVFLY_CLSTM16_COOP_SPINS="0")
+    assert int(coop["standby_runs"]) == 0
+    assert int(soft["standby_runs"]) == 2 * (len(CLSTM_SHAPES) - 1), soft["standby_runs"]      # (two forwards per cooperative shape, one chunk each; the 7 176-row shape is past the kernel's range)
+    for shape in CLSTM_SHAPES:
+        for k in ("h1", "c1", "h2", "c2", "d1", "d2"):
+            bad = (coop[shape][k] != soft[shape][k])
+            assert not bad.any(), (shape, k, int(bad.sum()), bad.nonzero()[:5].tolist())
 
 
 def test_convlstm_gate_fused_gemm_keeps_two_copies_of_h(gpu_device):

@@ -24,6 +24,53 @@ def base_trunk():
     om.use_trunk()
 
 
+def _g15_stages():
+    import evfly_amd.ViTsubmodules as vs
+    st1 = vs.MixTransformerEncoderLayer(1, 128, patch_size=7, stride=4, padding=3, n_layers=4, reduction_ratio=8, num_heads=4,
+                                        expansion_factor=8)
+    st1.load_state_dict(syn.fill_state_dict(st1.state_dict(), "vitfly_vitlstm.encoder_blocks.0."))
+    st2 = vs.MixTransformerEncoderLayer(128, 256, patch_size=3, stride=2, padding=1, n_layers=4, reduction_ratio=4, num_heads=8,
+                                        expansion_factor=8)
+    st2.load_state_dict(syn.fill_state_dict(st2.state_dict(), "vitfly_vitlstm.encoder_blocks.1."))
+    rs = np.random.RandomState(150)
+    x1 = torch.from_numpy(rs.rand(2, 1, 60, 90).astype(np.float32))
+    x2 = torch.from_numpy(rs.standard_normal((2, 128, 15, 23)).astype(np.float32))
+    return st1, st2, x1, x2
+
+
+def test_vit_base_stages_vs_reference_golden_g15_fp32(gpu_device):
+    """`evfly_vit_stage_forward` at the ViT-base hyper-parameters (widths 128 / 256, heads 4 / 8, 4 + 4 layers) against G15 = the
+    REFERENCE's own MixTransformerEncoderLayer run at them (ViTsubmodules.py:122-148; make_golden.py::g15): pins the head split and
+    the 4-layer chain that the oracle-vs-HIP tests of C3 / C4 lean on."""
+    from _util import golden
+    g = golden("g15_mixstage_base")
+    st1, st2, x1, x2 = _g15_stages()
+    st1 = st1.to(gpu_device).eval(); st2 = st2.to(gpu_device).eval()
+    y1 = st1(x1.to(gpu_device))
+    y12 = st2(y1)
+    y2 = st2(x2.to(gpu_device))
+    assert y1.shape == (2, 128, 15, 23) and y2.shape == (2, 256, 8, 12)
+    for tag, got, want in (("y1", y1, g["y1"]), ("y12", y12, g["y12"]), ("y2", y2, g["y2"])):
+        assert rel_err(got.cpu(), want) < 1e-4, (tag, rel_err(got.cpu(), want))
+        assert rel_err_elem(got.cpu(), want) < ELEM_TOL, (tag, rel_err_elem(got.cpu(), want))
+
+
+def test_vit_base_stages_vs_reference_golden_g15_bf16(gpu_device):
+    """The same in the bf16 pipeline (C3's trunk: fused MixFFN kernel, attention in the query projection) at the map bars."""
+    from _util import golden
+    g = golden("g15_mixstage_base")
+    st1, st2, x1, x2 = _g15_stages()
+    for st in (st1, st2):
+        st.to(gpu_device).eval()
+        st.set_compute_dtype("bf16")
+    y1 = st1(x1.to(gpu_device))
+    y2 = st2(x2.to(gpu_device))
+    y12 = st2(torch.from_numpy(g["y1"]).to(gpu_device))       # stage 2 on the reference's stage-1 map: one stage's error, not two
+    assert_bf16_close("g15 y1", y1, g["y1"], BF16_MAP)
+    assert_bf16_close("g15 y2", y2, g["y2"], BF16_MAP)
+    assert_bf16_close("g15 y12", y12, g["y12"], BF16_MAP)
+
+
 def test_vit_base_fp32(gpu_device, base_trunk):
     import evfly_amd.vitfly_models as vm
     net = vm.LSTMNetVIT(**base_trunk)

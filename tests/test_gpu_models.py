@@ -401,6 +401,33 @@ def test_multi_stream_matches_per_stream_oracle(gpu_device):
     assert rel_err(vp.reshape(S, T, 3).cpu(), v.reshape(S, T, 3)[perm].cpu()) < 1e-6
 
 
+def test_c2_64_streams_oracle_sample_through_stream_pipeline(gpu_device):
+    """The headline configuration at FULL size, as bench.py runs it: 64 streams x 5 windows of DISTINCT frames (not tiled) through
+    `StreamPipeline` in exact fp32, two pipelined steps; streams 0 / 31 / 63 of the second step against the oracle's composite
+    (learner_models.py:629-636) run per stream -- depth and velocity within 1e-4 max-norm and north_star's 1e-3 element-wise."""
+    from evfly_amd.pipeline import StreamPipeline
+    net, sd = _composite(gpu_device)
+    pipe = StreamPipeline(net)
+    S, T = 64, 5
+    x = cond_frames(640, S * T)
+    desvel = torch.full((S * T, 1), 4.0)
+    xg, dg = x.to(gpu_device), desvel.to(gpu_device)
+    with torch.no_grad():
+        outs = [pipe.step(xg, dg, S, T) for _ in range(2)]
+        pipe.wait()
+        torch.cuda.synchronize()
+    v, (d, up, _), _ = outs[1]
+    assert torch.equal(v, outs[0][0]) and torch.equal(d, outs[0][1][0])
+    for s in (0, 31, 63):
+        sl = slice(s * T, (s + 1) * T)
+        v_ref, (d_ref, up_ref, _) = om.composite_forward(sd, [x[sl], desvel[sl], [None, None], None])
+        assert rel_err(v[sl].cpu(), v_ref) < TOL and rel_err(d[sl].cpu(), d_ref) < TOL and rel_err(up[sl].cpu(), up_ref) < TOL, s
+        assert rel_err_elem(v[sl].cpu(), v_ref) < ELEM_TOL and rel_err_elem(d[sl].cpu(), d_ref) < ELEM_TOL, s
+    # distinct streams: no two of the sampled velocity blocks coincide
+    vv = v.reshape(S, T, 3)
+    assert not torch.equal(vv[0], vv[31]) and not torch.equal(vv[31], vv[63])
+
+
 def test_full_batch_is_bitwise_reproducible(gpu_device):
     """C2-sized call (64 streams x 5 windows) three times on the same input: depth, velocity and states bit-identical.
     The Winograd kernel counts its own vector-memory queue and hands tiles over through LDS with raw barriers; a missing

@@ -138,6 +138,28 @@ def test_mix_stages():
     assert rel_err(y1, g["y1"]) < TOL and rel_err(y2, g["y2"]) < TOL
 
 
+# ------------------------------------------------------------------ G15 Mix-Transformer stages at the ViT-base widths
+def test_mix_stages_base_widths():
+    """The oracle's ViT-base instantiation (use_trunk(BASE): heads 4 / 8, 4 + 4 layers, widths 128 / 256 from the weights) against
+    the reference's own MixTransformerEncoderLayer at those hyper-parameters (ViTsubmodules.py:122-148; G15 by make_golden.py::g15)."""
+    import evfly_amd.vitfly_models as vm
+    g = golden("g15_mixstage_base")
+    sd = syn.fill_state_dict(vm.LSTMNetVIT(**vm.BASE).state_dict(), "vitfly_vitlstm.")
+    om.use_trunk(heads=vm.BASE["heads"], layers=vm.BASE["layers"], reductions=vm.BASE["reductions"])
+    try:
+        st = om._STAGES[0]
+        rs = np.random.RandomState(150)
+        x1 = torch.from_numpy(rs.rand(2, 1, 60, 90).astype(np.float32))
+        y1 = om.mix_stage_forward(sd, "encoder_blocks.0.", x1, **st[0])
+        y12 = om.mix_stage_forward(sd, "encoder_blocks.1.", y1, **st[1])
+        x2 = torch.from_numpy(rs.standard_normal((2, 128, 15, 23)).astype(np.float32))
+        y2 = om.mix_stage_forward(sd, "encoder_blocks.1.", x2, **st[1])
+    finally:
+        om.use_trunk()
+    assert y1.shape == (2, 128, 15, 23) and y2.shape == (2, 256, 8, 12)
+    assert rel_err(y1, g["y1"]) < TOL and rel_err(y12, g["y12"]) < TOL and rel_err(y2, g["y2"]) < TOL
+
+
 # ------------------------------------------------------------------ G5 LSTMNetVIT / ViT
 def test_lstmnetvit_and_vit():
     g = golden("g5_vit")
