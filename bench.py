@@ -327,10 +327,19 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
     B, T, epw, (Hs, Ws), dtype = cfg["streams"], cfg["windows"], cfg["epw"], cfg["sensor"], cfg["dtype"]
     composite = cfg["model"] == "composite"
     model, sd = build_model(cfg)
-    batch = syn.make_batch(B, T, Hs, Ws, epw, first_stream=rank * B)
-    ev = voxelizer.upload_events(batch)
-    n_events = int(batch["offsets"][-1])
+    # N > 1 ranks share one host's cores for the set-up: at most 32 streams per rank come from their seeds, the rest are rotated copies
+    # ON THE DEVICE (voxelizer.tile_events == synthetic.make_batch's `distinct` layout: C4's 76.8 M events per rank cost 12 s alone and 48 s
+    # eight at a time on an 8-core host -- most of it first-touch page faults of 1 GB of host arrays per rank); one rank generates every stream as before
+    t_setup = time.perf_counter()
+    distinct = 32 if dist is not None and B > 32 else B
+    batch = syn.make_batch(distinct, T, Hs, Ws, epw, first_stream=rank * B)
+    ev = voxelizer.upload_events(batch, prepare=distinct == B)
     del batch
+    if distinct < B:
+        ev = voxelizer.tile_events(ev, B, Hs, Ws)
+    n_events = int(ev["offsets"][-1])
+    torch.cuda.synchronize()
+    setup_events_s = time.perf_counter() - t_setup
     desvel = torch.full((B * T, 1), 4.0, device="cuda")                            # run.py:255
     # sensor larger than the model's 260 x 346 (C3): the centre crop of run.py:345-350 is the voxelizer's region of interest
     roi = None if (Hs, Ws) == (H, W) else voxelizer.centre_crop_roi(Hs, Ws, (H, W))
@@ -530,7 +539,7 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
                      "(evfly_amd/pipeline.py; --no-overlap = one stream)" if pipe else "one HIP stream"),
     }
     if dist is not None:
-        out["ranks"] = {"ms_per_step_by_rank": rank_ms, "all_gather_us": gather_us,
+        out["ranks"] = {"ms_per_step_by_rank": rank_ms, "all_gather_us": gather_us, "setup_events_s": round(setup_events_s, 2),
                         "note": "ms/step of every rank between its own barrier + synchronize pairs (`ms_per_step` = their max); all_gather_us = "
                                 "the velocity all_gather alone (RCCL, 50 back-to-back calls on this rank's rows)"}
     if rank == 0:

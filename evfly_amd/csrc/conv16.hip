@@ -1433,8 +1433,13 @@ int conv16_launch(const ConvDesc &d, const void *wd, float *y_pool, hipStream_t 
                       "one frame channel and C_out = 32");
         // round 5: the one-stream form of this layer (k_conv16pre); EVFLY_CONV16_PRE_OLD=1 keeps the phased kernel for A/B runs
         static const bool old_pre = getenv("EVFLY_CONV16_PRE_OLD") != nullptr;
-        if (!old_pre && d.Nc == 32 && d.NI < 65536 && g.tiles_y < 256 && g.tiles_x < 256)
+        // (every bound launch16pre requires is part of the selection: a batch beyond them falls back to the phased kernel instead of failing)
+        const bool pre_fits = d.Nc == 32 && d.NI < 65536 && g.tiles_y < 256 && g.tiles_x < 256 && g.n_slices == 1 &&
+                              (int64_t)d.NI * (d.H + 2) * (d.W + 2) * 4 < ((int64_t)1 << 31) && (int64_t)d.NI * d.OH * d.OW < ((int64_t)1 << 31);
+        if (!old_pre && pre_fits)
             return pool ? launch16pre<true>(d, g, w, st) : launch16pre<false>(d, g, w, st);
+        // the phased kernel reads the frames through a buffer descriptor with a 32-bit size
+        EVFLY_REQUIRE((int64_t)d.NI * (d.H + 2) * (d.W + 2) * 4 < ((int64_t)1 << 32), "conv16: frames beyond the 4 GB a buffer descriptor spans (chunk the batch)");
         return pool ? launch16d<2, 1, true, true>(d, g, w, st) : launch16d<2, 1, false, true>(d, g, w, st);
     }
     if (d.dot_y) {          // unet_out in the epilogue instead of the 32-channel map (the caller checked conv16_dot_fusable)

@@ -192,9 +192,10 @@ __device__ __forceinline__ float pre_op(float v, int pre) {
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bilinear(const float *__restrict__ x, int n, int Hi, int Wi, int C, int64_t ldx,
                                                   float *__restrict__ y, int Ho, int Wo, int64_t ldy, int align, int pre,
-                                                  float sh, float sw, SkipGrid excl, unsigned cv_magic) {
+                                                  float sh, float sw, SkipGrid excl, unsigned cv_magic, int RPB) {
     const int CV = C / VEC;
-    constexpr int RPB = 16;                                  // consecutive output rows per block and trip (amortises the column setup)
+    // RPB consecutive output rows per block and trip (the launcher's choice: 16 for the large batches, fewer for small ones so that a
+    // single-stream deployment keeps a block per row)
     const int nrows = n * Ho;
     for (int row0 = blockIdx.x * RPB; row0 < nrows; row0 += gridDim.x * RPB)
     for (int row = row0; row < min(row0 + RPB, nrows); ++row) {
@@ -758,13 +759,16 @@ int launch_bilinear(const float *x, int n, int Hi, int Wi, int C, int64_t ldx, f
     const int CV = C % 4 == 0 ? C / 4 : C;
     EVFLY_REQUIRE((int64_t)n * Ho < ((int64_t)1 << 31) && (int64_t)Wo * CV * CV < ((int64_t)1 << 32), "bilinear: map too large");
     const unsigned cv_magic = CV <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)CV + 1);      // floor(i / CV) == umulhi(i, magic) while i * CV < 2^32
-    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)n * Ho, 1 << 20);
+    // rows per block: 16 once that still leaves >= 8 blocks per CU, one row per block for the small batches (n = 1 deployment)
+    const int64_t nrows = (int64_t)n * Ho;
+    const int rpb = (int)std::max<int64_t>(1, std::min<int64_t>(16, nrows / (8 * kNumCU)));
+    const unsigned grid = (unsigned)std::min<int64_t>((nrows + rpb - 1) / rpb, 1 << 20);
     if (C % 4 == 0)
         hipLaunchKernelGGL(k_bilinear<4>, dim3(grid), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy, align_corners, pre, sh, sw,
-                           excl, cv_magic);
+                           excl, cv_magic, rpb);
     else
         hipLaunchKernelGGL(k_bilinear<1>, dim3(grid), dim3(256), 0, st, x, n, Hi, Wi, C, ldx, y, Ho, Wo, ldy, align_corners, pre, sh, sw,
-                           excl, cv_magic);
+                           excl, cv_magic, rpb);
     EVFLY_LAUNCH_CHECK();
     return 0;
 }

@@ -47,9 +47,25 @@ def make_stream(stream_id, T, H=260, W=346, events_per_window=60_000, polarity="
 
 
 def make_batch(B, T, H=260, W=346, events_per_window=60_000, polarity="pm1",
-               clustered=False, seed_base=1234, first_stream=0):
-    """B concatenated streams in SoA form + CSR-style offsets + (B, T+1) window edges."""
+               clustered=False, seed_base=1234, first_stream=0, distinct=None):
+    """B concatenated streams in SoA form + CSR-style offsets + (B, T+1) window edges.
+    distinct: generate only that many streams from their seeds; stream b >= distinct is stream b % distinct with its pixel coordinates
+    rotated by (7, 3) * (b // distinct) (mod W, H) -- different frames, the same timestamps and window populations. Bounds the set-up
+    time of a many-rank benchmark launch (8 ranks x 76.8 M events on one host's cores); never used by the parity tests."""
     xs, ys, ts, ps, offs, edges = [], [], [], [], [0], []
+    if distinct is not None and distinct < B:
+        base = make_batch(distinct, T, H, W, events_per_window, polarity, clustered, seed_base, first_stream)
+        o = base["offsets"]
+        for k in range((B + distinct - 1) // distinct):           # whole blocks of `distinct` streams (the last one may be shorter)
+            nb = min(distinct, B - k * distinct)
+            end = int(o[nb])
+            xk = base["x"][:end] + np.asarray(7 * k % W, base["x"].dtype); xk = np.where(xk >= W, xk - np.asarray(W, xk.dtype), xk)
+            yk = base["y"][:end] + np.asarray(3 * k % H, base["y"].dtype); yk = np.where(yk >= H, yk - np.asarray(H, yk.dtype), yk)
+            xs.append(xk); ys.append(yk); ts.append(base["t"][:end]); ps.append(base["p"][:end])
+            offs.extend((offs[-1] + o[1:nb + 1]).tolist())
+            edges.append(base["edges"][:nb])
+        return dict(x=np.concatenate(xs), y=np.concatenate(ys), t=np.concatenate(ts), p=np.concatenate(ps),
+                    offsets=np.asarray(offs, dtype=np.int64), edges=np.concatenate(edges).astype(np.int64))
     gen = lambda b: make_stream(first_stream + b, T, H, W, events_per_window, polarity, clustered, seed_base)
     if B * T * events_per_window >= 1 << 25:
         # large batches (C3: 512 M events): one stream per worker thread -- every stream has its own RandomState and numpy

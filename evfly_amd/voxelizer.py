@@ -33,6 +33,32 @@ def upload_events(batch, prepare=True):
     return prepare_events(ev) if prepare else ev
 
 
+def tile_events(ev, B, H, W, prepare=True):
+    """Benchmark set-up helper: grow an uploaded batch of D streams to B >= D streams ON THE DEVICE -- stream b is stream b % D with its
+    pixel coordinates rotated by (7, 3) * (b // D) (mod W, H): different frames, the same timestamps and window populations (the layout
+    `evfly_amd.synthetic.make_batch(..., distinct=D)` builds on the host, bit for bit). A many-rank launch then generates D streams per
+    rank from their seeds instead of B (host memory for 8 x 76.8 M events is what an 8-rank C4 set-up waits for)."""
+    D = ev["offsets"].numel() - 1
+    if B <= D:
+        return prepare_events(ev) if prepare and "starts" not in ev else ev
+    o = ev["offsets"]
+    n_full, rem = divmod(B, D)
+    xs, ys, ts, ps, offs, edges = [], [], [], [], [o[:1]], []
+    total = 0
+    for k in range(n_full + (1 if rem else 0)):
+        nb = D if k < n_full else rem
+        end = int(o[nb])
+        x = (ev["x"][:end].to(torch.int32) & 0xFFFF) + (7 * k) % W
+        y = (ev["y"][:end].to(torch.int32) & 0xFFFF) + (3 * k) % H
+        xs.append(torch.where(x >= W, x - W, x).to(torch.int16)); ys.append(torch.where(y >= H, y - H, y).to(torch.int16))
+        ts.append(ev["t"][:end]); ps.append(ev["p"][:end])
+        offs.append(o[1:nb + 1] + total)
+        edges.append(ev["edges"][:nb])
+        total += end
+    out = dict(x=torch.cat(xs), y=torch.cat(ys), t=torch.cat(ts), p=torch.cat(ps), offsets=torch.cat(offs), edges=torch.cat(edges))
+    return prepare_events(out) if prepare else out
+
+
 def _prep_key(ev):
     """identity of the arrays evfly_voxel_prepare read: (pointer, version counter, size) of t, offsets, edges"""
     return tuple((ev[k].data_ptr(), ev[k]._version, ev[k].numel()) for k in ("t", "offsets", "edges"))

@@ -137,3 +137,20 @@ def test_shard_covers_all_streams():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_make_batch_distinct_layout():
+    """synthetic.make_batch(..., distinct=D) -- the layout bench.py's many-rank set-up builds on the device (voxelizer.tile_events):
+    streams 0 .. D-1 from their seeds, stream b >= D = stream b % D with coordinates rotated by (7, 3) * (b // D), same timestamps."""
+    import numpy as np
+    from evfly_amd import synthetic as syn
+    H, W, T, B, D = 260, 346, 2, 11, 4
+    a = syn.make_batch(D, T, H, W, 500, first_stream=9)
+    c = syn.make_batch(B, T, H, W, 500, first_stream=9, distinct=D)
+    oa, oc = a["offsets"], c["offsets"]
+    assert len(oc) == B + 1 and c["edges"].shape == (B, T + 1) and c["x"].dtype == a["x"].dtype
+    for b in range(B):
+        k, j = divmod(b, D)
+        sa, sc = slice(oa[j], oa[j + 1]), slice(oc[b], oc[b + 1])
+        assert np.array_equal(c["t"][sc], a["t"][sa]) and np.array_equal(c["p"][sc], a["p"][sa]) and np.array_equal(c["edges"][b], a["edges"][j])
+        assert np.array_equal(c["x"][sc], (a["x"][sa].astype(np.int64) + 7 * k) % W) and np.array_equal(c["y"][sc], (a["y"][sa].astype(np.int64) + 3 * k) % H)

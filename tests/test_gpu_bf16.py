@@ -136,6 +136,39 @@ def test_conv16p_tile_variants(gpu_device, bp):
         assert ("-> bp %s " % bp) in r.stderr, r.stderr[-2000:]
 
 
+def test_bf16_relu_sign_bit_nan_is_zeroed_fp32_keeps_it(gpu_device):
+    """The documented deviation of the bf16 pipeline's shallow 3x3 kernels: ReLU is an integer maximum on the rounded
+    bf16 pair, so a NaN with its SIGN BIT SET comes out as +0 where torch.relu propagates it; a NaN with a clear sign bit passes through,
+    and the fp32 operator propagates both. One input pixel carries the NaN: exactly its 3x3 neighbourhood of outputs is affected."""
+    rs = np.random.RandomState(5)
+    n, h, w, cin, cout = 1, 20, 36, 32, 32
+    wt = torch.from_numpy((rs.standard_normal((cout, 3, 3, cin)) * 0.1).astype(np.float32)).cuda()
+    bias = torch.zeros(cout).cuda()
+    L = _lib.lib()
+    for bits, name in ((0xFFC0, "negative"), (0x7FC0, "positive")):
+        x = torch.from_numpy(rs.standard_normal((n, h, w, cin)).astype(np.float32))
+        _, xbits = _bits(x)
+        xb = xbits.clone()
+        xb[0, 9, 17, 3] = np.int16(np.uint16(bits).astype(np.int16))
+        y = torch.empty(n, h - 2, w - 2, cout, dtype=torch.int16, device="cuda")
+        _lib.check(L.evfly_op_conv2d_nhwc_bf16(_lib.ptr(xb), n, h, w, cin, _lib.ptr(wt), _lib.ptr(bias), cout, 3, 3, 1, 0, 1,
+                                               None, _lib.ptr(y), _lib.cur_stream()))
+        got = y.cpu().view(torch.bfloat16).float()
+        hood = got[0, 7:10, 15:18]                      # the outputs whose window holds the pixel
+        outside = got.clone(); outside[0, 7:10, 15:18] = 0
+        assert torch.isfinite(outside).all(), name
+        if name == "negative":
+            assert (hood == 0).all(), "a sign-bit NaN is expected to come out of the packed-integer ReLU as +0"
+        else:
+            assert torch.isnan(hood).all(), "a NaN with a clear sign bit passes the integer maximum"
+        # the exact-fp32 operator propagates either
+        xf = xb.cpu().view(torch.bfloat16).float().cuda().contiguous()
+        yf = torch.empty(n, h - 2, w - 2, cout, device="cuda")
+        _lib.check(L.evfly_op_conv2d_nhwc(_lib.ptr(xf), n, h, w, cin, _lib.ptr(wt), _lib.ptr(bias), cout, 3, 3, 1, 0, 1, None,
+                                          _lib.ptr(yf), 0, _lib.cur_stream()))
+        assert torch.isnan(yf[0, 7:10, 15:18]).all(), name
+
+
 def _unet(dev, **kw):
     import evfly_amd.learner_models as lm
     args = dict(num_in_channels=2, num_out_channels=1, num_recurrent=[1, 0], input_shape=[1, 1, 260, 346], velpred=0,

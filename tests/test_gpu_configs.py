@@ -212,8 +212,9 @@ def test_bench_child_process_rccl_path_on_one_gpu(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, EVFLY_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt",
-                        "--no-stage-rates", "--streams", "16", "--no-overlap", "--c4-streams", "8"], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--side-cpu-seconds", "1",
+                        "--no-alt", "--no-stage-rates", "--streams", "16", "--no-overlap", "--c4-streams", "40"], env=env, capture_output=True, text=True,
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     b = json.loads(line)
@@ -221,8 +222,12 @@ def test_bench_child_process_rccl_path_on_one_gpu(tmp_path):
     # the all_gather of this rank's (streams * 5, 3) velocity rows timed alone
     c4 = b["c4"]
     assert "error" not in c4, c4
-    assert c4["workload"].startswith("C4: 8 streams x 5 windows") and "ViT-base" in c4["workload"] and c4["dtype"] == "f32"
-    assert abs(c4["value"] - 8 * 5 * 1e3 / c4["ms_per_step"]) < 1e-2 * c4["value"] and c4["ranks"]["all_gather_us"] > 0 and c4["n_gpus"] == 1
+    assert c4["workload"].startswith("C4: 40 streams x 5 windows") and "ViT-base" in c4["workload"] and c4["dtype"] == "f32"
+    assert abs(c4["value"] - 40 * 5 * 1e3 / c4["ms_per_step"]) < 1e-2 * c4["value"] and c4["ranks"]["all_gather_us"] > 0 and c4["n_gpus"] == 1
+    # ... and its own CPU baseline (rank 0) and the set-up time of the rank's event streams (SCALE readiness: bounded per rank -- with ranks
+    # talking, at most 32 streams per rank are generated from their seeds, the other 8 here are rotated copies made on the device)
+    assert c4["cpu_baseline"]["value"] > 0 and c4["cpu_baseline"]["kind"] == "port" and c4["ranks"]["setup_events_s"] < 60
+    assert b["cpu_baseline"]["value"] > 0
     assert b["n_gpus"] == 1 and b["steps"] == 2 and b["unit"] == "event-frames/s" and b["value"] > 0
     assert abs(b["value"] - 16 * 5 * 1e3 / b["ms_per_step"]) < 1e-2 * b["value"] and "roofline" in b
     assert b["ranks"]["ms_per_step_by_rank"] and b["ranks"]["all_gather_us"] > 0 and b["pipeline"] == "one HIP stream"

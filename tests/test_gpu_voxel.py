@@ -368,3 +368,20 @@ def test_to_events_empty_and_out_of_range(gpu_device):
     fr = te.slice_trajectory(edge, edges, 12, 16, 0.2, 0.3)      # right / bottom edge inclusive (np.histogram2d)
     # the third event is 1 ns before the last edge: float32(29 999 999) == 3e7, so the reference's `ts < t_end` drops it
     assert fr[0, 11, 15] == 0.2 and fr[2, 0, 0] == -0.3 and np.count_nonzero(fr) == 2
+
+
+def test_tile_events_equals_host_layout(gpu_device):
+    from evfly_amd import voxelizer
+    """voxelizer.tile_events (bench.py's many-rank set-up: D streams from their seeds, the rest rotated copies made on the device) ==
+    synthetic.make_batch(..., distinct=D) bit for bit, and the voxelizer's frames of a rotated stream are the rotated frames."""
+    H, W, T, B, D = 260, 346, 3, 11, 4
+    host = syn.make_batch(B, T, H, W, events_per_window=3000, first_stream=5, distinct=D)
+    ev = voxelizer.tile_events(voxelizer.upload_events(syn.make_batch(D, T, H, W, events_per_window=3000, first_stream=5), prepare=False), B, H, W)
+    for k in ("t", "p", "offsets", "edges"):
+        assert np.array_equal(ev[k].cpu().numpy(), host[k]), k
+    for k in ("x", "y"):
+        assert np.array_equal(ev[k].cpu().numpy().view(np.uint16), host[k]), k
+    counts = voxelizer.voxelize_windows(ev, H, W, out="counts")
+    assert np.array_equal(counts.cpu().numpy(), ovox.batch_window_counts(host, H, W))
+    c = counts.cpu().numpy()
+    assert np.array_equal(np.roll(c[1], shift=(3, 7), axis=(-2, -1)), c[1 + D])          # stream 5 = stream 1 rotated by (7, 3)
