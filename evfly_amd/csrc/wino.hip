@@ -257,7 +257,7 @@ __device__ __forceinline__ void produce_patch(const ConvDesc &d, const WinoGeom 
 //   Y00 = s_00 + s_10 + s_20   Y01 = s_01 + s_11 + s_21   Y10 = s_10 - s_20 - s_30   Y11 = s_11 - s_21 - s_31
 // sets in LDS: k0 = s_01, k1 = s_10, k2 = s_11, k3 = s_20, k4 = s_21, k5 = s_30
 template <int MT, int A>
-__device__ __forceinline__ void out_transform(const f32x16 (&acc)[4], float *smem, int mt, int lane, float bias, int act) {
+__device__ __forceinline__ void out_transform(const f32x16 *acc, float *smem, int mt, int lane, float bias, int act) {
     float4 *xch = reinterpret_cast<float4 *>(smem);   // [mt MT][set 6][r / 4][lane 64] float4 (r % 4)  = MT x 24 KB
     auto at4 = [&](int k, int q) -> float4 & { return xch[((mt * 6 + k) * 4 + q) * 64 + lane]; };   // 16-B LDS accesses
     const int fm = lane & 31, fh = lane >> 5;
@@ -306,12 +306,15 @@ __device__ __forceinline__ void out_transform(const f32x16 (&acc)[4], float *sme
 // <= 168 registers per wave (room to fetch the next quarter's fragments under the current quarter's MFMAs); MT = 2
 // blocks two per CU and single-chunk MT = 1 blocks four per CU with <= 128.
 // ACT = the activation compiled in (ACT_RELU: every U-Net layer) or -1 = d.act at run time.
-template <int MT, int ND, bool ONE, bool PRE, int ACT>
-__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT == 2 || ONE) ? 4 : 3, (MT == 2 || ONE) ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
-    constexpr int NW = 4 * MT, NTHR = 256 * MT;
+// NT = 32-channel output tiles per wave (round 6). NT = 2: a block owns 64 output channels, a wave 8 accumulator tiles (128 registers, two
+// waves per SIMD): every V fragment -- its two fragment reads, its row and column combination -- feeds TWO MFMAs instead of one, the patch is
+// DMA'd once per 64 output channels, prologue and barriers are paid once per 128 MFMAs per wave and chunk. The output transform runs per n-tile.
+template <int MT, int ND, bool ONE, bool PRE, int ACT, int NT>
+__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(NT == 2 ? 2 : (MT == 2 || ONE) ? 4 : 3, NT == 2 ? 2 : (MT == 2 || ONE) ? 4 : 3))) void k_wino9(ConvDesc d, const float *__restrict__ U, WinoGeom g) {
+    constexpr int NW = 4 * MT, NTHR = 256 * MT, NB = 2 * NT;       // NB: U loads in flight per wave (two positions pairs x NT n-tiles)
     // next quarter's fragments fetched under the current quarter's second half-step: only where 168 registers allow it
     // (at the 128-register cap it measured +-1 %)
-    constexpr int PREFETCH = (MT == 1 && !ONE) ? 1 : 0;
+    constexpr int PREFETCH = ((MT == 1 || NT == 2) && !ONE) ? 1 : 0;
     constexpr int BUF_FLOATS = ND * NW * 256;             // one patch buffer: ND * NW pieces of 1 KiB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const int rowq = udiv(bt, g.bx, g.u_bx), bxi = bt - rowq * g.bx;
     const int big = udiv(rowq, g.by, g.u_by), byi = rowq - big * g.by;
     const int img0 = big * g.IMGS, ty0 = g.ty_off + byi * g.TY, tx0 = g.tx_off + bxi * g.TX;
-    const int n0 = nt * 32;
+    const int n0 = nt * (32 * NT);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs
     const int mt = MT == 2 ? (wv & 1) : 0, a = MT == 2 ? (wv >> 1) : wv;
@@ -367,19 +370,30 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     const float sg = a == 1 ? 1.f : -1.f;
     int off0[2][2];         // fragment byte offsets (row rA / rB) x (column pair 0 / 1) of this lane's tile: from ftv
 
-    f32x16 acc[4];          // not zero-filled: the first half-step of chunk 0 starts every accumulator from C = 0
+    f32x16 acc[4 * NT];     // not zero-filled: the first half-step of chunk 0 starts every accumulator from C = 0
 
     const int nchunks = (int)((unsigned)d.C >> 5);
     const int iy0 = 2 * ty0, ix0 = 2 * tx0;
 
     // U stream: [nt][cc][j][hg][pos pair 8][lane 64][pos 2][2]; this wave reads pairs 2a, 2a + 1 (positions 4a .. 4a+3):
     // two 16-B loads 1 KiB apart per half-step, 8 KiB per half-step
-    const float *ub = U + (unsigned)((nt * nchunks * 64 + 2 * a) * 256);      // (32-bit: U holds < 2^24 floats)
+    // (NT = 2: the second n-tile's stream lies nchunks * 64 KiB behind the first; loads are issued in consumption order: position pair q,
+    // then n-tile -- bcur[q * NT + n])
+    const float *ub = U + (unsigned)((nt * NT * nchunks * 64 + 2 * a) * 256);      // (32-bit: U holds < 2^24 floats)
+    const float *ub1 = ub + (NT == 2 ? nchunks * 16384 : 0);
     const unsigned ulane = lane * 16;
-    f32x4 bcur[2] = {};
+    f32x4 bcur[NB] = {};
+    auto u_issue = [&](auto qc, auto nc) {
+        constexpr int Q = decltype(qc)::value, N = decltype(nc)::value;
+        if constexpr (Q == 0) u_load<0>(bcur[Q * NT + N], ulane, N == 0 ? ub : ub1);
+        else u_load<1024>(bcur[Q * NT + N], ulane, N == 0 ? ub : ub1);
+    };
     auto u_first = [&]() {
-        u_load<0>(bcur[0], ulane, ub); u_load<1024>(bcur[1], ulane, ub);
-        ub += 16 * 64 * 2;
+        u_issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (NT == 2) u_issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        u_issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        if constexpr (NT == 2) u_issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        ub += 16 * 64 * 2; ub1 += 16 * 64 * 2;
     };
 
     // ---- patch: either produced from the raw frame (fused first conv, single-chunk layers only) or DMA'd. Descriptor
@@ -407,8 +421,8 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     if constexpr (!produced) {
         u_first();
         // the tables have landed (they are older than the two U loads, which stay in flight)
-        if constexpr (ND == 5) asm volatile("s_waitcnt vmcnt(2)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(ftv));
-        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(ftv));
+        if constexpr (ND == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(ftv) : "n"(NB));
+        else asm volatile("s_waitcnt vmcnt(%7)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(ftv) : "n"(NB));
     }
     if constexpr (!produced) {
         // descriptor from the block's patch origin (img0, iy0, ix0) to the end of its image group: images past the batch
@@ -485,37 +499,42 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         for (int c = 0; c < 4; ++c)
             t[c] = f32x4{fmaf(sg, fv[c].x, fu[c].x), fmaf(sg, fv[c].y, fu[c].y), fmaf(sg, fv[c].z, fu[c].z), fmaf(sg, fv[c].w, fu[c].w)};
     };
-    // one half-step: channel pair e, e + 1 of the four positions (8 MFMAs); KW = operations younger than bcur[q]'s load
+    // one half-step: channel pair e, e + 1 of the four positions x NT n-tiles (8 NT MFMAs); KW = operations younger than the load waited for
+    // (the NB U loads circulate in consumption order: the other NB - 1 are always younger, plus the chunk's DMA pieces while they sit behind them)
     auto half_step = [&](auto kw, auto first, int hg, auto last) {
         constexpr int KW = decltype(kw)::value;
         constexpr bool FIRST = decltype(first)::value;      // the very first half-step of the block: accumulate from zero
         constexpr bool LAST = decltype(last)::value;        // the last half-step of a single-chunk block: nothing left to refill
         const int e = 2 * hg;
-        // column combinations of the four positions first (8 VALU), then the 8 MFMAs
+        // column combinations of the four positions first (8 VALU), then the MFMAs
         float va[4], vb[4];
         va[0] = tq(t[0], e) - tq(t[2], e); vb[0] = tq(t[0], e + 1) - tq(t[2], e + 1);
         va[1] = tq(t[1], e) + tq(t[2], e); vb[1] = tq(t[1], e + 1) + tq(t[2], e + 1);
         va[2] = tq(t[2], e) - tq(t[1], e); vb[2] = tq(t[2], e + 1) - tq(t[1], e + 1);
         va[3] = tq(t[1], e) - tq(t[3], e); vb[3] = tq(t[1], e + 1) - tq(t[3], e + 1);
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (LAST && q == 1) u_wait<0>(bcur[q]);        // (no refill of bcur[0] behind it: nothing younger)
-            else u_wait<KW>(bcur[q]);
-            acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q], bcur[q].x, FIRST ? zero : acc[2 * q], 0, 0, 0);
-            acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q], bcur[q].y, acc[2 * q], 0, 0, 0);
-            acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q + 1], bcur[q].z, FIRST ? zero : acc[2 * q + 1], 0, 0, 0);
-            acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q + 1], bcur[q].w, acc[2 * q + 1], 0, 0, 0);
+        auto one = [&](auto qc, auto nc) {
+            constexpr int q = decltype(qc)::value, n = decltype(nc)::value, i = q * NT + n;
+            f32x4 &b = bcur[i];
+            if constexpr (LAST) u_wait<NB - 1 - i>(b);     // (no refills behind the last half-step: only the loads not consumed yet are younger)
+            else u_wait<KW>(b);
+            f32x16 &c0 = acc[4 * n + 2 * q], &c1 = acc[4 * n + 2 * q + 1];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q], b.x, FIRST ? zero : c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q], b.y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * q + 1], b.z, FIRST ? zero : c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[2 * q + 1], b.w, c1, 0, 0, 0);
             // refill (multi-chunk: unconditional, one half-step of slack behind the end of U)
-            if constexpr (!LAST) {
-                if (q == 0) u_load<0>(bcur[0], ulane, ub);
-                else u_load<1024>(bcur[1], ulane, ub);
-            }
-        }
-        ub += 16 * 64 * 2;
+            if constexpr (!LAST) u_issue(qc, nc);
+        };
+        one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (NT == 2) one(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        one(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        if constexpr (NT == 2) one(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        ub += 16 * 64 * 2; ub1 += 16 * 64 * 2;
     };
 
-    constexpr int KDMA = 1 + ((kAbl & 1) ? 0 : ND);     // while the chunk's DMA pieces sit younger than bcur's loads
+    constexpr int KU = NB - 1;                           // the other U loads in flight
+    constexpr int KDMA = KU + ((kAbl & 1) ? 0 : ND);    // while the chunk's DMA pieces sit younger than bcur's loads
     // one chunk: barrier, DMA of the next chunk, 4 quarter-steps of 2 half-steps (64 MFMAs per wave). Chunk 0 is peeled
     // (FIRST): its first half-step initialises the accumulators.
     auto chunk = [&](int cc, auto first) {
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
             chunk_barrier<0>();
             if constexpr (PRE) asm volatile("" : "+v"(ftv));
             off0[0][0] = ftv[0]; off0[0][1] = ftv[1]; off0[1][0] = ftv[2]; off0[1][1] = ftv[3];
-        } else chunk_barrier<2>();       // chunk cc has landed (two U refills stay in flight); everyone is done reading the other buffer
+        } else chunk_barrier<NB>();      // chunk cc has landed (the NB U refills stay in flight); everyone is done reading the other buffer
         if constexpr (FIRST) WINO_TS(2);
         set_frag_base((cc & 1) * BUF_FLOATS * 4);
         if constexpr (!ONE) dma(cc + 1, cc + 1 < nchunks);
@@ -533,14 +552,14 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             combine();
-            if (j == 0) half_step(std::integral_constant<int, ONE ? 1 : KDMA>{}, std::integral_constant<bool, FIRST>{}, 0, std::false_type{});
-            else half_step(std::integral_constant<int, 1>{}, std::false_type{}, 0, std::false_type{});
+            if (j == 0) half_step(std::integral_constant<int, ONE ? KU : KDMA>{}, std::integral_constant<bool, FIRST>{}, 0, std::false_type{});
+            else half_step(std::integral_constant<int, KU>{}, std::false_type{}, 0, std::false_type{});
             // the next quarter's fragments fly under the second half-step where the registers allow it (MT = 1)
             if constexpr (PREFETCH == 1) { if (j < 3) read_frag(j + 1); }
             // (the last half-step of a single-chunk block waits for bcur[0] with bcur[1]'s load as the only younger operation,
             // for bcur[1] with none)
-            if (ONE && j == 3) half_step(std::integral_constant<int, 1>{}, std::false_type{}, 1, std::true_type{});
-            else half_step(std::integral_constant<int, 1>{}, std::false_type{}, 1, std::false_type{});
+            if (ONE && j == 3) half_step(std::integral_constant<int, KU>{}, std::false_type{}, 1, std::true_type{});
+            else half_step(std::integral_constant<int, KU>{}, std::false_type{}, 1, std::false_type{});
             if constexpr (PREFETCH == 0) { if (j < 3) read_frag(j + 1); }
         }
     };
@@ -549,7 +568,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
         for (int cc = 1; cc < nchunks; ++cc) chunk(cc, std::false_type{});
     // drain the slack refills before their registers die
     WINO_TS(3);
-    if constexpr (!ONE) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
+    if constexpr (!ONE) {
+        if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3]));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bcur[0]), "+v"(bcur[1]));
+    }
     WINO_TS(4);
 
     if constexpr (kAbl & 512) {      // ablation: no epilogue at all (keeps the accumulators alive through one store)
@@ -562,22 +584,30 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
     // sets in LDS: k0 = s_01, k1 = s_10, k2 = s_11, k3 = s_20, k4 = s_21, k5 = s_30
     // The epilogue's global operands are requested first and land under the transform (the vector-memory queue is empty
     // here, so hipcc's own waits are exact again): bias, and this thread's store / pool table entries.
-    const bool nokl = n0 + fm < d.Nc;
-    const float bias = (d.bias && nokl) ? d.bias[n0 + fm] : 0.f;
+    float bias_n[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bias_n[n] = (d.bias && n0 + 32 * n + fm < d.Nc) ? d.bias[n0 + 32 * n + fm] : 0.f;
     uint2 se[4], pe = {0u, 0xffffffffu};
 #pragma unroll
     for (int q = 0; q < 4; ++q) se[q] = g.stab[q * NTHR + tid];
     pe = g.ptab[tid];       // (unconditional: under `if (d.y_pool)` hipcc merges the two values with a move right behind the load -- a drained queue)
     lds_barrier();
     WINO_TS(5);
+    const int n0_block = n0;
+    // one pass per n-tile of the wave (NT = 2: the second pass reuses the exchange sets and the transposed tile of the first)
+    auto epilogue = [&](auto nc) {
+    constexpr int NI_ = decltype(nc)::value;
+    const int n0 = n0_block + 32 * NI_;
+    const float bias = bias_n[NI_];
+    const f32x16 *accn = acc + 4 * NI_;
     // (one straight-line copy per position row: with `a` a run-time scalar the set choices below compile into ~40 scalar
     // branches, v_cndmask chains and 4-B LDS writes)
     const int act = ACT >= 0 ? ACT : d.act;
     switch (a) {
-    case 0: out_transform<MT, 0>(acc, smem, mt, lane, bias, act); break;
-    case 1: out_transform<MT, 1>(acc, smem, mt, lane, bias, act); break;
-    case 2: out_transform<MT, 2>(acc, smem, mt, lane, bias, act); break;
-    default: out_transform<MT, 3>(acc, smem, mt, lane, bias, act); break;
+    case 0: out_transform<MT, 0>(accn, smem, mt, lane, bias, act); break;
+    case 1: out_transform<MT, 1>(accn, smem, mt, lane, bias, act); break;
+    case 2: out_transform<MT, 2>(accn, smem, mt, lane, bias, act); break;
+    default: out_transform<MT, 3>(accn, smem, mt, lane, bias, act); break;
     }
     const float *ot = smem + MT * 6 * 16 * 64;         // the transposed tile: MT x 16 KB behind the exchange sets
     lds_barrier();
@@ -712,6 +742,11 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu((MT ==
                     }
         }
     }
+    // (the next n-tile's exchange sets overwrite what this pass's stores and skip items still read)
+    if constexpr (NI_ + 1 < NT) lds_barrier();
+    };
+    epilogue(std::integral_constant<int, 0>{});
+    if constexpr (NT == 2) epilogue(std::integral_constant<int, 1>{});
 #ifdef EVFLY_WINO_TS
     WINO_TS(7);
 #ifdef EVFLY_WINO_TS_PRE
@@ -769,7 +804,7 @@ __global__ void k_wino_weights(const float *__restrict__ w, int cout, int cin, i
 
 // MT: M-tiles per block; max_px: patch budget (pixels) of one LDS buffer
 // (tiles_y x tiles_x: the tile grid of the region to cover, at tile offset (ty_off, tx_off) of the map)
-bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px, int tiles_y, int tiles_x, int ty_off, int tx_off) {
+bool plan(const ConvDesc &d, WinoGeom &g, int MT, int NT, int max_px, int tiles_y, int tiles_x, int ty_off, int tx_off) {
     const int slots = 32 * MT;
     // cost of a plan ~ launched work: every block pays its tile slots (MFMA time, used or not) and its patch pixels
     // (DMA + LDS traffic; ~5 px per tile for a square arrangement, far more for thin ones; weight 0.06 slot per pixel)
@@ -797,7 +832,7 @@ bool plan(const ConvDesc &d, WinoGeom &g, int MT, int max_px, int tiles_y, int t
     g.ngroups = cdiv(g.npix, 8);
     g.ntiles = g.IMGS * g.TY * g.TX;
     g.by = cdiv(tiles_y, g.TY); g.bx = cdiv(tiles_x, g.TX); g.bi = cdiv(d.NI, g.IMGS);
-    g.n_nt = cdiv(d.Nc, 32);
+    g.n_nt = cdiv(d.Nc, 32 * NT);
     g.n_btiles = g.bx * g.by * g.bi;
     g.cpx = cdiv(g.n_btiles, kNumXCD);
     g.tab = nullptr; g.ftab = nullptr; g.stab = g.ptab = nullptr;
@@ -847,7 +882,7 @@ namespace {
 
 // kernel variant: M-tiles per block, DMA pieces per wave and chunk (one patch buffer = ND * 4 * MT KiB = ND * MT * 32
 // pixels), patch buffers
-struct WinoCfg { int MT, ND, nbuf; int max_px() const { return ND * MT * 32; } };
+struct WinoCfg { int MT, ND, nbuf, NT; int max_px() const { return ND * MT * 32; } };
 
 struct WinoRegion { WinoCfg c; WinoGeom g; };
 // one launch per region: the whole map, or two regions (a column or a row split of the tile grid) with their own arrangements
@@ -859,10 +894,21 @@ struct WinoPlan { WinoRegion r[kMaxRegions]; int nreg; double exec_flops, effici
 // forces one. Single-chunk layers on the non-persistent kernel (the fused first conv) need one buffer only.
 bool plan_region(const ConvDesc &d, int tiles_y, int tiles_x, int ty_off, int tx_off, WinoRegion &out) {
     static const int force = getenv("EVFLY_WINO_MT") ? atoi(getenv("EVFLY_WINO_MT")) : 0;
-    const WinoCfg c2{2, 5, 2}, c1{1, 6, 2};
-    WinoGeom g1, g2;
-    const bool ok1 = plan(d, g1, c1.MT, c1.max_px(), tiles_y, tiles_x, ty_off, tx_off);
-    const bool ok2 = plan(d, g2, c2.MT, c2.max_px(), tiles_y, tiles_x, ty_off, tx_off);
+    // round 6: 64 output channels per block (NT = 2: 32-tile blocks of four waves with eight accumulator tiles each, two blocks per CU) where
+    // C_out is a multiple of 64 and nothing is fused that the per-n-tile epilogue does not carry (the 1x1 consumer: C_out = 32 anyway).
+    // Same-box per-layer runs at the C2 shapes (tools/conv_sweep.py 200, NT = 1 -> 2): e32 -5.9 %, e42 -3.4 %, e51 -8 %, e52 -5 %, d11 -5.5 %,
+    // d12 -6 %, d22 -4.5 %, d31 -7.6 %, e31 -10 % in the model; worse where its 32-tile arrangement launches more tile slots than the best
+    // 32 / 64-tile plan (d21 +6.7 % slots: +3.4 % time; d32 +4.5 %: +4.4 %), on the single-chunk layer (e21: the four-blocks-per-CU kernel wins
+    // by 3-20 %) and on e22 (64 -> 64 with fused pool + skip: two epilogue passes behind two chunks, +3 % in the model). Hence the rule:
+    // at least two chunks, a 128-wide side, and a plan cost within 2 % of the NT = 1 plan's. EVFLY_WINO_NT=1 never, =2 wherever eligible.
+    static const int nt_force = getenv("EVFLY_WINO_NT") ? atoi(getenv("EVFLY_WINO_NT")) : 0;
+    static const double nt_f = getenv("EVFLY_WINO_NT_F") ? atof(getenv("EVFLY_WINO_NT_F")) : 1.02;
+    const bool nt2_ok = nt_force != 1 && d.Nc % 64 == 0 && !d.pre_frames && !d.dot_y;
+    const WinoCfg c2{2, 5, 2, 1}, c1{1, 6, 2, 1}, cn{1, 6, 2, 2};
+    WinoGeom g1, g2, gn;
+    const bool ok1 = plan(d, g1, c1.MT, 1, c1.max_px(), tiles_y, tiles_x, ty_off, tx_off);
+    const bool ok2 = plan(d, g2, c2.MT, 1, c2.max_px(), tiles_y, tiles_x, ty_off, tx_off);
+    const bool okn = nt2_ok && plan(d, gn, cn.MT, 2, cn.max_px(), tiles_y, tiles_x, ty_off, tx_off);
     bool use2;
     if (force) use2 = force == 2 ? ok2 : !ok1;
     // single-chunk layers (C_in = 32: e12, e21, d42): 64 MFMAs per wave between a cold patch and the output transform --
@@ -875,7 +921,12 @@ bool plan_region(const ConvDesc &d, int tiles_y, int tiles_x, int ty_off, int tx
     else use2 = ok1 && ok2 ? !(g1.cost < 0.995 * g2.cost) : ok2;
     out.c = use2 ? c2 : c1;
     out.g = use2 ? g2 : g1;
-    return use2 ? ok2 : ok1;
+    const bool ok = use2 ? ok2 : ok1;
+    if (okn && (nt_force == 2 || !ok || (d.C >= 64 && std::max(d.C, d.Nc) >= 128 && gn.cost <= nt_f * out.g.cost))) {
+        out.c = cn; out.g = gn;
+        return true;
+    }
+    return ok;
 }
 
 // Split plans: rectangular blocks of TY x TX tiles (x IMGS images) leave the last block row / column of a map partly empty
@@ -958,7 +1009,7 @@ WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
         double slots = 0;
         for (int i = 0; i < p.nreg; ++i) slots += (double)p.r[i].g.n_btiles * 32.0 * p.r[i].c.MT;
         // matrix-core flops the launch issues: 16 positions x tile slots x 32-channel slices x C_in, times 2
-        p.exec_flops = 2.0 * 16.0 * slots * ((double)p.g.n_nt * 32.0) * d.C;
+        p.exec_flops = 2.0 * 16.0 * slots * ((double)p.g.n_nt * 32.0 * p.c.NT) * d.C;
         p.efficiency = (double)d.NI * ty * tx / slots;
     }
     return p;
@@ -1087,7 +1138,7 @@ int plan_tables(const ConvDesc &d, const WinoRegion &p, WinoTables *out) {
     return 0;
 }
 
-template <int MT, int ND, bool ONE, bool PRE, int ACT>
+template <int MT, int ND, bool ONE, bool PRE, int ACT, int NT>
 int launch_act(const ConvDesc &d, const float *U, const WinoRegion &p, hipStream_t st) {
     const WinoGeom &g = p.g;
     // patch buffer(s); the epilogue reuses them for the exchange sets (MT x 24 KB) + the transposed tile (MT x 16 KB)
@@ -1095,7 +1146,7 @@ int launch_act(const ConvDesc &d, const float *U, const WinoRegion &p, hipStream
     int lds = std::max((ONE ? 1 : 2) * buf, MT * 40 * 1024);
     if (d.pre_frames)   // fused producer: formed frame patch + weights + bias behind the (single) patch buffer
         lds = std::max(lds, buf + (d.pre_cin * g.IMGS * (g.PH + 2) * (g.PW + 2) + 9 * d.pre_cin * 32 + 32) * 4);
-    auto kern = k_wino9<MT, ND, ONE, PRE, ACT>;
+    auto kern = k_wino9<MT, ND, ONE, PRE, ACT, NT>;
     // the > 64 KB dynamic-LDS opt-in is per device (one process may drive several GPUs)
     static std::atomic<bool> lds_set[64];
     int dev = 0;
@@ -1109,7 +1160,7 @@ int launch_act(const ConvDesc &d, const float *U, const WinoRegion &p, hipStream
     if (dbg) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256 * MT, lds);
-        fprintf(stderr, "wino9<%d,%d,%d>: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, %d B LDS, %d blocks/CU\n", MT, ND, (int)ONE,
+        fprintf(stderr, "wino9<%d,%d,%d,nt%d>: %dx%dx%d C%d N%d -> IMGS %d TY %d TX %d patch %d px, %d blocks x %d nt, %d B LDS, %d blocks/CU\n", MT, ND, (int)ONE, NT,
                 d.NI, d.OH, d.OW, d.C, d.Nc, g.IMGS, g.TY, g.TX, g.npix, g.n_btiles, g.n_nt, lds, nb);
     }
     WinoGeom gg = g;
@@ -1121,9 +1172,9 @@ int launch_act(const ConvDesc &d, const float *U, const WinoRegion &p, hipStream
     return 0;
 }
 
-template <int MT, int ND, bool ONE, bool PRE>
+template <int MT, int ND, bool ONE, bool PRE, int NT = 1>
 int launch(const ConvDesc &d, const float *U, const WinoRegion &p, hipStream_t st) {
-    return d.act == ACT_RELU ? launch_act<MT, ND, ONE, PRE, ACT_RELU>(d, U, p, st) : launch_act<MT, ND, ONE, PRE, -1>(d, U, p, st);
+    return d.act == ACT_RELU ? launch_act<MT, ND, ONE, PRE, ACT_RELU, NT>(d, U, p, st) : launch_act<MT, ND, ONE, PRE, -1, NT>(d, U, p, st);
 }
 
 }  // namespace
@@ -1171,7 +1222,11 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
         EVFLY_REQUIRE((int64_t)p.g.n_btiles * p.g.n_nt < (1 << 21) && p.g.bx < 2048 && p.g.by < 2048 && p.g.n_nt < 2048,
                       "wino: grid too large for the 32-bit magic divisions");
         int rc;
-        if (p.c.MT == 2)
+        // (NT = 2 has no single-chunk instance: in the straight-line chunk hipcc's instruction selection lets the MFMAs float below all 32 operand
+        // refills and parks the operands in scratch; e21 runs the chunk-loop kernel with one chunk -- its extra DMA issue is an empty descriptor)
+        if (p.c.NT == 2)
+            rc = p.c.MT == 2 ? launch<2, 5, false, false, 2>(d, U, p, st) : launch<1, 6, false, false, 2>(d, U, p, st);
+        else if (p.c.MT == 2)
             rc = !one ? launch<2, 5, false, false>(d, U, p, st) : pre ? launch<2, 5, true, true>(d, U, p, st) : launch<2, 5, true, false>(d, U, p, st);
         else
             rc = !one ? launch<1, 6, false, false>(d, U, p, st) : pre ? launch<1, 6, true, true>(d, U, p, st) : launch<1, 6, true, false>(d, U, p, st);
