@@ -638,7 +638,11 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
             # inputs resident, torch events on the launch stream. V = voxelize + condition, D = OrigUNet + ConvLSTM,
             # P = ViT + LSTM on 260x346 depth images (resize to 60x90 inside, like the composite's hand-off).
             fper = B * T
-            rates = {"v_only": {"frames_per_s": round(fper / ((vox_ms + cond_ms) * 1e-3), 1), "ms": round(vox_ms + cond_ms, 4), "what": "voxelize + crop/q97 conditioning"}}
+            rates = {"v_only": {"frames_per_s": round(fper / ((vox1_ms + cond_ms) * 1e-3), 1), "ms": round(vox1_ms + cond_ms, 4),
+                                "what": "voxelize FRESH events (pass 1 over the timestamps included: 13 B/event, stages.voxelize_with_pass1_*) + crop/q97 "
+                                        "conditioning; the timed step itself replays resident events whose pass-1 tables were prepared at upload "
+                                        "(stages.voxelize_ms)",
+                                "replayed_events": {"frames_per_s": round(fper / ((vox_ms + cond_ms) * 1e-3), 1), "ms": round(vox_ms + cond_ms, 4)}}}
             with torch.no_grad():
                 x = voxelizer.condition_frames(frames.view(B * T, H, W), out_hw=(H, W))
                 unet = model.origunet if composite else model

@@ -26,25 +26,32 @@ __device__ __forceinline__ int stream_of(const int64_t *__restrict__ offs, int n
 __global__ __launch_bounds__(256) void k_check_sorted(const int64_t *__restrict__ t, int64_t n,
                                                       const int64_t *__restrict__ offs, int n_streams,
                                                       int *__restrict__ unsorted) {
-    // each thread owns 4 consecutive events (two 16-B loads) + the first of the next quad
-    const int64_t nq = (n + 3) >> 2;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i0 = q << 2;
-        int64_t v[5];
-        if (i0 + 4 < n) {
-            const longlong2 a = *reinterpret_cast<const longlong2 *>(t + i0);
-            const longlong2 b = *reinterpret_cast<const longlong2 *>(t + i0 + 2);
-            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = t[i0 + 4];
+    // each thread owns 8 consecutive events (four 16-B loads, all in flight together); the event behind them is the first event of the
+    // next lane (one lane exchange) -- only the last lane of a wave loads it. (Round 6: the round-1 form read 40 B per 32 B of events in
+    // three dependent-free but narrow loads per thread and reached 2.2-2.8 TB/s at C2's 19.2 M events.)
+    const int64_t no = (n + 7) >> 3;
+    const int lane = threadIdx.x & 63;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q - lane < no; q += (int64_t)gridDim.x * blockDim.x) {      // (wave-uniform trip count)
+        const int64_t i0 = q << 3;
+        int64_t v[9];
+        if (i0 + 8 <= n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const longlong2 a = *reinterpret_cast<const longlong2 *>(t + i0 + 2 * k);
+                v[2 * k] = a.x; v[2 * k + 1] = a.y;
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) v[k] = (i0 + k < n) ? t[i0 + k] : INT64_MAX;
+            for (int k = 0; k < 8; ++k) v[k] = (i0 + k < n) ? t[i0 + k] : INT64_MAX;
         }
+        const int64_t nxt = __shfl_down(v[0], 1);
+        v[8] = lane == 63 ? ((i0 + 8 < n) ? t[i0 + 8] : INT64_MAX) : nxt;
         bool inv = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) inv |= (i0 + k + 1 < n) && (v[k] > v[k + 1]);
+        for (int k = 0; k < 8; ++k) inv |= (i0 + k + 1 < n) && (v[k] > v[k + 1]);
         if (inv) {
             // an inversion only counts inside one stream: locate it exactly (rare path)
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 if (i0 + k + 1 < n && v[k] > v[k + 1]) {
                     const int b = stream_of(offs, n_streams, i0 + k);
                     if (i0 + k + 1 < offs[b + 1]) unsorted[b] = 1;
@@ -54,21 +61,38 @@ __global__ __launch_bounds__(256) void k_check_sorted(const int64_t *__restrict_
     }
 }
 
-// pass 1b: window -> event range by binary search on the (sorted) timestamps of each stream.
+// pass 1b: window -> event range by search on the (sorted) timestamps of each stream.
 // starts[b*(T+1)+e] = first event index of stream b with t >= edge e.
-__global__ void k_window_ranges(const int64_t *__restrict__ t, const int64_t *__restrict__ offs,
-                                const int64_t *__restrict__ edges, int n_streams, int T,
-                                int64_t *__restrict__ starts) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per (stream, edge), 64-ary: every round the lanes probe 64 evenly spaced timestamps of the remaining range and a ballot picks
+// the sub-range -- three or four dependent memory round trips for a stream of 10^5..10^7 events instead of the 18-24 of a per-thread
+// binary search (which at C2 was ~20 us of pure latency in front of the accumulation kernel). Same answer: the lower bound is unique.
+__global__ __launch_bounds__(256) void k_window_ranges(const int64_t *__restrict__ t, const int64_t *__restrict__ offs,
+                                                       const int64_t *__restrict__ edges, int n_streams, int T,
+                                                       int64_t *__restrict__ starts, int *__restrict__ zero_a, int n_a, int *__restrict__ zero_b, int n_b) {
+    // (this launch runs FIRST and also clears the flag words the launches behind it set: the streams' `unsorted` flags and, inside
+    // evfly_voxelize_windows, the frames' overflow flags -- two memset launches less in front of the accumulation kernel)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_a; i += gridDim.x * blockDim.x) zero_a[i] = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_b; i += gridDim.x * blockDim.x) zero_b[i] = 0;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= n_streams * (T + 1)) return;
     const int b = idx / (T + 1);
     const int64_t edge = edges[idx];
-    int64_t lo = offs[b], hi = offs[b + 1];
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (t[mid] < edge) lo = mid + 1; else hi = mid;
+    int64_t lo = offs[b], hi = offs[b + 1];                  // invariant: t[i] < edge for i < lo, t[i] >= edge for i >= hi
+    while (hi - lo > 64) {
+        const int64_t step = (hi - lo + 63) >> 6;            // probes at lo + (lane + 1) * step - 1, clamped to hi - 1
+        const int64_t pos = min(lo + (int64_t)(lane + 1) * step - 1, hi - 1);
+        const bool below = t[pos] < edge;                    // monotone in the lane (sorted stream): a prefix of the lanes is below
+        const int k = (int)__popcll(__ballot(below));        // number of probes below the edge
+        const int64_t nlo = k == 0 ? lo : min(lo + (int64_t)k * step - 1, hi - 1) + 1;
+        const int64_t nhi = k == 64 ? hi : min(lo + (int64_t)(k + 1) * step - 1, hi - 1);
+        lo = nlo; hi = nhi;
     }
-    starts[idx] = lo;
+    {
+        const int64_t pos = lo + lane;
+        const bool below = pos < hi && t[pos] < edge;
+        lo += (int64_t)__popcll(__ballot(below));
+    }
+    if (lane == 0) starts[idx] = lo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -158,14 +182,14 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
         const unsigned dummy = (unsigned)(words + 2) + (threadIdx.x & 63u);
         const bool pm1 = a.pol_mode == EVFLY_POL_PM1;
         unsigned acc_s = 0;                                                // accepted events of this WAVE (scalar)
-        for (int64_t i0 = first + (int64_t)threadIdx.x * 8; i0 < hi; i0 += (int64_t)kVoxThreads * 8) {
-            uint4 xv, yv;
-            uint2 pv;
+        // (round 6: the loads of trip i + 1 are requested before trip i's events are processed -- the loop was half its time in s_waitcnt,
+        // one memory round trip per trip with nothing in flight behind it)
+        auto fetch = [&](int64_t i0, uint4 &xv, uint4 &yv, uint2 &pv) {
             if (i0 + 8 <= a.n_total) {
                 xv = *reinterpret_cast<const uint4 *>(a.x + i0);
                 yv = *reinterpret_cast<const uint4 *>(a.y + i0);
                 pv = *reinterpret_cast<const uint2 *>(a.p + i0);
-            } else {  // last partial vector of the arrays: never read past n_total
+            } else {  // last partial vector of the arrays (or a trip past the window): never read past n_total
                 unsigned xt[4] = {0, 0, 0, 0}, yt[4] = {0, 0, 0, 0}, pt[2] = {0, 0};
                 for (int k = 0; k < 8 && i0 + k < a.n_total; ++k) {
                     xt[k >> 1] |= (unsigned)a.x[i0 + k] << ((k & 1) * 16);
@@ -176,6 +200,17 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
                 yv = make_uint4(yt[0], yt[1], yt[2], yt[3]);
                 pv = make_uint2(pt[0], pt[1]);
             }
+        };
+        uint4 xn = make_uint4(0, 0, 0, 0), yn = xn;
+        uint2 pn = make_uint2(0, 0);
+        {
+            const int64_t i0 = first + (int64_t)threadIdx.x * 8;
+            if (i0 < hi) fetch(i0, xn, yn, pn);
+        }
+        for (int64_t i0 = first + (int64_t)threadIdx.x * 8; i0 < hi; i0 += (int64_t)kVoxThreads * 8) {
+            const uint4 xv = xn, yv = yn;
+            const uint2 pv = pn;
+            if (i0 + (int64_t)kVoxThreads * 8 < hi) fetch(i0 + (int64_t)kVoxThreads * 8, xn, yn, pn);
             const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
             const int rel0 = (int)(i0 - lo);                               // (>= -7; events of the partial vector past n_total: index >= hi)
 #pragma unroll
@@ -492,21 +527,29 @@ extern "C" int evfly_voxelize_windows_roi(const uint16_t *x, const uint16_t *y, 
 
 // Pass 1 on its own: the per-stream sortedness flags and the window -> event-range table depend on the timestamps and the
 // window edges only, i.e. they are a property of an uploaded batch, not of a voxelization call.
+namespace evfly {
+namespace {
+// pass 1; zero_extra: n_extra more flag words cleared by the first launch (the caller's overflow flags)
+int voxel_prepare_impl(const int64_t *t, int64_t n_events, const int64_t *stream_offsets, int n_streams, const int64_t *window_edges,
+                       int n_windows, int *unsorted_out, int64_t *starts_out, int *zero_extra, int n_extra, hipStream_t st) {
+    hipLaunchKernelGGL(k_window_ranges, dim3(cdiv(n_streams * (n_windows + 1), 4)), dim3(256), 0, st, t, stream_offsets, window_edges,
+                       n_streams, n_windows, starts_out, unsorted_out, n_streams, zero_extra, n_extra);
+    EVFLY_LAUNCH_CHECK();
+    if (n_events > 0) {
+        const int blocks = (int)std::min<int64_t>((int64_t)1 << 20, cdiv(cdiv(n_events, 8), 256));      // (one trip per thread: a grid-stride loop of 2048 blocks read 3.8 TB/s at C2)
+        hipLaunchKernelGGL(k_check_sorted, dim3(blocks), dim3(256), 0, st, t, n_events, stream_offsets, n_streams, unsorted_out);
+        EVFLY_LAUNCH_CHECK();
+    }
+    return 0;
+}
+}  // namespace
+}  // namespace evfly
+
 extern "C" int evfly_voxel_prepare(const int64_t *t, int64_t n_events, const int64_t *stream_offsets, int n_streams,
                                    const int64_t *window_edges, int n_windows, int *unsorted_out, int64_t *starts_out, void *stream) {
     EVFLY_REQUIRE(n_streams > 0 && n_windows > 0 && n_events >= 0, "voxel_prepare: empty geometry");
     EVFLY_REQUIRE(stream_offsets && window_edges && unsorted_out && starts_out, "voxel_prepare: null argument");
-    hipStream_t st = as_stream(stream);
-    EVFLY_HIP(hipMemsetAsync(unsorted_out, 0, (size_t)n_streams * 4, st));
-    if (n_events > 0) {
-        const int blocks = (int)std::min<int64_t>(8 * kNumCU, cdiv(cdiv(n_events, 4), 256));
-        hipLaunchKernelGGL(k_check_sorted, dim3(blocks), dim3(256), 0, st, t, n_events, stream_offsets, n_streams, unsorted_out);
-        EVFLY_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_window_ranges, dim3(cdiv(n_streams * (n_windows + 1), 128)), dim3(128), 0, st, t, stream_offsets, window_edges,
-                       n_streams, n_windows, starts_out);
-    EVFLY_LAUNCH_CHECK();
-    return 0;
+    return voxel_prepare_impl(t, n_events, stream_offsets, n_streams, window_edges, n_windows, unsorted_out, starts_out, nullptr, 0, as_stream(stream));
 }
 
 extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t *y, const int64_t *t, const int8_t *p,
@@ -534,13 +577,23 @@ extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t
 
     const int64_t *starts = prepared_starts;
     const int *unsorted = prepared_unsorted;
+    // optimistic mode's per-frame overflow flags (see below): allocated here so that pass 1's first launch can clear them
+    static const bool no_optimistic = getenv("EVFLY_VOX_NO_OPTIMISTIC") != nullptr;      // A/B switch
+    int *overflow = nullptr;
+    if (skip_kernels != 2 && !no_optimistic) {
+        void *fl = nullptr;
+        if (int rc = scratch_get(align_up((size_t)n_frames * 4, 256), &fl, st, 2)) return rc;
+        overflow = static_cast<int *>(fl);
+    }
+    bool overflow_cleared = false;
     if (!starts) {
         // scratch: starts[n_streams*(T+1)] i64 | unsorted[n_streams] i32
         void *scr = nullptr;
         const size_t starts_bytes = align_up((size_t)n_streams * (n_windows + 1) * 8, 256);
         if (int rc = scratch_get(starts_bytes + align_up((size_t)n_streams * 4, 256), &scr, st)) return rc;
-        if (int rc = evfly_voxel_prepare(t, n_events, stream_offsets, n_streams, window_edges, n_windows, (int *)((char *)scr + starts_bytes),
-                                         (int64_t *)scr, stream)) return rc;
+        if (int rc = voxel_prepare_impl(t, n_events, stream_offsets, n_streams, window_edges, n_windows, (int *)((char *)scr + starts_bytes),
+                                        (int64_t *)scr, overflow, overflow ? n_frames : 0, st)) return rc;
+        overflow_cleared = true;
         starts = (const int64_t *)scr;
         unsorted = (const int *)((char *)scr + starts_bytes);
     }
@@ -557,17 +610,15 @@ extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t
     // proves afterwards that no counter wrapped and flags the frame if one did) and the 32-bit kernel behind it takes the unsorted
     // streams and the flagged frames: a 480x640 sensor at 200 k events per window needs three row bands of 4-byte cells instead of five
     // of 8-byte ones, each of which reads the whole window (C3: 3.0 -> 2.0 ms per 2560 frames).
-    static const bool no_optimistic = getenv("EVFLY_VOX_NO_OPTIMISTIC") != nullptr;      // A/B switch
-    if (skip_kernels != 2 && !no_optimistic) {
-        void *fl = nullptr;
-        if (int rc = scratch_get(align_up((size_t)n_frames * 4, 256), &fl, st, 2)) return rc;
-        EVFLY_HIP(hipMemsetAsync(fl, 0, (size_t)n_frames * 4, st));
-        a.overflow = static_cast<int *>(fl);
+    if (overflow) {
+        if (!overflow_cleared) EVFLY_HIP(hipMemsetAsync(overflow, 0, (size_t)n_frames * 4, st));
+        a.overflow = overflow;
     }
     for (int general = 0; general < 2; ++general) {
         if (general == 1 ? skip_kernels == 2 : (skip_kernels == 1 && !a.overflow)) continue;      // this kernel owns no frame
         const int bytes_per_row = roi_width * (general ? 8 : 4);
-        const int rows_max = (kMaxLds - 16 - 256) / bytes_per_row;
+        static const int band_lds = getenv("EVFLY_VOX_BAND_LDS") ? atoi(getenv("EVFLY_VOX_BAND_LDS")) : kMaxLds;      // tuning switch: LDS budget of a band
+        const int rows_max = std::max(1, (std::min(band_lds, kMaxLds) - 16 - 256) / bytes_per_row);
         a.n_bands = cdiv(roi_height, rows_max);
         a.rows_per_band = cdiv(roi_height, a.n_bands);
         const int lds_bytes = (int)align_up((size_t)a.rows_per_band * bytes_per_row + 8 + 256, 16);

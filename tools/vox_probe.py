@@ -25,3 +25,13 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 by = 5.0 * n_events + 4.0 * B * T * 260 * 346
 print(f"{cname}: {B} streams x {T} windows, {n_events} events: {ms:.4f} ms per call, {by / ms / 1e6:.1f} GB/s of 5 B/event + frames = {by / ms / 1e6 / 8000:.3f} of 8 TB/s")
+# the same call on a batch WITHOUT the pass-1 tables (k_check_sorted + k_window_ranges run inside it: 13 B/event; bench.py's voxelize_with_pass1)
+ev2 = voxelizer.upload_events(batch, prepare=False)
+for _ in range(3):
+    voxelizer.voxelize_windows(ev2, Hs, Ws, out="f32", frames=frames, roi=roi)
+e0.record()
+for _ in range(reps):
+    voxelizer.voxelize_windows(ev2, Hs, Ws, out="f32", frames=frames, roi=roi)
+e1.record(); torch.cuda.synchronize()
+ms1 = e0.elapsed_time(e1) / reps
+print(f"  with pass 1: {ms1:.4f} ms per call (pass 1 = {ms1 - ms:.4f} ms, {8.0 * n_events / (ms1 - ms) / 1e6:.1f} GB/s of 8 B/event); both: {(by + 8.0 * n_events) / ms1 / 1e6 / 8000:.3f} of 8 TB/s")
