@@ -44,8 +44,8 @@ H, W = 260, 346
 PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, summarised per kernel family (first existing file wins)
-PMC_TRAFFIC = {"C2": ("r5_C2_pmc_traffic.json", "r4_C2_pmc_traffic.json", "r3_C2_pmc_traffic.json"), "C5": ("r5_C5_pmc_traffic.json", "r4_C5_pmc_traffic.json"),
-               "C3": ("r5_C3_pmc_traffic.json",)}
+PMC_TRAFFIC = {"C2": ("r6_C2_pmc_traffic.json", "r5_C2_pmc_traffic.json", "r4_C2_pmc_traffic.json", "r3_C2_pmc_traffic.json"),
+               "C5": ("r6_C5_pmc_traffic.json", "r5_C5_pmc_traffic.json", "r4_C5_pmc_traffic.json"), "C3": ("r6_C3_pmc_traffic.json", "r5_C3_pmc_traffic.json")}
 
 CONFIGS = {
     # The composite configs run the velocity model on a second HIP stream (evfly_amd/pipeline.py; --no-overlap: one stream). With the
