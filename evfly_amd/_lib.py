@@ -69,6 +69,7 @@ SIGNATURES = {
     "evfly_unet_forward": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "evfly_vit_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "evfly_vit_stage_forward": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "evfly_vit_block_forward": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "evfly_e2v_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "evfly_model_tap": (c_i64, [c_p, C.c_char_p, c_p, c_i64, C.POINTER(c_i64), c_p]),
     "evfly_model_set_profiling": (c_i, [c_p, c_i]),

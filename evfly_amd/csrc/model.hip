@@ -1300,6 +1300,52 @@ extern "C" int evfly_vit_stage_forward(evfly_model *m, int stage, const float *x
     return with_arena(m, body);
 }
 
+// ============================================================================ one half of a Mix-Transformer block on its own
+// EfficientSelfAttention.forward (ViTsubmodules.py:54-83: reduction conv + LayerNorm, key / value and query projections, softmax attention,
+// finalLayer -- WITHOUT the block's residual) or MixFFN.forward (:98-120: mlp1, grouped 3x3 conv, erf-GELU, mlp2 -- without residual and
+// LayerNorm) of layer `l` of stage `s`, on tokens (n, h * w, C). Exact-fp32 kernels, the launches vit_stage issues for the same step.
+static int vit_block_part(evfly_model *m, int s, int l, int part, const float *x, int n, int h, int w, float *y) {
+    const auto &c = m->cfg;
+    hipStream_t st = m->st;
+    const int C = c.vit_width[s], heads = c.vit_heads[s], R = c.vit_reduction[s], E = C * c.vit_expansion;
+    const int64_t rows = (int64_t)n * h * w;
+    const std::string NL = "s" + std::to_string(s) + "." + std::to_string(l) + ".";
+    if (part == EVFLY_VIT_PART_ATTENTION) {
+        const int rh = (h - R) / R + 1, rw = (w - R) / R + 1, nkv = rh * rw;
+        float *red = m->alloc_act((int64_t)n * nkv * C);
+        if (int rc = conv(m, "vit_kv_reduce_conv", NL + "red", x, n, h, w, C, C, C, R, R, R, 0, ACT_NONE, nullptr, 0, red, C, nullptr, nullptr,
+                          nullptr, 0, 0, 0, nullptr, 0)) return rc;
+        float *redn = m->alloc_act((int64_t)n * nkv * C);
+        RUN(m, "vit_layernorm", 0, 8.0 * n * nkv * C, launch_layernorm(red, nullptr, (int64_t)n * nkv, C, m->W(NL + "ln1.g"), m->W(NL + "ln1.beta"), redn, st));
+        float *kv = m->alloc_act((int64_t)n * nkv * 2 * C);
+        if (int rc = linear(m, "vit_linear", NL + "kv", redn, (int64_t)n * nkv, C, C, 2 * C, ACT_NONE, nullptr, 0, kv, 2 * C, 0)) return rc;
+        float *q = m->alloc_act(rows * C), *att = m->alloc_act(rows * C);
+        if (int rc = linear(m, "vit_linear", NL + "q", x, rows, C, C, C, ACT_NONE, nullptr, 0, q, C, 0)) return rc;
+        RUN(m, "vit_attention", 4.0 * rows * C * nkv, 8.0 * rows * C, launch_attention(q, kv, n, h * w, nkv, C, heads, att, st));
+        return linear(m, "vit_linear", NL + "fin", att, rows, C, C, C, ACT_NONE, nullptr, 0, y, C, 0);
+    }
+    float *h1 = m->alloc_act(rows * E), *h2 = m->alloc_act(rows * E);
+    if (int rc = linear(m, "vit_linear", NL + "mlp1", x, rows, C, C, E, ACT_NONE, nullptr, 0, h1, E, 0)) return rc;
+    if (gconv_fits(h, w, E))
+        RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 8.0 * rows * E, launch_gconv_gelu(h1, n, h, w, E, m->W(NL + "dw.wp"), m->W(NL + "dw.b"), h2, false, st));
+    else
+        RUN(m, "vit_grouped_conv_gelu", 2.0 * rows * E * 72, 8.0 * rows * E, launch_grouped_conv_gelu(h1, n, h, w, E, m->W(NL + "dw.w"), m->W(NL + "dw.b"), h2, st));
+    return linear(m, "vit_linear", NL + "mlp2", h2, rows, E, E, C, ACT_NONE, nullptr, 0, y, C, 0);
+}
+
+extern "C" int evfly_vit_block_forward(evfly_model *m, int stage, int layer, int part, const float *x, int n, int h, int w, float *y, void *stream) {
+    if (int rc = check_model(m, stream)) return rc;
+    EVFLY_REQUIRE(stage == 0 || stage == 1, "vit_block_forward: stage must be 0 or 1");
+    EVFLY_REQUIRE(layer >= 0 && layer < m->cfg.vit_layers[stage], "vit_block_forward: layer %d of %d", layer, m->cfg.vit_layers[stage]);
+    EVFLY_REQUIRE(part == EVFLY_VIT_PART_ATTENTION || part == EVFLY_VIT_PART_MIXFFN, "vit_block_forward: part must be EVFLY_VIT_PART_ATTENTION or _MIXFFN");
+    EVFLY_REQUIRE(x && y && n > 0 && h > 0 && w > 0, "vit_block_forward: null or empty argument");
+    EVFLY_REQUIRE(!m->act16, "vit_block_forward: the stand-alone block halves run in the exact-fp32 pipeline (compute_dtype f32)");
+    EVFLY_REQUIRE(part != EVFLY_VIT_PART_ATTENTION || (h >= m->cfg.vit_reduction[stage] && w >= m->cfg.vit_reduction[stage]),
+                  "vit_block_forward: a %d x %d token grid is smaller than the reduction ratio %d", h, w, m->cfg.vit_reduction[stage]);
+    auto body = [&]() { return vit_block_part(m, stage, layer, part, x, n, h, w, y); };
+    return with_arena(m, body);
+}
+
 extern "C" int evfly_e2v_forward(evfly_model *m, const float *frames, const float *desvel, int n_streams, int T,
                                  float *h_state, float *c_state, float *lstm_h, float *lstm_c, float *depth_out,
                                  float *upconv_out, float *vel_out, void *stream) {

@@ -291,6 +291,16 @@ int evfly_vit_forward(evfly_model *m, const float *img, int img_h, int img_w, in
 int evfly_vit_stage_forward(evfly_model *m, int stage, const float *x, int n, int h, int w,
                             float *y, void *stream);
 
+/* One half of a Mix-Transformer block on its own, for the reference's import-surface modules called alone: part
+ * EVFLY_VIT_PART_ATTENTION replaces EfficientSelfAttention.forward learner/ViTsubmodules.py:54-83 (reduction conv + LayerNorm, key / value
+ * and query projections, softmax(q k^T / sqrt(C / heads)) v, finalLayer; no residual), EVFLY_VIT_PART_MIXFFN replaces MixFFN.forward
+ * learner/ViTsubmodules.py:98-120 (mlp1, grouped 3x3 'same' conv, erf-GELU, mlp2; no residual, no LayerNorm), both for layer `layer`
+ * of trunk stage `stage` of the handle. x, y: tokens (n, h * w, C) fp32 = (n, h, w, C) NHWC. Exact-fp32 handles only. */
+#define EVFLY_VIT_PART_ATTENTION 1
+#define EVFLY_VIT_PART_MIXFFN 2
+int evfly_vit_block_forward(evfly_model *m, int stage, int layer, int part, const float *x, int n, int h, int w,
+                            float *y, void *stream);
+
 /* Replaces OrigUNet_w_VITFLY_ViTLSTM.forward learner/learner_models.py:629-636: U-Net, then
  * clip(2*depth, 0, 1), then the velocity head, without materialising the depth hand-off on the
  * host. Arguments as above. */

@@ -176,3 +176,43 @@ def test_op_grouped_conv_gelu(gpu_device, shape, bf16):
     _lib.check(L.evfly_op_grouped_conv_gelu(_lib.ptr(xi), n, h, w, ce, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y2), int(bf16), _lib.cur_stream()))
     torch.cuda.synchronize()
     assert torch.equal(y.view(torch.int16 if bf16 else torch.int32), y2.view(torch.int16 if bf16 else torch.int32))
+
+
+# ------------------------------------------------------------------ the Mix-Transformer sub-modules called on their own
+def test_vit_submodules_standalone_forward(gpu_device):
+    """`OverlapPatchMerging`, `EfficientSelfAttention`, `MixFFN` (learner/ViTsubmodules.py:21-34, 54-83, 98-120) are import-surface
+    symbols with forwards of their own: same signatures and return values as the reference's (tokens (B, N, C), H, W), run through
+    `evfly_vit_stage_forward` (a stage of zero layers) / `evfly_vit_block_forward`, against the oracle's restatement of each --
+    at the reference's two stage shapes and at the ViT-base widths (heads 4 / 8)."""
+    import evfly_amd.ViTsubmodules as vs
+    rs = np.random.RandomState(77)
+    # OverlapPatchMerging: (1 -> 32, 7x7 stride 4) on the 60 x 90 image and (32 -> 64, 3x3 stride 2) on its 15 x 23 map
+    for cin, cout, k, s, p, hw in ((1, 32, 7, 4, 3, (60, 90)), (32, 64, 3, 2, 1, (15, 23)), (128, 256, 3, 2, 1, (15, 23))):
+        pm = vs.OverlapPatchMerging(cin, cout, k, s, p)
+        sd = syn.fill_state_dict(pm.state_dict(), f"pm{cout}.")
+        pm.load_state_dict(sd)
+        x = torch.from_numpy(rs.standard_normal((2, cin) + hw).astype(np.float32))
+        tok, H, W = pm.to(gpu_device)(x.to(gpu_device))
+        y = F.conv2d(x, sd["cn1.weight"], sd["cn1.bias"], stride=s, padding=p)
+        want = F.layer_norm(y.flatten(2).transpose(1, 2), (cout,), sd["layerNorm.weight"], sd["layerNorm.bias"], 1e-5)
+        assert (H, W) == tuple(y.shape[2:]) and tok.shape == want.shape
+        assert rel_err(tok.cpu(), want) < 1e-4, (cout, rel_err(tok.cpu(), want))
+    for C, R, heads, (H, W) in ((32, 8, 1, (15, 23)), (64, 4, 2, (8, 12)), (128, 8, 4, (15, 23)), (256, 4, 8, (8, 12))):
+        x = torch.from_numpy(rs.standard_normal((3, H * W, C)).astype(np.float32))
+        att = vs.EfficientSelfAttention(C, R, heads)
+        sd = syn.fill_state_dict(att.state_dict(), f"esa{C}.")
+        att.load_state_dict(sd)
+        got = att.to(gpu_device)(x.to(gpu_device), H, W)
+        want = om.esa_forward(sd, "", x, H, W, R, heads)
+        assert got.shape == want.shape and rel_err(got.cpu(), want) < 1e-4, (C, rel_err(got.cpu(), want))
+        ffn = vs.MixFFN(C, 8)
+        sd = syn.fill_state_dict(ffn.state_dict(), f"ffn{C}.")
+        ffn.load_state_dict(sd)
+        got = ffn.to(gpu_device)(x.to(gpu_device), H, W)
+        want = om.mixffn_forward(sd, "", x, H, W, C)
+        assert got.shape == want.shape and rel_err(got.cpu(), want) < 1e-4, (C, rel_err(got.cpu(), want))
+    # CPU tensors in, CPU tensors out; a token count that does not match the grid is the caller's error
+    got = ffn(x, H, W)
+    assert got.device.type == "cpu"
+    with pytest.raises(ValueError):
+        ffn(x, H, W + 1)
