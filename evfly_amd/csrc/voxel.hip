@@ -120,6 +120,12 @@ struct VoxArgs {
     // optimistic mode (non-null): sorted windows with more than 65535 events are accumulated by the 16-bit kernel too, which proves
     // afterwards that no counter wrapped (sum of all halves == events it accepted) and flags the frame for the 32-bit kernel otherwise
     int *overflow;
+    // round 6: k_vox_frame ran first (one block per frame, 12-bit cells, every event visited once) and left overflow[frame] = 0 (done, or not
+    // its frame) or 2 (a 6-bit count wrapped: the 16-bit band kernel below redoes the frame; its own wrap then sets 1 for the 32-bit kernel)
+    int frame_first;
+    // frames [0, frame_first_n) are k_vox_frame's (whole rounds of one block per CU); the tail of a batch that would leave most CUs idle in
+    // a last round (C2: 320 frames on 256 CUs) goes to the band kernel, three shorter blocks per frame
+    int frame_first_n;
 };
 
 constexpr int kVoxThreads = 1024;
@@ -144,7 +150,8 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
     const bool optimistic = a.overflow != nullptr && (s1 - s0) < ((int64_t)1 << 31);      // (below 2^31 events the wrap check's 32-bit sums are exact)
     const bool fast_ok = sorted && (small || optimistic);
     if (!GENERAL && !fast_ok) return;                                  // the other instantiation owns this frame
-    if (GENERAL && sorted && (small || (optimistic && a.overflow[frame] == 0))) return;
+    if (!GENERAL && a.frame_first && frame < a.frame_first_n && a.overflow[frame] != 2) return;   // k_vox_frame has written this frame
+    if (GENERAL && sorted && (small || (optimistic && a.overflow[frame] != 1))) return;
     int64_t e0 = 0, e1 = 0;
     // GENERAL blocks own two kinds of frames: unsorted streams (scan the whole stream with the time test) and sorted
     // windows with more than 65535 events (480x640 sensors at 200 k events / window): the contiguous range like the fast
@@ -305,6 +312,152 @@ __global__ __launch_bounds__(kVoxThreads) void k_vox_band(VoxArgs a) {
             const int64_t cb = (int64_t)frame * 2 * a.RH * a.RW + (int64_t)r0 * a.RW + i;
             a.counts[cb] = (int32_t)P;
             a.counts[cb + (int64_t)a.RH * a.RW] = (int32_t)N;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2, round 6: one block = one FRAME, every event of the window visited ONCE.
+// The band kernel above pulls a window through three CUs (one per row band) and each of them rejects two thirds of what it reads: 58 % of
+// its time is the event loop, and the loop is bound by event visits (profiles/r5_vox_band_pmc.txt). A whole 260 x 346 histogram fits one
+// CU's LDS if a pixel takes 12 bits -- P and N as 6-bit counts, five pixels per 64-bit word (ds_add_u64): 144 KB. Counts above 63 per pixel,
+// sign and window do happen (hot pixels), so the block PROVES that nothing wrapped before it writes: every carry out of a 6-bit field
+// lowers the sum of all fields (by 63, or by 64 when it leaves the word's 60 bits) and nothing raises it, hence
+//     sum of fields == events accepted  <=>  no field wrapped  (the counts are then the true ones).
+// A frame that fails the proof is flagged (overflow[frame] = 2) and redone by the 16-bit band kernel behind this launch, which hands its
+// own (> 65535) wraps to the 32-bit kernel as before. Sorted streams only (the window is a contiguous range); others are left to the
+// 32-bit kernel. Output conversion: pos_thresh * P and neg_thresh * N come from two 64-entry f64 tables the block fills with the
+// reference's own products, so a pixel costs one f64 subtract and one rounding (to_events.py:409: the same two roundings, then the subtract).
+// ------------------------------------------------------------------------------------------
+constexpr int kFrameCellsPerWord = 5;
+// Ablation build switch for tools/scripts only (timing experiments; results are garbage): 1 no event loop, 2 no write-out, 4 no LDS atomics,
+// 8 no proof. The shipped library is built with 0.
+#ifndef EVFLY_VOXF_ABL
+#define EVFLY_VOXF_ABL 0
+#endif
+constexpr int kVoxfAbl = EVFLY_VOXF_ABL;
+__host__ __device__ inline int vox_frame_lds_bytes(int cells) { return ((cells + 4) / 5 + 64) * 8 + 2 * 64 * 8 + 16; }
+
+__global__ __launch_bounds__(kVoxThreads) void k_vox_frame(VoxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+    const int frame = blockIdx.x;
+    if (frame >= a.frame_first_n) {      // trailing blocks: clear the flags of the frames this kernel leaves to the band kernel
+        const int i = a.frame_first_n + (frame - a.frame_first_n) * kVoxThreads + (int)threadIdx.x;
+        if (i < a.n_frames) a.overflow[i] = 0;
+        return;
+    }
+    const int b = frame / a.T, w = frame - b * a.T;
+    const int64_t lo = a.starts[b * (a.T + 1) + w], hi = a.starts[b * (a.T + 1) + w + 1];
+    if (a.unsorted[b] != 0 || hi - lo >= ((int64_t)1 << 31)) {          // not this kernel's frame (block-uniform)
+        if (threadIdx.x == 0) a.overflow[frame] = 0;
+        return;
+    }
+    const int cells = a.RH * a.RW, words = (cells + kFrameCellsPerWord - 1) / kFrameCellsPerWord;
+    double *tp = reinterpret_cast<double *>(lds64 + words + 64), *tn = tp + 64;      // pos_thresh * P, neg_thresh * N for P, N in 0..63
+    unsigned *chk = reinterpret_cast<unsigned *>(tn + 64);                              // [0] sum of fields, [1] accepted events
+    for (int i = threadIdx.x; i < words + 64; i += kVoxThreads) lds64[i] = 0ull;      // (+ a scratch word per lane for rejected events)
+    if (threadIdx.x < 64) { tp[threadIdx.x] = a.pos_thresh * (double)threadIdx.x; tn[threadIdx.x] = a.neg_thresh * (double)threadIdx.x; }
+    if (threadIdx.x < 2) chk[threadIdx.x] = 0u;
+    __syncthreads();
+
+    const int64_t first = lo & ~int64_t(7);
+    const unsigned nrel = (unsigned)(hi - lo);
+    const int Wm1 = a.W - 1, Hm1 = a.H - 1, RHm1 = a.RH - 1, RWm1 = a.RW - 1;
+    const unsigned dummy = (unsigned)words + (threadIdx.x & 63u);
+    const bool pm1 = a.pol_mode == EVFLY_POL_PM1;
+    unsigned acc_s = 0;                                                    // accepted events of this WAVE (scalar)
+    // (one block per CU: the loads of trip i + 1 are requested before trip i's events are processed)
+    auto fetch = [&](int64_t i0, uint4 &xv, uint4 &yv, uint2 &pv) {
+        if (i0 + 8 <= a.n_total) {
+            xv = *reinterpret_cast<const uint4 *>(a.x + i0);
+            yv = *reinterpret_cast<const uint4 *>(a.y + i0);
+            pv = *reinterpret_cast<const uint2 *>(a.p + i0);
+        } else {  // last partial vector of the arrays: never read past n_total
+            unsigned xt[4] = {0, 0, 0, 0}, yt[4] = {0, 0, 0, 0}, pt[2] = {0, 0};
+            for (int k = 0; k < 8 && i0 + k < a.n_total; ++k) {
+                xt[k >> 1] |= (unsigned)a.x[i0 + k] << ((k & 1) * 16);
+                yt[k >> 1] |= (unsigned)a.y[i0 + k] << ((k & 1) * 16);
+                pt[k >> 2] |= (unsigned)(uint8_t)a.p[i0 + k] << ((k & 3) * 8);
+            }
+            xv = make_uint4(xt[0], xt[1], xt[2], xt[3]);
+            yv = make_uint4(yt[0], yt[1], yt[2], yt[3]);
+            pv = make_uint2(pt[0], pt[1]);
+        }
+    };
+    const int64_t hi_loop = (kVoxfAbl & 1) ? 0 : hi;
+    uint4 xn = make_uint4(0, 0, 0, 0), yn = xn;
+    uint2 pn = make_uint2(0, 0);
+    if (first + (int64_t)threadIdx.x * 8 < hi_loop) fetch(first + (int64_t)threadIdx.x * 8, xn, yn, pn);
+    for (int64_t i0 = first + (int64_t)threadIdx.x * 8; i0 < hi_loop; i0 += (int64_t)kVoxThreads * 8) {
+        const uint4 xv = xn, yv = yn;
+        const uint2 pv = pn;
+        if (i0 + (int64_t)kVoxThreads * 8 < hi_loop) fetch(i0 + (int64_t)kVoxThreads * 8, xn, yn, pn);
+        const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+        const int rel0 = (int)(i0 - lo);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ex = (int)((k & 1) ? xs[k >> 1] >> 16 : xs[k >> 1] & 0xffffu);
+            const int ey = (int)((k & 1) ? ys[k >> 1] >> 16 : ys[k >> 1] & 0xffffu);
+            const int ep = __builtin_amdgcn_sbfe((int)(k < 4 ? pv.x : pv.y), (k & 3) * 8, 8);
+            // the band kernel's sign-bit test (see there), with the whole region of interest as the band
+            const int cx = min(ex, Wm1) - a.rleft, cy = min(ey, Hm1) - a.rtop;
+            const int rel = rel0 + k;
+            const int pterm = pm1 ? ep * ep - 1 : ep;
+            const int bad = (cy | (RHm1 - cy) | cx) | ((RWm1 - cx) | rel | ((int)(nrel - 1u) - rel)) | ((a.W - ex) | (a.H - ey) | pterm);
+            const bool ok = bad >= 0;
+            const unsigned cell = (unsigned)(__mul24(cy, a.RW) + cx);
+            const unsigned wd = __umulhi(cell, 0xCCCCCCCDu) >> 2;                          // cell / 5 (exact for 32-bit cell)
+            const unsigned sh = (cell - 5u * wd) * 12u + (ep > 0 ? 0u : 6u);
+            if constexpr (kVoxfAbl & 4) acc_s += (wd ^ sh ^ dummy) & 1u;
+            else atomicAdd(&lds64[ok ? wd : dummy], ok ? (1ull << sh) : 0ull);
+            acc_s += (unsigned)__builtin_popcountll(__ballot(ok));
+        }
+    }
+    __syncthreads();
+    {   // the proof
+        unsigned sum = 0;
+        for (int i = threadIdx.x; i < words; i += kVoxThreads) {
+            unsigned long long v = lds64[i];
+            // ten 6-bit fields: pairwise into five 12-bit lanes (each <= 126), then across
+            const unsigned long long m = 0x03F03F03F03F03Full;                             // bits 0-5 of every 12-bit lane
+            v = (v & m) + ((v >> 6) & m);
+            sum += (unsigned)((v & 0xFFF) + ((v >> 12) & 0xFFF) + ((v >> 24) & 0xFFF) + ((v >> 36) & 0xFFF) + ((v >> 48) & 0xFFF));
+        }
+        unsigned accepted = (threadIdx.x & 63) == 0 ? acc_s : 0u;
+        for (int dlt = 32; dlt > 0; dlt >>= 1) { sum += __shfl_xor(sum, dlt); accepted += __shfl_xor(accepted, dlt); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&chk[0], sum); atomicAdd(&chk[1], accepted); }
+        __syncthreads();
+        const bool wrapped = (kVoxfAbl & (1 | 4 | 8)) ? false : chk[0] != chk[1];
+        if (threadIdx.x == 0) a.overflow[frame] = wrapped ? 2 : 0;
+        if (wrapped) return;
+    }
+    const int64_t fbase = (int64_t)frame * cells;
+    auto px = [&](int i, unsigned &P, unsigned &N) {
+        const unsigned wd = __umulhi((unsigned)i, 0xCCCCCCCDu) >> 2;
+        const unsigned long long v = lds64[wd] >> (((unsigned)i - 5u * wd) * 12u);
+        P = (unsigned)v & 63u; N = (unsigned)(v >> 6) & 63u;
+    };
+    const bool vec4 = (cells & 3) == 0 && a.f32 && !a.f64 && !a.counts && (((uintptr_t)a.f32) & 15) == 0;      // (block-uniform)
+    if (vec4) {
+        // four consecutive pixels per thread, one 16-B store (a 4-B store per lane is store-issue-bound at a third of this rate)
+        for (int i = threadIdx.x * 4; i < ((kVoxfAbl & 2) ? 0 : cells); i += kVoxThreads * 4) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { unsigned P, N; px(i + k, P, N); o[k] = (float)(tp[P] - tn[N]); }
+            *reinterpret_cast<float4 *>(a.f32 + fbase + i) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < ((kVoxfAbl & 2) ? 0 : cells); i += kVoxThreads) {
+        unsigned P, N;
+        px(i, P, N);
+        const double f = tp[P] - tn[N];
+        if (a.f32) a.f32[fbase + i] = (float)f;
+        if (a.f64) a.f64[fbase + i] = f;
+        if (a.counts) {
+            const int64_t cb = 2 * fbase + i;
+            a.counts[cb] = (int32_t)P;
+            a.counts[cb + cells] = (int32_t)N;
         }
     }
 }
@@ -579,8 +732,12 @@ extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t
     const int *unsorted = prepared_unsorted;
     // optimistic mode's per-frame overflow flags (see below): allocated here so that pass 1's first launch can clear them
     static const bool no_optimistic = getenv("EVFLY_VOX_NO_OPTIMISTIC") != nullptr;      // A/B switch
+    // round 6: the frame kernel (k_vox_frame: every event visited once, 12-bit cells with a wrap proof) goes first wherever the region of
+    // interest fits one CU's LDS at 12 bits per pixel; it needs the per-frame flags in every mode. EVFLY_VOX_NO_FRAME=1: A/B switch.
+    static const bool no_frame = getenv("EVFLY_VOX_NO_FRAME") != nullptr;
+    const bool frame_first = !no_frame && !no_optimistic && vox_frame_lds_bytes(roi_height * roi_width) <= kMaxLds;
     int *overflow = nullptr;
-    if (skip_kernels != 2 && !no_optimistic) {
+    if ((skip_kernels != 2 && !no_optimistic) || frame_first) {
         void *fl = nullptr;
         if (int rc = scratch_get(align_up((size_t)n_frames * 4, 256), &fl, st, 2)) return rc;
         overflow = static_cast<int *>(fl);
@@ -592,7 +749,7 @@ extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t
         const size_t starts_bytes = align_up((size_t)n_streams * (n_windows + 1) * 8, 256);
         if (int rc = scratch_get(starts_bytes + align_up((size_t)n_streams * 4, 256), &scr, st)) return rc;
         if (int rc = voxel_prepare_impl(t, n_events, stream_offsets, n_streams, window_edges, n_windows, (int *)((char *)scr + starts_bytes),
-                                        (int64_t *)scr, overflow, overflow ? n_frames : 0, st)) return rc;
+                                        (int64_t *)scr, overflow, (overflow && !frame_first) ? n_frames : 0, st)) return rc;
         overflow_cleared = true;
         starts = (const int64_t *)scr;
         unsorted = (const int *)((char *)scr + starts_bytes);
@@ -611,8 +768,23 @@ extern "C" int evfly_voxelize_windows_prepared(const uint16_t *x, const uint16_t
     // streams and the flagged frames: a 480x640 sensor at 200 k events per window needs three row bands of 4-byte cells instead of five
     // of 8-byte ones, each of which reads the whole window (C3: 3.0 -> 2.0 ms per 2560 frames).
     if (overflow) {
-        if (!overflow_cleared) EVFLY_HIP(hipMemsetAsync(overflow, 0, (size_t)n_frames * 4, st));
+        if (!overflow_cleared && !frame_first) EVFLY_HIP(hipMemsetAsync(overflow, 0, (size_t)n_frames * 4, st));      // (the frame kernel writes every frame's flag)
         a.overflow = overflow;
+    }
+    if (frame_first) {
+        // whole rounds of one block per CU for the frame kernel; a remainder whose three band blocks per frame fit ONE round of the band
+        // kernel (3 rem <= CUs) goes there -- a band block is shorter than a frame block, and the frame kernel's last round would leave
+        // most CUs idle (C2's 320 frames = 256 + 64: 0.072 -> 0.063 ms; a single deployment frame: three CUs instead of one). A larger
+        // remainder costs two band rounds, more than one frame round (C3's window size, 640 frames: 0.26 ms all-frame, 0.30 split).
+        static const int tail_force = getenv("EVFLY_VOX_FRAME_TAIL") ? atoi(getenv("EVFLY_VOX_FRAME_TAIL")) : -1;      // A/B: 0 never split, 1 always
+        const int rem = n_frames % kNumCU;
+        const bool split = tail_force >= 0 ? tail_force != 0 : 3 * rem <= kNumCU;
+        a.frame_first = 1;
+        a.frame_first_n = split ? n_frames - rem : n_frames;
+        const int extra = cdiv(n_frames - a.frame_first_n, kVoxThreads);
+        if (int rc = set_max_lds(k_vox_frame, kMaxLds)) return rc;
+        hipLaunchKernelGGL(k_vox_frame, dim3(a.frame_first_n + extra), dim3(kVoxThreads), vox_frame_lds_bytes(roi_height * roi_width), st, a);
+        EVFLY_LAUNCH_CHECK();
     }
     for (int general = 0; general < 2; ++general) {
         if (general == 1 ? skip_kernels == 2 : (skip_kernels == 1 && !a.overflow)) continue;      // this kernel owns no frame
