@@ -165,7 +165,7 @@ def test_c4_shard_256_streams_vit_base(gpu_device, base_trunk):
 
 def test_c3_model_2560_frames_bf16_base(gpu_device, base_trunk):
     """BASELINE config C3's model at its launch plan: 256 streams x 10 windows = 2560 conditioned frames through the TWO-STREAM pipeline in
-    bf16 with the ViT-base trunk (640-frame chunks, the one-launch ConvLSTM recurrence `k_clstm16_seq`, `k_mixffn16<256, 2>` at full grids),
+    bf16 with the ViT-base trunk (640-frame chunks, the one-launch ConvLSTM recurrence (6 656 state rows per chunk: the cooperative kernel `k_clstm16_coop` with its gated stand-by), `k_mixffn16<256, 2>` at full grids),
     three sampled streams (first chunk, a middle one, the last stream) against the fp32 oracle at the bf16 bars -- the twin of
     test_c4_shard_256_streams_vit_base. (Frames from syn.make_frames: the 512 M events of the bench are the voxelizer's test, not this one's.)"""
     import evfly_amd.learner_models as lm
