@@ -614,7 +614,10 @@ def run_config(a, cname, cfg, rank, world, dist, detail):
         if os.environ.get("BENCH_DUMP_LAYERS"):      # developer switch: every launch site of the bracketed step, not only the families
             out["layers"] = [{"name": p["name"], "ms": round(p["ms"], 4), "launches": p["launches"],
                               "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1) if p["flops"] and p["ms"] else None,
-                              "gbs": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] else None} for p in layers]
+                              "gbs": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] else None,
+                              "slot_fill": round(p["useful_flops"] / p["exec_flops"], 4) if p.get("exec_flops") and p.get("useful_flops") else None,
+                              "issued_frac_of_peak": round(p["exec_flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK[dtype], 3) if p.get("exec_flops") and p["ms"] else None}
+                             for p in layers]
         out["conv_layers"] = [{"name": p["name"], "ms_per_step": round(p["ms"], 3),
                                "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)}
                               for p in layers if p["name"].startswith(dom["name"] + "/")]

@@ -422,7 +422,11 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(NT == 
         u_first();
         // the tables have landed (they are older than the two U loads, which stay in flight)
         if constexpr (ND == 5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(ftv) : "n"(NB));
-        else asm volatile("s_waitcnt vmcnt(%7)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(ftv) : "n"(NB));
+        else if constexpr (ND == 6) asm volatile("s_waitcnt vmcnt(%7)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(ftv) : "n"(NB));
+        else {
+            static_assert(ND == 5 || ND == 6 || ND == 8, "the table wait names every entry");
+            asm volatile("s_waitcnt vmcnt(%9)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(te[6]), "+v"(te[7]), "+v"(ftv) : "n"(NB));
+        }
     }
     if constexpr (!produced) {
         // descriptor from the block's patch origin (img0, iy0, ix0) to the end of its image group: images past the batch
@@ -904,7 +908,10 @@ bool plan_region(const ConvDesc &d, int tiles_y, int tiles_x, int ty_off, int tx
     static const int nt_force = getenv("EVFLY_WINO_NT") ? atoi(getenv("EVFLY_WINO_NT")) : 0;
     static const double nt_f = getenv("EVFLY_WINO_NT_F") ? atof(getenv("EVFLY_WINO_NT_F")) : 1.02;
     const bool nt2_ok = nt_force != 1 && d.Nc % 64 == 0 && !d.pre_frames && !d.dot_y;
-    const WinoCfg c2{2, 5, 2, 1}, c1{1, 6, 2, 1}, cn{1, 6, 2, 2};
+    // (NT = 2 blocks run two per CU by their registers: a 32 KB patch buffer -- 256 pixels instead of 192 -- fits, and with it arrangements that fill
+    // the 32 tile slots of the small deep maps better: EVFLY_WINO_NT_ND=6 keeps the 24 KB buffer for A/B runs)
+    static const int nt_nd = getenv("EVFLY_WINO_NT_ND") ? atoi(getenv("EVFLY_WINO_NT_ND")) : 8;
+    const WinoCfg c2{2, 5, 2, 1}, c1{1, 6, 2, 1}, cn{1, nt_nd == 6 ? 6 : 8, 2, 2};
     WinoGeom g1, g2, gn;
     const bool ok1 = plan(d, g1, c1.MT, 1, c1.max_px(), tiles_y, tiles_x, ty_off, tx_off);
     const bool ok2 = plan(d, g2, c2.MT, 1, c2.max_px(), tiles_y, tiles_x, ty_off, tx_off);
@@ -1110,7 +1117,7 @@ int plan_tables(const ConvDesc &d, const WinoRegion &p, WinoTables *out) {
     int dev = 0;
     EVFLY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_tuple(std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, d.ldx, d.ldy, dev), p.c.MT, p.g.IMGS, p.g.TY, p.g.TX);
+    const auto key = std::make_tuple(std::make_tuple(d.NI, d.OH, d.OW, d.C, d.Nc, d.ldx, d.ldy, dev), p.c.MT * 100 + p.c.ND, p.g.IMGS, p.g.TY, p.g.TX);
     auto it = cache.find(key);
     if (it == cache.end()) {
         const int MT = p.c.MT, npieces = p.c.ND * 4 * MT, nthr = 256 * MT;
@@ -1225,7 +1232,7 @@ int wino_launch(const ConvDesc &d, const float *U, hipStream_t st) {
         // (NT = 2 has no single-chunk instance: in the straight-line chunk hipcc's instruction selection lets the MFMAs float below all 32 operand
         // refills and parks the operands in scratch; e21 runs the chunk-loop kernel with one chunk -- its extra DMA issue is an empty descriptor)
         if (p.c.NT == 2)
-            rc = p.c.MT == 2 ? launch<2, 5, false, false, 2>(d, U, p, st) : launch<1, 6, false, false, 2>(d, U, p, st);
+            rc = p.c.MT == 2 ? launch<2, 5, false, false, 2>(d, U, p, st) : p.c.ND == 8 ? launch<1, 8, false, false, 2>(d, U, p, st) : launch<1, 6, false, false, 2>(d, U, p, st);
         else if (p.c.MT == 2)
             rc = !one ? launch<2, 5, false, false>(d, U, p, st) : pre ? launch<2, 5, true, true>(d, U, p, st) : launch<2, 5, true, false>(d, U, p, st);
         else
