@@ -1006,7 +1006,8 @@ WinoPlan make_plan(const ConvDesc &d, bool allow_split) {
             return best;
         };
         // (depth 2 -- up to four launches, 41 per C2 step -- measured as a wash: e31 / d11 -2..3 %, d21 / d31 / d22 / d42 +2..3 %)
-        const Part pt = part(ty, tx, 0, 0, 1);
+        static const int split_depth = getenv("EVFLY_WINO_SPLIT_DEPTH") ? atoi(getenv("EVFLY_WINO_SPLIT_DEPTH")) : 1;      // tuning switch
+        const Part pt = part(ty, tx, 0, 0, split_depth);
         p.nreg = (int)pt.regs.size();
         for (int i = 0; i < p.nreg; ++i) p.r[i] = pt.regs[i];
     }
